@@ -106,4 +106,11 @@ def test_g7_training_trace(golden):
     for k, v in f["final_small_params"].items():
         if k.endswith("masked_bias"):
             continue
-        torch.testing.assert_close(sd[k], v, rtol=2e-3, atol=2e-4)
+        if k.endswith("c_attn.bias"):
+            # the K third of the qkv bias has a mathematically zero gradient (softmax is
+            # invariant to a per-query shift): Adam normalises pure rounding noise there.
+            d = cfg.embed_dim
+            torch.testing.assert_close(sd[k][:d], v[:d], rtol=2e-3, atol=2e-5)
+            torch.testing.assert_close(sd[k][2 * d:], v[2 * d:], rtol=2e-3, atol=2e-5)
+            continue
+        torch.testing.assert_close(sd[k], v, rtol=2e-3, atol=2e-5)
