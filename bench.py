@@ -1,0 +1,193 @@
+#!/usr/bin/env python
+"""Benchmark of the hot path: full training steps (pack -> fwd -> loss -> bwd -> [RCCL all-reduce] -> clip ->
+AdamW) of the 768d x 6L x 24H Gato policy on fixed-shape synthetic multimodal sequences (T = 1024).
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task statement).  metric = BASELINE.json's
+"multimodal tokens/sec (fwd+bwd)", value = whole-job tokens/s with inputs resident on the device,
+T counts every position of the padded sequence.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+D, L, H, T, V_TEXT = 768, 6, 24, 1024, 50257
+V = V_TEXT + 2048
+MFMA_PEAK_TFLOPS = 2500.0      # dense bf16, MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def flops_per_token_fwd(d=D, layers=L, t=T, v=V):
+    """linear layers 24 d^2, causal attention at its useful half 2 d (T+1), LM head 2 d V."""
+    return layers * (24 * d * d + 2 * d * (t + 1)) + 2 * d * v
+
+
+def make_batch(workload: str, B: int, seed: int, device):
+    from neko_amd.tasks import synthetic as S
+    if workload == "m-mix":
+        return S.metric_mix_batch(B, seed, device)
+    if workload == "m-text":
+        return S.SyntheticTextTask(1023, V_TEXT, seed=seed, device=device).sample_batch(B)
+    if workload == "c2":   # halfcheetah-shaped, T = 240
+        return S.SyntheticControlTask(17, 6, 10, seed=seed, device=device).sample_batch(B)
+    raise ValueError(workload)
+
+
+def cpu_baseline(seconds_budget: float = 30.0):
+    """The CPU oracle (plain PyTorch fp32 restatement of the reference path, pinned to reference fixtures)
+    timed on this box's host cores on a bounded sample of the same workload: ONE text sequence of
+    T=1024 (1023 ids + SEP) through the same 768d x 6L x 24H model, forward + backward."""
+    from oracle import neko_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = O.OracleConfig(embed_dim=D, layers=L, heads=H, text_tokens=V_TEXT, context_len=T)
+    sd = O.init_state_dict(cfg, 0)
+    g = torch.Generator().manual_seed(1234)
+    batch = [{"text": torch.randint(0, V_TEXT, (T - 1,), generator=g).tolist()}]
+    t0 = time.time()
+    n = 0
+    while True:
+        O.loss_and_grads(sd, cfg, batch)
+        n += 1
+        el = time.time() - t0
+        if n >= 2 or el > seconds_budget * 0.5:
+            break
+    return {"value": n * T / el, "unit": "tokens/s", "cores": cores, "kind": "port",
+            "sample": f"{n} x (B=1, T=1024 text) fwd+bwd of the 768d/6L/24H model, fp32, torch CPU threads={cores}"}
+
+
+def time_dominant_kernel(model, rows: int, iters: int = 10):
+    """The LM-head logits GEMM (rows x 768 @ 768 x 52305, bf16 MFMA) is the largest single kernel of the step.
+    Timed with HIP events on the stream it is launched on (torch's current stream)."""
+    from neko_amd import ops
+    hp = model._head_params()
+    a = torch.randn(rows, D, device="cuda").to(torch.bfloat16)
+    out = torch.empty(rows, hp.Vpad, dtype=torch.float32, device="cuda")
+    for _ in range(2):
+        ops.gemm(a, hp.w, rows, hp.V, D, ldb=D, out_f32=out, ldcf=hp.Vpad)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        ops.gemm(a, hp.w, rows, hp.V, D, ldb=D, out_f32=out, ldcf=hp.Vpad)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    flops = 2.0 * rows * D * hp.V
+    return {"kernel": "gemm_bf16_kernel<A k-contig, B k-contig> (LM head logits)", "shape": [rows, hp.V, D],
+            "ms": ms, "tflops": flops / ms / 1e9}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="sequences per GPU per step")
+    ap.add_argument("--workload", default="m-mix", choices=["m-mix", "m-text", "c2"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-optimizer", action="store_true", help="time fwd+bwd(+all-reduce) only")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.distributed.init_process_group("nccl", device_id=dev)
+
+    from neko_amd.dp import GradReducer
+    from neko_amd.policy.gato_policy import GatoPolicy
+    from neko_amd.training.optim import NekoAdamW
+
+    torch.manual_seed(0)
+    dropout = 0.0   # HIP dropout kernels not implemented yet; the reference trains with 0.1
+    model = GatoPolicy(dev, D, L, H, dropout, resid_mid_channels=128, context_len=T, text_tokenizer=V_TEXT)
+    model.transformer.drop.p = 0.0
+    model.train()
+    opt = NekoAdamW(model, lr=1e-4, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.1)
+    dp = None
+    if world > 1:
+        dp = GradReducer(model._flat)
+        dp.broadcast_parameters()
+        dp.attach(model, opt)
+
+    B = args.batch
+    batches = [make_batch(args.workload, B, 1234 + rank + 100 * i, dev) for i in range(2)]
+    Tlen = 240 if args.workload == "c2" else T
+
+    def step(i):
+        _, loss = model.forward(inputs=batches[i % len(batches)], compute_loss=True, return_logits=False)
+        loss.backward()
+        if dp is not None:
+            dp.flush()
+            dp.finish()
+        if not args.no_optimizer:
+            opt.clip_grad_norm_(1.0)
+            opt.step()
+        opt.zero_grad()
+        return loss
+
+    for i in range(args.warmup):
+        loss = step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        el = float(t)
+
+    if rank == 0:
+        tokens = world * B * Tlen * args.steps
+        value = tokens / el
+        fpt = 3 * flops_per_token_fwd(t=Tlen)
+        dom = time_dominant_kernel(model, min(4096, B * Tlen))
+        out = {
+            "metric": "multimodal tokens/sec (fwd+bwd+optimizer, whole job)", "value": value, "unit": "tokens/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+            "data": "synthetic",
+            "config": {"workload": f"{args.workload}: 768d x 6L x 24H (hd=32), V=52305, T={Tlen}, "
+                                   f"{B} sequences/GPU/step, dropout {dropout}, "
+                                   f"{'fwd+bwd only' if args.no_optimizer else 'fwd+bwd+clip+AdamW'}",
+                       "global_batch": world * B, "seq_len": Tlen, "parallelism": f"dp{world}"},
+            "tokens_per_sec_per_gpu": value / world,
+            "final_loss": float(loss),
+            "step_mfma_frac": value / world * fpt / (MFMA_PEAK_TFLOPS * 1e12),
+            "flops_per_token_fwd_bwd": fpt,
+            "roofline": {"bound": "mfma", "achieved": dom["tflops"], "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": dom["tflops"] / MFMA_PEAK_TFLOPS, "traffic": None, "kernel": dom["kernel"],
+                         "shape_MNK": dom["shape"], "ms_per_launch": dom["ms"]},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,174 @@
+/*
+ * neko_hip.h -- C ABI of libneko_hip.so: the MI355X (gfx950) hot path of ManifoldRG/NEKO's
+ * Gato-style policy (forward + backward of gato.policy.GatoPolicy / gato.transformers.GPT2Model
+ * and the optimiser tail of Trainer.train_step).
+ *
+ * The reference is pure Python and has NO FFI / plugin interface; the
+ * seam it offers is a Python call signature.  Each entry point below therefore names the reference
+ * expression it replaces (file:line relative to the reference root); the Python binding a NEKO
+ * maintainer would add is shown in INTEGRATION.md and implemented in neko_amd/_lib.py (ctypes).
+ *
+ * Conventions
+ *  - plain C: raw device pointers, explicit sizes / leading dimensions (in ELEMENTS), a HIP stream
+ *    passed as void* (hipStream_t).  No torch types, no global state, no allocation: every buffer
+ *    (inputs, outputs, workspaces) is owned by the caller for the duration of the enqueued work.
+ *  - every call only ENQUEUES kernels on `stream` and returns immediately.
+ *  - return value: 0 = ok; NEKO_ERR_ARG (-1) bad argument; NEKO_ERR_UNSUPPORTED (-2) shape outside
+ *    the supported set; <= -3: launch failure, value = -3 - hipError_t.  Nothing throws.
+ *  - bf16 tensors are `uint16_t` bit patterns; "f32" = float; row-major everywhere.
+ *  - thread model: one host thread per process, one process per GPU (the Accelerate launch model
+ *    of train.py:33-41).
+ */
+#ifndef NEKO_HIP_H
+#define NEKO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NEKO_OK 0
+#define NEKO_ERR_ARG (-1)
+#define NEKO_ERR_UNSUPPORTED (-2)
+#define NEKO_ERR_LAUNCH (-3)
+
+#define NEKO_ABI_VERSION 1
+
+int neko_abi_version(void);
+/* human-readable text for a return code (static storage) */
+const char* neko_status_string(int code);
+
+/* ---------------------------------------------------------------------------------------------
+ * GEMM with fused epilogue -- HF Conv1D `torch.addmm(bias, x.view(-1,in), W)` with W stored
+ * (in,out) (gato/transformers/trajectory_gpt2.py:139-141,222,253,264-265,274,277), the exact-erf
+ * GELU of MLP.forward (:274), the residual adds of Block.forward (:333,355), nn.Linear
+ * predict_token / post_embedding_projection (gato/policy/gato_policy.py:122,172;
+ * gato/policy/embeddings.py:24,53) and the dgrad / wgrad contractions autograd derives from them.
+ *
+ *   C[M,N] = alpha * opA(A)[M,K] x opB(B)[K,N]  (+ bias[N])  (act)  (+ resid[M,N])  (+ C)
+ *   alpha_dev (may be null): device scalar multiplied into alpha (autograd's grad_output, no host sync)
+ *   a_kstrided = 0: A[m*lda + k]        1: A[k*lda + m]   (wgrad: X^T)
+ *   b_kstrided = 0: B[n*ldb + k]        1: B[k*ldb + n]   (Conv1D weight (in,out))
+ *   act = 0 none | 1 GELU (pre-activation rounded to bf16 first; optionally stored to pre_out)
+ *         | 2 multiply by GELU'(act_in[m,n])  (dgrad through the MLP activation)
+ *   outputs: Cf (f32) and/or Cb (bf16); accumulate != 0: Cf += result.
+ *   splitk > 1: K is cut in `splitk` slices of k_per_split (multiple of 64) reduced with f32
+ *   atomics into Cf (caller zeroes Cf or wants accumulation; act must be 0, Cb null).
+ *   Contract: contiguous extents and leading dims are multiples of 8 elements.
+ *   safe_transpose != 0 selects the transposing-store fallback for k-strided operands (debug).
+ * ------------------------------------------------------------------------------------------- */
+int neko_gemm_bf16(const uint16_t* A, long lda, int a_kstrided, const uint16_t* B, long ldb, int b_kstrided,
+                   int M, int N, int K, float alpha, const float* alpha_dev, const float* bias, const float* resid,
+                   long ldr, int act,
+                   const uint16_t* act_in, long ldact, uint16_t* pre_out, long ldpre, float* Cf, long ldcf,
+                   int accumulate, uint16_t* Cb, long ldcb, int splitk, int k_per_split, int safe_transpose,
+                   void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * LayerNorm -- nn.LayerNorm(d, eps) ln_1 / ln_2 / ln_f (trajectory_gpt2.py:301,303,323,353,543,779).
+ * fwd: x f32 [M,d] -> y16 (bf16, may be null) and/or y32 (f32, may be null); mean/rstd f32 [M] (may be null).
+ * bwd: dy f32 [M,d]; g_in (may be null) is the residual-stream gradient added to the result;
+ *      dx f32 and/or dx16 bf16 (either may be null); dgamma/dbeta f32 [d] (+= when accumulate);
+ *      workspace: neko_layernorm_bwd_blocks(M) * 2 * d floats.
+ * ------------------------------------------------------------------------------------------- */
+int neko_layernorm_fwd(const float* x, const float* gamma, const float* beta, uint16_t* y16, float* y32,
+                       float* mean, float* rstd, int M, int d, float eps, void* stream);
+int neko_layernorm_bwd_blocks(int M);
+int neko_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                       const float* g_in, float* dx, uint16_t* dx16, float* dgamma, float* dbeta, int accumulate,
+                       float* workspace, int M, int d, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Attention -- Attention._attn + split_heads/merge_heads (trajectory_gpt2.py:163-201,222-226,252)
+ * with the mask preparation of GPT2Model.forward (:663-679).  Dropout p = 0 (attn_pdrop path: see DESIGN.md).
+ *   neko_mask_bias: mask f32 [B,T] (1 real, 0 pad) -> kbias f32 [B,T] = (1-mask)*-1e4 and
+ *                   kstart int32 [B] = index of the first real key (may be null).
+ *   qkv  bf16 [B*T, 3*H*hd]  (q | k | v, head h at columns h*hd..) as produced by c_attn
+ *   out  bf16 [B*T, H*hd]    lse f32 [B,H,T]
+ *   bwd workspace: D f32 [B*H*T], qflags int32 [B*ceil(T/64)]; dqkv bf16 [B*T, 3*H*hd] fully written.
+ *   hd in {32, 64, 128}.
+ * ------------------------------------------------------------------------------------------- */
+int neko_mask_bias(const float* mask, float* kbias, int* kstart, int B, int T, void* stream);
+int neko_attn_fwd(const uint16_t* qkv, const float* kbias, const int* kstart, uint16_t* out, float* lse, int B,
+                  int T, int H, int hd, void* stream);
+int neko_attn_bwd(const uint16_t* qkv, const uint16_t* out, const uint16_t* dout, const float* kbias,
+                  const int* kstart, const float* lse, float* D, int* qflags, uint16_t* dqkv, int B, int T, int H,
+                  int hd, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Masked cross-entropy over a chunk of logits -- gato_policy.py:174-186 (shift, mask product,
+ * boolean gather, F.cross_entropy mean) and its backward.
+ *   logits f32 [R, ldl] (V valid columns), target int64 [R], weight f32 [R] (= loss_mask / N)
+ *   loss_row f32 [R] = lse - logit[target] (0 where weight == 0)           (may be null)
+ *   dlogits bf16 [R, ldd] = weight * (softmax - onehot), zero in columns V..Vpad-1   (may be null)
+ * ------------------------------------------------------------------------------------------- */
+int neko_ce_fwd_bwd(const float* logits, long ldl, int V, int Vpad, const long long* target, const float* weight,
+                    float* loss_row, uint16_t* dlogits, long ldd, int R, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Packing front-end -- GatoPolicy.tokenize_input_dicts (gato_policy.py:195-432) incl.
+ * ContinuousTokenizer.encode / mu_law (gato/policy/input_tokenizers.py:5-30) and the embedding
+ * lookups (gato_policy.py:117,124,149).  desc: int32 [ntok,4] = {kind, src, pos, target}:
+ *   kind 0 pad | 1 token id = src | 2 continuous obs (mu-law) cont_vals[src] | 3 continuous action
+ *   cont_vals[src] | 4 discrete disc_vals[src] | 5 separator | 6 image-patch row src of img_emb;
+ *   pos >= 0: add pos_embed[pos]; target: 1 if the position is a prediction target.
+ * fwd writes x f32 [ntok,d], tokens int64, tmask f32, pmask f32.
+ * bwd scatters dx into d_embed / d_pos / d_sep (+=, f32 atomics) and copies image rows to d_img.
+ * ------------------------------------------------------------------------------------------- */
+int neko_pack_embed_fwd(const int* desc, const float* cont_vals, const int* disc_vals, const float* img_emb,
+                        const float* embed, const float* pos_embed, const float* sep, float* x, long long* tokens,
+                        float* tmask, float* pmask, int ntok, int d, float mu, float M, int n_bins, int cont_start,
+                        int disc_start, void* stream);
+int neko_pack_embed_bwd(const int* desc, const long long* tokens, const float* dx, float* d_embed, float* d_pos,
+                        float* d_sep, float* d_img, int ntok, int d, void* stream);
+/* ContinuousTokenizer.encode on a flat array (input_tokenizers.py:17-30) */
+int neko_tokenize_continuous(const float* x, int* ids, long n, int use_mu_law, float mu, float M, int n_bins,
+                             int offset, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Elementwise / optimiser tail -- Trainer.train_step (gato/training/trainer.py:181-186):
+ * clip_grad_norm_(params, max_norm) then torch.optim.AdamW.step (train.py:127-133).
+ *   neko_cast_f32_bf16 : weight shadow refresh (bf16 MFMA operands of fp32 master weights)
+ *   neko_colsum_bf16   : out[N] (+)= column sums of bf16 [M,ld]   (Conv1D bias gradients)
+ *   neko_sqnorm_f32    : *out_accum (device double) += sum(g^2)
+ *   neko_adamw_step    : per contiguous parameter range; clip coefficient min(1, max_norm /
+ *                        (sqrt(*gnorm_sq)+1e-6)) read on device (gnorm_sq null = no clipping);
+ *                        *grad_scale (may be null) multiplies g; step = device int32 counter of the
+ *                        range (bias correction); *active == 0 (may be null) skips the range the way
+ *                        torch skips parameters whose grad is None; p16 (may be null) gets bf16(p).
+ * ------------------------------------------------------------------------------------------- */
+int neko_cast_f32_bf16(const float* x, uint16_t* y, long n, void* stream);
+int neko_colsum_bf16(const uint16_t* x, long ld, int M, int N, float* out, int accumulate, void* stream);
+int neko_sqnorm_f32(const float* g, long n, double* out_accum, void* stream);
+int neko_adamw_step(float* p, const float* g, float* m, float* v, uint16_t* p16, long n, float lr, float beta1,
+                    float beta2, float eps, float weight_decay, const double* gnorm_sq, float max_norm,
+                    const float* grad_scale, int* step, const int* active, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Image patch embedding -- ImageEmbedding.forward / ResidualBlock_V2 / PatchPosEncoding
+ * (gato/policy/embeddings.py:28-61,63-110,111-131).
+ *   neko_patch_resblock_fwd: images (f32 or u8, [n,3,H,W], values 0..255) -> y bf16 [P,768]
+ *       (P = n*(H/16)*(W/16) patches in (b, n_h, n_w) order; y = x + conv2(GELU(GN(conv1(GELU(x)))))
+ *       flattened (c p1 p2)), patch normalisation (x/255*2-1)/sqrt(16) included.
+ *   neko_patch_resblock_bwd: dy f32 [P,768] -> += dW1,db1,dgamma,dbeta,dW2,db2 (recomputes the block).
+ *   neko_patch_pos_add / _bwd: out[p,:] += row_emb[hpos[p]] + col_emb[wpos[p]] and its scatter.
+ * The 768->d projection runs on neko_gemm_bf16.
+ * ------------------------------------------------------------------------------------------- */
+int neko_patch_resblock_fwd(const void* images, int images_are_u8, int n, int H, int W, const float* w1,
+                            const float* b1, const float* gn_w, const float* gn_b, const float* w2,
+                            const float* b2, int mid_channels, int num_groups, uint16_t* y16, float* x_patches,
+                            void* stream);
+int neko_patch_resblock_bwd(const float* x_patches, const float* dy, int P, const float* w1, const float* b1,
+                            const float* gn_w, const float* gn_b, const float* w2, const float* b2,
+                            int mid_channels, int num_groups, float* dw1, float* db1, float* dgn_w, float* dgn_b,
+                            float* dw2, float* db2, void* stream);
+int neko_patch_pos_add(float* out, const int* hpos, const int* wpos, const float* row_emb, const float* col_emb,
+                       int P, int d, void* stream);
+int neko_patch_pos_add_bwd(const float* dout, const int* hpos, const int* wpos, float* d_row_emb,
+                           float* d_col_emb, int P, int d, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NEKO_HIP_H */

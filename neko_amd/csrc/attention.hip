@@ -1,0 +1,591 @@
+// Fused causal + key-padding-masked self-attention, forward and backward, bf16 MFMA / fp32 softmax.
+// Replaces Attention._attn + split_heads/merge_heads + mask prep of the reference
+// (gato/transformers/trajectory_gpt2.py:163-188,190-201,222-226,252 and :663-679) and their autograd.
+//
+// Mask semantics are the reference's, literally:
+//     s = (q.k)/sqrt(hd);  s = (key <= query) ? s : -1e4   (REPLACE, finite);  s += (1-mask[key]) * -1e4 (ADD)
+// so padded *query* rows still produce the reference's finite outputs (they see every key).
+// A query tile with no masked query row only visits key tiles up to its diagonal (and skips a fully
+// padded left prefix): for those rows every skipped term is exp(<= -1e4 - m) == 0 in fp32.
+//
+// Layout: qkv bf16 [B*T, 3*d] as written by the c_attn GEMM (q | k | v, head h at columns h*hd);
+// out bf16 [B*T, d] (merge_heads layout); lse fp32 [B,H,T]; no (B,H,T,T) tensor ever exists.
+//
+// gfx950 mapping: 4 waves per block, "one lane owns one query (or key) column": scores are computed
+// transposed, S^T = K.Q^T with v_mfma_f32_32x32x16_bf16, so the 32x32 accumulator leaves each lane with
+// 16 keys of ONE query -> the online softmax is in-lane plus a single lane^32 exchange, and the bf16
+// probabilities are already the B operand of the P.V MFMA (O^T = V^T.P^T) with the key order
+// permuted identically on the V^T side (LDS image [hd][key], 8-byte fragment reads).  K / V^T / Q^T / dO^T
+// tiles are staged through padded LDS images; everything is fp32 except MFMA operands.
+#include "neko_kernels.h"
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int KT = 64;          // keys (or queries, in dK/dV) per inner tile
+constexpr int TSTR = KT * 2 + 8;  // transposed image row stride in bytes (136: conflict-free ds_read_b64)
+constexpr float MASK_VAL = -10000.0f;
+
+template <int HD> struct Cfg {
+  static constexpr int NSTR = HD * 2 + 16;    // natural image row stride (bytes)
+  static constexpr int KS = HD / 16;          // MFMA k-steps over the head dim
+  static constexpr int IB = HD / 32;          // 32-row blocks over the head dim
+  static constexpr int CH = HD / 8;           // 16-B chunks per row
+  static constexpr int LPT = (KT * CH) / NT;  // 16-B loads per thread per 64-row tile (>=1)
+  static constexpr int NAT_BYTES = KT * NSTR;
+  static constexpr int TR_BYTES = HD * TSTR;
+};
+
+// ---- staging helpers (64 rows x HD of a [*, ld] bf16 matrix) ------------------------------------
+template <int HD>
+__device__ __forceinline__ void tile_load(const bf16_t* __restrict__ base, long ld, int row0, int nrows, int tid,
+                                          uint4 (&reg)[Cfg<HD>::LPT]) {
+#pragma unroll
+  for (int i = 0; i < Cfg<HD>::LPT; ++i) {
+    const int c = tid + NT * i;
+    const int row = c / Cfg<HD>::CH, ch = c % Cfg<HD>::CH;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (row0 + row < nrows) v = *reinterpret_cast<const uint4*>(base + (long)(row0 + row) * ld + ch * 8);
+    reg[i] = v;
+  }
+}
+template <int HD>
+__device__ __forceinline__ void tile_store_nat(char* lds, int tid, const uint4 (&reg)[Cfg<HD>::LPT]) {
+#pragma unroll
+  for (int i = 0; i < Cfg<HD>::LPT; ++i) {
+    const int c = tid + NT * i;
+    const int row = c / Cfg<HD>::CH, ch = c % Cfg<HD>::CH;
+    *reinterpret_cast<uint4*>(lds + row * Cfg<HD>::NSTR + ch * 16) = reg[i];
+  }
+}
+template <int HD>
+__device__ __forceinline__ void tile_store_tr(char* lds, int tid, const uint4 (&reg)[Cfg<HD>::LPT]) {
+#pragma unroll
+  for (int i = 0; i < Cfg<HD>::LPT; ++i) {
+    const int c = tid + NT * i;
+    const int row = c / Cfg<HD>::CH, ch = c % Cfg<HD>::CH;
+    const uint32_t w[4] = {reg[i].x, reg[i].y, reg[i].z, reg[i].w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      *reinterpret_cast<uint16_t*>(lds + (ch * 8 + e) * TSTR + row * 2) = (uint16_t)(w[e >> 1] >> ((e & 1) * 16));
+  }
+}
+
+// A fragment from a natural image: row (rowbase + lane%32), head-dim slots ks*16 + 8*(lane/32) + 0..7
+template <int HD>
+__device__ __forceinline__ bf16x8_v frag_nat(const char* lds, int rowbase, int ks, int lane) {
+  const uint4 v = *reinterpret_cast<const uint4*>(lds + (rowbase + (lane & 31)) * Cfg<HD>::NSTR +
+                                                  (ks * 2 + (lane >> 5)) * 16);
+  return __builtin_bit_cast(bf16x8_v, v);
+}
+// A fragment from a transposed image [hd][64]: row (hdbase + lane%32); contraction slots j=0..7 map to
+// column 16*s + 8*(j>>2) + 4*(lane/32) + (j&3)  == the order the 32x32 accumulator leaves in a lane.
+__device__ __forceinline__ bf16x8_v frag_tr(const char* lds, int hdbase, int s, int lane) {
+  const char* p = lds + (hdbase + (lane & 31)) * TSTR + (16 * s + 4 * (lane >> 5)) * 2;
+  const uint2 lo = *reinterpret_cast<const uint2*>(p);
+  const uint2 hi = *reinterpret_cast<const uint2*>(p + 16);
+  return __builtin_bit_cast(bf16x8_v, make_uint4(lo.x, lo.y, hi.x, hi.y));
+}
+// B fragment for contraction step s (16 columns of the 64-wide tile) from two 32x32 accumulators
+__device__ __forceinline__ bf16x8_v frag_from_acc(const f32x16 (&t)[2], int s) {
+  const f32x16& a = t[s >> 1];
+  const int o = 8 * (s & 1);
+  bf16x8_v r;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r[j] = (__bf16)a[o + j];
+  return r;
+}
+// own-row B fragments (lane's query/key row, head-dim slots ks*16 + 8*(lane/32)..+7) straight from HBM
+template <int HD>
+__device__ __forceinline__ void row_frags(const bf16_t* __restrict__ rowptr, bool valid, int lane,
+                                          bf16x8_v (&f)[Cfg<HD>::KS]) {
+#pragma unroll
+  for (int ks = 0; ks < Cfg<HD>::KS; ++ks) {
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (valid) v = *reinterpret_cast<const uint4*>(rowptr + ks * 16 + (lane >> 5) * 8);
+    f[ks] = __builtin_bit_cast(bf16x8_v, v);
+  }
+}
+// index inside a 32-wide accumulator tile of register r for this lane
+__device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+// =====================================================================================================
+// forward
+// =====================================================================================================
+template <int HD>
+__global__ __launch_bounds__(NT) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ kbias,
+                                                      const int* __restrict__ kstart, bf16_t* __restrict__ out,
+                                                      float* __restrict__ lse, int B, int T, int H, float scale) {
+  using C = Cfg<HD>;
+  __shared__ __attribute__((aligned(16))) char smem[C::NAT_BYTES + C::TR_BYTES + KT * 4 + 16];
+  char* ldsK = smem;
+  char* ldsVt = smem + C::NAT_BYTES;
+  float* ldsKb = reinterpret_cast<float*>(smem + C::NAT_BYTES + C::TR_BYTES);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int qt = (gridDim.x - 1) - blockIdx.x;   // heaviest (latest) query tiles first
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int d = H * HD;
+  const long ld = 3L * d;
+  const bf16_t* qbase = qkv + (long)b * T * ld + h * HD;
+  const bf16_t* kbase = qbase + d;
+  const bf16_t* vbase = qbase + 2 * d;
+  const float* kb = kbias + (long)b * T;
+
+  const int q0 = qt * 128;
+  const int qw0 = q0 + wave * 32;
+  const int q = qw0 + (lane & 31);
+  const bool qvalid = q < T;
+
+  bf16x8_v qf[C::KS];
+  row_frags<HD>(qbase + (long)q * ld, qvalid, lane, qf);
+
+  // does this query tile hold a masked query row?  (then the whole key range is visited)
+  int masked_q = 0;
+  if (tid < 128 && q0 + tid < T) masked_q = (kb[q0 + tid] != 0.f);
+  const int full = __syncthreads_or(masked_q);
+  const int qmax = min(q0 + 127, T - 1);
+  const int kt_end = full ? (T + KT - 1) / KT : qmax / KT + 1;
+  const int kt_beg = full ? 0 : (kstart ? kstart[b] / KT : 0);
+
+  f32x16 o[C::IB];
+#pragma unroll
+  for (int i = 0; i < C::IB; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  uint4 rk[C::LPT], rv[C::LPT];
+  float rkb = 0.f;
+  auto prefetch = [&](int kt) {
+    const int k0 = kt * KT;
+    tile_load<HD>(kbase, ld, k0, T, tid, rk);
+    tile_load<HD>(vbase, ld, k0, T, tid, rv);
+    if (tid < KT) rkb = (k0 + tid < T) ? kb[k0 + tid] : 0.f;
+  };
+  if (kt_beg < kt_end) prefetch(kt_beg);
+
+  for (int kt = kt_beg; kt < kt_end; ++kt) {
+    const int k0 = kt * KT;
+    __syncthreads();
+    tile_store_nat<HD>(ldsK, tid, rk);
+    tile_store_tr<HD>(ldsVt, tid, rv);
+    if (tid < KT) ldsKb[tid] = rkb;
+    const int has_pad = __syncthreads_or(tid < KT && rkb != 0.f);
+    if (kt + 1 < kt_end) prefetch(kt + 1);
+
+    // S^T = K . Q^T : two 32-key tiles
+    f32x16 s[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < C::KS; ++ks)
+        s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_nat<HD>(ldsK, t * 32, ks, lane), qf[ks], s[t], 0, 0, 0);
+    }
+    // scale + masks (wave-uniform choice of the cheap path)
+    const bool interior = (k0 + KT - 1 <= qw0) && !has_pad && (k0 + KT <= T);
+    if (interior) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[t][r] *= scale;
+    } else {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int kl = t * 32 + acc_row(r, lane);
+          const int key = k0 + kl;
+          float v = (key <= q) ? s[t][r] * scale : MASK_VAL;
+          v += ldsKb[kl];
+          s[t][r] = (key < T) ? v : -INFINITY;
+        }
+    }
+    // online softmax: lane pair (l, l^32) shares a query
+    float mx = s[0][0];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[t][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __expf(m_run - m_new);   // exp(-inf) = 0 on the first tile
+    float psum = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = __expf(s[t][r] - m_new);
+        s[t][r] = pv;
+        psum += pv;
+      }
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int i = 0; i < C::IB; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+    // O^T += V^T . P^T
+#pragma unroll
+    for (int sp = 0; sp < 4; ++sp) {
+      const bf16x8_v pf = frag_from_acc(s, sp);
+#pragma unroll
+      for (int i = 0; i < C::IB; ++i)
+        o[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(ldsVt, i * 32, sp, lane), pf, o[i], 0, 0, 0);
+    }
+  }
+
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  if (qvalid) {
+    const float inv = 1.0f / l_tot;
+    bf16_t* orow = out + ((long)b * T + q) * d + h * HD;
+#pragma unroll
+    for (int i = 0; i < C::IB; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        uint2 pk;
+        pk.x = pack_bf16x2(o[i][4 * g + 0] * inv, o[i][4 * g + 1] * inv);
+        pk.y = pack_bf16x2(o[i][4 * g + 2] * inv, o[i][4 * g + 3] * inv);
+        *reinterpret_cast<uint2*>(orow + i * 32 + 8 * g + 4 * (lane >> 5)) = pk;
+      }
+    if (lane < 32) lse[((long)b * H + h) * T + q] = m_run + __logf(l_tot);
+  }
+}
+
+// =====================================================================================================
+// backward prep: D[b,h,q] = sum_hd dO*O  and per (b, 64-query tile) "holds a masked query row" flags
+// =====================================================================================================
+__global__ void attn_bwd_prep_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
+                                     const float* __restrict__ kbias, float* __restrict__ D, int* __restrict__ qflags,
+                                     int B, int T, int H, int HD) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;   // over B*T*H
+  const long total = (long)B * T * H;
+  if (idx < total) {
+    const int h = idx % H;
+    const long row = idx / H;
+    const int b = row / T, q = row % T;
+    const bf16_t* po = o + row * (long)H * HD + h * HD;
+    const bf16_t* pd = dout + row * (long)H * HD + h * HD;
+    float acc = 0.f;
+    for (int c = 0; c < HD; c += 8) {
+      const uint4 a = *reinterpret_cast<const uint4*>(po + c);
+      const uint4 g = *reinterpret_cast<const uint4*>(pd + c);
+      const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, gw[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        acc += bf16_to_f32((bf16_t)(aw[e] & 0xffff)) * bf16_to_f32((bf16_t)(gw[e] & 0xffff));
+        acc += bf16_to_f32((bf16_t)(aw[e] >> 16)) * bf16_to_f32((bf16_t)(gw[e] >> 16));
+      }
+    }
+    D[((long)b * H + h) * T + q] = acc;
+  }
+  const int nqt = (T + KT - 1) / KT;
+  if (idx < (long)B * nqt) {
+    const int b = idx / nqt, t = idx % nqt;
+    int f = 0;
+    for (int i = t * KT; i < min(T, (t + 1) * KT); ++i) f |= (kbias[(long)b * T + i] != 0.f);
+    qflags[idx] = f;
+  }
+}
+
+// =====================================================================================================
+// backward dQ: lanes own queries (same geometry as forward)
+// =====================================================================================================
+template <int HD>
+__global__ __launch_bounds__(NT) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+                                                         const float* __restrict__ kbias, const int* __restrict__ kstart,
+                                                         const float* __restrict__ lse, const float* __restrict__ Dv,
+                                                         bf16_t* __restrict__ dqkv, int B, int T, int H, float scale) {
+  using C = Cfg<HD>;
+  __shared__ __attribute__((aligned(16))) char smem[2 * C::NAT_BYTES + C::TR_BYTES + KT * 4 + 16];
+  char* ldsK = smem;
+  char* ldsV = smem + C::NAT_BYTES;
+  char* ldsKt = smem + 2 * C::NAT_BYTES;
+  float* ldsKb = reinterpret_cast<float*>(smem + 2 * C::NAT_BYTES + C::TR_BYTES);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int qt = (gridDim.x - 1) - blockIdx.x;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int d = H * HD;
+  const long ld = 3L * d;
+  const bf16_t* qbase = qkv + (long)b * T * ld + h * HD;
+  const bf16_t* kbase = qbase + d;
+  const bf16_t* vbase = qbase + 2 * d;
+  const float* kb = kbias + (long)b * T;
+
+  const int q0 = qt * 128, qw0 = q0 + wave * 32;
+  const int q = qw0 + (lane & 31);
+  const bool qvalid = q < T;
+
+  bf16x8_v qf[C::KS], dof[C::KS];
+  row_frags<HD>(qbase + (long)q * ld, qvalid, lane, qf);
+  row_frags<HD>(dout + ((long)b * T + q) * d + h * HD, qvalid, lane, dof);
+  const float my_lse = qvalid ? lse[((long)b * H + h) * T + q] : 0.f;
+  const float my_D = qvalid ? Dv[((long)b * H + h) * T + q] : 0.f;
+
+  int masked_q = 0;
+  if (tid < 128 && q0 + tid < T) masked_q = (kb[q0 + tid] != 0.f);
+  const int full = __syncthreads_or(masked_q);
+  const int qmax = min(q0 + 127, T - 1);
+  const int kt_end = full ? (T + KT - 1) / KT : qmax / KT + 1;
+  const int kt_beg = full ? 0 : (kstart ? kstart[b] / KT : 0);
+
+  f32x16 dq[C::IB];
+#pragma unroll
+  for (int i = 0; i < C::IB; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dq[i][r] = 0.f;
+
+  uint4 rk[C::LPT], rv[C::LPT];
+  float rkb = 0.f;
+  auto prefetch = [&](int kt) {
+    const int k0 = kt * KT;
+    tile_load<HD>(kbase, ld, k0, T, tid, rk);
+    tile_load<HD>(vbase, ld, k0, T, tid, rv);
+    if (tid < KT) rkb = (k0 + tid < T) ? kb[k0 + tid] : 0.f;
+  };
+  if (kt_beg < kt_end) prefetch(kt_beg);
+
+  for (int kt = kt_beg; kt < kt_end; ++kt) {
+    const int k0 = kt * KT;
+    __syncthreads();
+    tile_store_nat<HD>(ldsK, tid, rk);
+    tile_store_tr<HD>(ldsKt, tid, rk);
+    tile_store_nat<HD>(ldsV, tid, rv);
+    if (tid < KT) ldsKb[tid] = rkb;
+    __syncthreads();
+    if (kt + 1 < kt_end) prefetch(kt + 1);
+
+    f32x16 s[2], dp[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s[t][r] = 0.f; dp[t][r] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < C::KS; ++ks) {
+        s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_nat<HD>(ldsK, t * 32, ks, lane), qf[ks], s[t], 0, 0, 0);
+        dp[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_nat<HD>(ldsV, t * 32, ks, lane), dof[ks], dp[t], 0, 0, 0);
+      }
+    }
+    // dS^T = P^T o (dP^T - D); zero where the score was REPLACED by the causal constant
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kl = t * 32 + acc_row(r, lane);
+        const int key = k0 + kl;
+        const bool causal_ok = key <= q;
+        float sv = (causal_ok ? s[t][r] * scale : MASK_VAL) + ldsKb[kl];
+        const float pv = (key < T) ? __expf(sv - my_lse) : 0.f;
+        s[t][r] = causal_ok ? pv * (dp[t][r] - my_D) : 0.f;
+      }
+    // dQ^T += K^T . dS^T
+#pragma unroll
+    for (int sp = 0; sp < 4; ++sp) {
+      const bf16x8_v df = frag_from_acc(s, sp);
+#pragma unroll
+      for (int i = 0; i < C::IB; ++i)
+        dq[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(ldsKt, i * 32, sp, lane), df, dq[i], 0, 0, 0);
+    }
+  }
+
+  if (qvalid) {
+    bf16_t* orow = dqkv + ((long)b * T + q) * ld + h * HD;
+#pragma unroll
+    for (int i = 0; i < C::IB; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        uint2 pk;
+        pk.x = pack_bf16x2(dq[i][4 * g + 0] * scale, dq[i][4 * g + 1] * scale);
+        pk.y = pack_bf16x2(dq[i][4 * g + 2] * scale, dq[i][4 * g + 3] * scale);
+        *reinterpret_cast<uint2*>(orow + i * 32 + 8 * g + 4 * (lane >> 5)) = pk;
+      }
+  }
+}
+
+// =====================================================================================================
+// backward dK/dV: lanes own keys; loop over 64-query tiles
+// =====================================================================================================
+template <int HD>
+__global__ __launch_bounds__(NT) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+                                                          const float* __restrict__ kbias, const float* __restrict__ lse,
+                                                          const float* __restrict__ Dv, const int* __restrict__ qflags,
+                                                          bf16_t* __restrict__ dqkv, int B, int T, int H, float scale) {
+  using C = Cfg<HD>;
+  __shared__ __attribute__((aligned(16))) char smem[2 * C::NAT_BYTES + 2 * C::TR_BYTES + 2 * KT * 4];
+  char* ldsQ = smem;
+  char* ldsdO = smem + C::NAT_BYTES;
+  char* ldsQt = smem + 2 * C::NAT_BYTES;
+  char* ldsdOt = smem + 2 * C::NAT_BYTES + C::TR_BYTES;
+  float* ldsLse = reinterpret_cast<float*>(smem + 2 * C::NAT_BYTES + 2 * C::TR_BYTES);
+  float* ldsD = ldsLse + KT;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kblk = blockIdx.x;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int d = H * HD;
+  const long ld = 3L * d;
+  const bf16_t* qbase = qkv + (long)b * T * ld + h * HD;
+  const bf16_t* kbase = qbase + d;
+  const bf16_t* vbase = qbase + 2 * d;
+  const bf16_t* dobase = dout + (long)b * T * d + h * HD;
+  const float* lse_b = lse + ((long)b * H + h) * T;
+  const float* D_b = Dv + ((long)b * H + h) * T;
+
+  const int k0 = kblk * 128, kw0 = k0 + wave * 32;
+  const int key = kw0 + (lane & 31);
+  const bool kvalid = key < T;
+  const float my_kb = kvalid ? kbias[(long)b * T + key] : 0.f;
+
+  bf16x8_v kf[C::KS], vf[C::KS];
+  row_frags<HD>(kbase + (long)key * ld, kvalid, lane, kf);
+  row_frags<HD>(vbase + (long)key * ld, kvalid, lane, vf);
+
+  f32x16 dk[C::IB], dv[C::IB];
+#pragma unroll
+  for (int i = 0; i < C::IB; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk[i][r] = 0.f; dv[i][r] = 0.f; }
+
+  const int nqt = (T + KT - 1) / KT;
+  const int qt_causal = k0 / KT;   // first query tile that can see this key block causally
+
+  uint4 rq[C::LPT], rdo[C::LPT];
+  float rl = 0.f;
+  auto next_tile = [&](int t) {   // next query tile >= t that has to be visited (block-uniform)
+    while (t < nqt && t < qt_causal && !qflags[b * nqt + t]) ++t;
+    return t;
+  };
+  auto prefetch = [&](int t) {
+    const int q0 = t * KT;
+    tile_load<HD>(qbase, ld, q0, T, tid, rq);
+    tile_load<HD>(dobase, d, q0, T, tid, rdo);
+    if (tid < KT) rl = (q0 + tid < T) ? lse_b[q0 + tid] : 0.f;
+    else if (tid < 2 * KT) rl = (q0 + tid - KT < T) ? D_b[q0 + tid - KT] : 0.f;
+  };
+  int qt = next_tile(0);
+  if (qt < nqt) prefetch(qt);
+
+  while (qt < nqt) {
+    const int q0 = qt * KT;
+    __syncthreads();
+    tile_store_nat<HD>(ldsQ, tid, rq);
+    tile_store_tr<HD>(ldsQt, tid, rq);
+    tile_store_nat<HD>(ldsdO, tid, rdo);
+    tile_store_tr<HD>(ldsdOt, tid, rdo);
+    if (tid < 2 * KT) ldsLse[tid] = rl;   // ldsD follows ldsLse
+    __syncthreads();
+    const int qn = next_tile(qt + 1);
+    if (qn < nqt) prefetch(qn);
+
+    // S = Q . K^T and dP = dO . V^T : rows = queries (two 32-query tiles), lane column = own key
+    f32x16 s[2], dp[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s[t][r] = 0.f; dp[t][r] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < C::KS; ++ks) {
+        s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_nat<HD>(ldsQ, t * 32, ks, lane), kf[ks], s[t], 0, 0, 0);
+        dp[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_nat<HD>(ldsdO, t * 32, ks, lane), vf[ks], dp[t], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ql = t * 32 + acc_row(r, lane);
+        const int qq = q0 + ql;
+        const bool causal_ok = key <= qq;
+        const float sv = (causal_ok ? s[t][r] * scale : MASK_VAL) + my_kb;
+        const float pv = (qq < T && kvalid) ? __expf(sv - ldsLse[ql]) : 0.f;
+        s[t][r] = pv;                                              // P   (for dV)
+        dp[t][r] = causal_ok ? pv * (dp[t][r] - ldsD[ql]) : 0.f;  // dS  (for dK)
+      }
+#pragma unroll
+    for (int sp = 0; sp < 4; ++sp) {
+      const bf16x8_v pf = frag_from_acc(s, sp);
+      const bf16x8_v df = frag_from_acc(dp, sp);
+#pragma unroll
+      for (int i = 0; i < C::IB; ++i) {
+        dv[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(ldsdOt, i * 32, sp, lane), pf, dv[i], 0, 0, 0);
+        dk[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(ldsQt, i * 32, sp, lane), df, dk[i], 0, 0, 0);
+      }
+    }
+    qt = qn;
+  }
+
+  if (kvalid) {
+    bf16_t* krow = dqkv + ((long)b * T + key) * ld + d + h * HD;
+    bf16_t* vrow = krow + d;
+#pragma unroll
+    for (int i = 0; i < C::IB; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        uint2 pk;
+        pk.x = pack_bf16x2(dk[i][4 * g + 0] * scale, dk[i][4 * g + 1] * scale);
+        pk.y = pack_bf16x2(dk[i][4 * g + 2] * scale, dk[i][4 * g + 3] * scale);
+        *reinterpret_cast<uint2*>(krow + i * 32 + 8 * g + 4 * (lane >> 5)) = pk;
+        pk.x = pack_bf16x2(dv[i][4 * g + 0], dv[i][4 * g + 1]);
+        pk.y = pack_bf16x2(dv[i][4 * g + 2], dv[i][4 * g + 3]);
+        *reinterpret_cast<uint2*>(vrow + i * 32 + 8 * g + 4 * (lane >> 5)) = pk;
+      }
+  }
+}
+
+template <int HD>
+int fwd_launch(const bf16_t* qkv, const float* kbias, const int* kstart, bf16_t* out, float* lse, int B, int T, int H,
+               hipStream_t s) {
+  const float scale = 1.0f / sqrtf((float)HD);
+  dim3 grid((T + 127) / 128, H, B);
+  hipLaunchKernelGGL((attn_fwd_kernel<HD>), grid, dim3(NT), 0, s, qkv, kbias, kstart, out, lse, B, T, H, scale);
+  NEKO_CHECK_LAUNCH();
+  return NEKO_OK;
+}
+template <int HD>
+int bwd_launch(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const float* kbias, const int* kstart,
+               const float* lse, float* D, int* qflags, bf16_t* dqkv, int B, int T, int H, hipStream_t s) {
+  const float scale = 1.0f / sqrtf((float)HD);
+  const long total = (long)B * T * H;
+  hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, out, dout, kbias, D,
+                     qflags, B, T, H, HD);
+  NEKO_CHECK_LAUNCH();
+  dim3 grid((T + 127) / 128, H, B);
+  hipLaunchKernelGGL((attn_bwd_dq_kernel<HD>), grid, dim3(NT), 0, s, qkv, dout, kbias, kstart, lse, D, dqkv, B, T, H,
+                     scale);
+  NEKO_CHECK_LAUNCH();
+  hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD>), grid, dim3(NT), 0, s, qkv, dout, kbias, lse, D, qflags, dqkv, B, T, H,
+                     scale);
+  NEKO_CHECK_LAUNCH();
+  return NEKO_OK;
+}
+
+}  // namespace
+
+int neko_attn_fwd_impl(const bf16_t* qkv, const float* kbias, const int* kstart, bf16_t* out, float* lse, int B, int T,
+                       int H, int hd, hipStream_t s) {
+  if (B <= 0 || T <= 0) return NEKO_OK;
+  if (!qkv || !kbias || !out || !lse || H <= 0) return NEKO_ERR_ARG;
+  switch (hd) {
+    case 32: return fwd_launch<32>(qkv, kbias, kstart, out, lse, B, T, H, s);
+    case 64: return fwd_launch<64>(qkv, kbias, kstart, out, lse, B, T, H, s);
+    case 128: return fwd_launch<128>(qkv, kbias, kstart, out, lse, B, T, H, s);
+    default: return NEKO_ERR_UNSUPPORTED;
+  }
+}
+
+// workspace: D fp32 [B*H*T] and qflags int32 [B*ceil(T/64)]
+int neko_attn_bwd_impl(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const float* kbias, const int* kstart,
+                       const float* lse, float* D, int* qflags, bf16_t* dqkv, int B, int T, int H, int hd,
+                       hipStream_t s) {
+  if (B <= 0 || T <= 0) return NEKO_OK;
+  if (!qkv || !out || !dout || !kbias || !lse || !D || !qflags || !dqkv || H <= 0) return NEKO_ERR_ARG;
+  switch (hd) {
+    case 32: return bwd_launch<32>(qkv, out, dout, kbias, kstart, lse, D, qflags, dqkv, B, T, H, s);
+    case 64: return bwd_launch<64>(qkv, out, dout, kbias, kstart, lse, D, qflags, dqkv, B, T, H, s);
+    case 128: return bwd_launch<128>(qkv, out, dout, kbias, kstart, lse, D, qflags, dqkv, B, T, H, s);
+    default: return NEKO_ERR_UNSUPPORTED;
+  }
+}

@@ -1,0 +1,224 @@
+// HBM-bound helpers of the path: fp32->bf16 weight shadow cast, bias-gradient column sums,
+// attention-mask bias, and the optimiser tail (global grad norm, clip, AdamW) of Trainer.train_step
+// (gato/training/trainer.py:181-186; torch.optim.AdamW set up at train.py:127-133).
+// All kernels are grid-stride, 16-B vectorised, and read their scalars from device memory so the
+// host never synchronises inside a step.
+#include "neko_kernels.h"
+
+namespace {
+
+// ---- fp32 -> bf16 (weights -> MFMA operand shadow) ---------------------------------------------
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, long n) {
+  const long stride = (long)gridDim.x * blockDim.x * 8;
+  for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 8; i < n; i += stride) {
+    if (i + 8 <= n) {
+      const float4 a = *reinterpret_cast<const float4*>(x + i);
+      const float4 b = *reinterpret_cast<const float4*>(x + i + 4);
+      uint4 pk;
+      pk.x = pack_bf16x2(a.x, a.y); pk.y = pack_bf16x2(a.z, a.w);
+      pk.z = pack_bf16x2(b.x, b.y); pk.w = pack_bf16x2(b.z, b.w);
+      *reinterpret_cast<uint4*>(y + i) = pk;
+    } else {
+      for (long j = i; j < n; ++j) y[j] = f32_to_bf16(x[j]);
+    }
+  }
+}
+
+// ---- out[N] (+)= column sums of a bf16 [M, ld] matrix (bias gradients) -------------------------------
+// block = 256 threads = 4 waves; a wave covers 512 columns (8 per lane, 16-B loads); blockIdx.x = column
+// group, blockIdx.y = row slice; partial sums meet in fp32 atomics (out zeroed by the host when !accumulate).
+__global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restrict__ x, long ld, int M, int N,
+                                                          float* __restrict__ out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c0 = (blockIdx.x * 64 + lane) * 8;
+  if (c0 >= N) return;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int r = blockIdx.y * 4 + wave; r < M; r += gridDim.y * 4) {
+    const uint4 v = *reinterpret_cast<const uint4*>(x + (long)r * ld + c0);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      acc[2 * e] += bf16_to_f32((bf16_t)(w[e] & 0xffff));
+      acc[2 * e + 1] += bf16_to_f32((bf16_t)(w[e] >> 16));
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e)
+    if (c0 + e < N) atomicAdd(out + c0 + e, acc[e]);
+}
+
+// ---- additive key bias (1-mask)*-1e4 and the number of leading masked keys per sequence ---------------
+// (trajectory_gpt2.py:663-679).  one block per sequence.
+__global__ void mask_bias_kernel(const float* __restrict__ mask, float* __restrict__ kbias, int* __restrict__ kstart,
+                                 int T) {
+  __shared__ int first_valid;
+  const int b = blockIdx.x;
+  if (threadIdx.x == 0) first_valid = T;
+  __syncthreads();
+  int fv = T;
+  for (int t = threadIdx.x; t < T; t += blockDim.x) {
+    const float m = mask[(long)b * T + t];
+    kbias[(long)b * T + t] = (1.0f - m) * -10000.0f;
+    if (m != 0.f && t < fv) fv = t;
+  }
+  atomicMin(&first_valid, fv);
+  __syncthreads();
+  if (threadIdx.x == 0 && kstart) kstart[b] = first_valid;
+}
+
+// ---- sum of squares of an fp32 range into a device double accumulator ---------------------------------
+__global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g, long n, double* __restrict__ out) {
+  __shared__ double red[4];
+  double acc = 0.0;
+  const long stride = (long)gridDim.x * blockDim.x * 4;
+  for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+    if (i + 4 <= n) {
+      const float4 v = *reinterpret_cast<const float4*>(g + i);
+      acc += (double)((v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w));
+    } else {
+      for (long j = i; j < n; ++j) acc += (double)(g[j] * g[j]);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, (red[0] + red[1]) + (red[2] + red[3]));
+}
+
+// ---- fused clip + AdamW (+ bf16 shadow refresh) over one contiguous parameter range -------------------
+// torch semantics: p *= 1 - lr*wd;  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;
+//                  p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)      with g already clipped:
+// clip coef = min(1, max_norm / (sqrt(*gnorm_sq) + 1e-6))  (clip_grad_norm_), read from device memory.
+// state[0] = step count of this range (incremented by the first thread *after* use via a second kernel),
+// `active` (device int, may be null) lets a range whose parameters took no part in the step be skipped
+// exactly like torch skips grad=None parameters.
+struct AdamArgs {
+  float* p; const float* g; float* m; float* v; bf16_t* p16; long n;
+  float lr, beta1, beta2, eps, wd, max_norm;
+  const double* gnorm_sq;     // null: no clipping
+  const float* grad_scale;    // optional extra multiplier on g (e.g. 1/world) or null
+  int* step;                  // device step counter of this range (already incremented for this step)
+  const int* active;          // null = always
+};
+__global__ void adam_step_inc_kernel(int* step, const int* active) {
+  if (!active || *active) *step += 1;
+}
+__global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
+  if (a.active && *a.active == 0) return;
+  // g_eff = grad_scale * g (e.g. 1/world after a SUM all-reduce); the clip norm is the norm of g_eff
+  const float gs = a.grad_scale ? *a.grad_scale : 1.f;
+  float coef = gs;
+  if (a.gnorm_sq) {
+    const float nrm = (float)sqrt(*a.gnorm_sq) * gs;
+    coef = fminf(1.f, a.max_norm / (nrm + 1e-6f)) * gs;
+  }
+  const int t = *a.step;
+  const float bc1 = 1.f - powf(a.beta1, (float)t);
+  const float bc2 = 1.f - powf(a.beta2, (float)t);
+  const float step_size = a.lr / bc1;
+  const float inv_sqrt_bc2 = 1.f / sqrtf(bc2);
+  const float decay = 1.f - a.lr * a.wd;
+  const long stride = (long)gridDim.x * blockDim.x * 4;
+  for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < a.n; i += stride) {
+    float pv[4], gv[4], mv[4], vv[4];
+    const int cnt = (i + 4 <= a.n) ? 4 : (int)(a.n - i);
+    if (cnt == 4) {
+      const float4 P = *reinterpret_cast<const float4*>(a.p + i), G = *reinterpret_cast<const float4*>(a.g + i);
+      const float4 Mm = *reinterpret_cast<const float4*>(a.m + i), Vv = *reinterpret_cast<const float4*>(a.v + i);
+      pv[0] = P.x; pv[1] = P.y; pv[2] = P.z; pv[3] = P.w;
+      gv[0] = G.x; gv[1] = G.y; gv[2] = G.z; gv[3] = G.w;
+      mv[0] = Mm.x; mv[1] = Mm.y; mv[2] = Mm.z; mv[3] = Mm.w;
+      vv[0] = Vv.x; vv[1] = Vv.y; vv[2] = Vv.z; vv[3] = Vv.w;
+    } else {
+      for (int e = 0; e < cnt; ++e) { pv[e] = a.p[i + e]; gv[e] = a.g[i + e]; mv[e] = a.m[i + e]; vv[e] = a.v[i + e]; }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (e < cnt) {
+        const float g = gv[e] * coef;
+        float p = pv[e] * decay;
+        const float m = a.beta1 * mv[e] + (1.f - a.beta1) * g;
+        const float v = a.beta2 * vv[e] + (1.f - a.beta2) * g * g;
+        p -= step_size * m / (sqrtf(v) * inv_sqrt_bc2 + a.eps);
+        pv[e] = p; mv[e] = m; vv[e] = v;
+      }
+    }
+    if (cnt == 4) {
+      *reinterpret_cast<float4*>(a.p + i) = make_float4(pv[0], pv[1], pv[2], pv[3]);
+      *reinterpret_cast<float4*>(a.m + i) = make_float4(mv[0], mv[1], mv[2], mv[3]);
+      *reinterpret_cast<float4*>(a.v + i) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+      if (a.p16) {
+        uint2 pk;
+        pk.x = pack_bf16x2(pv[0], pv[1]); pk.y = pack_bf16x2(pv[2], pv[3]);
+        *reinterpret_cast<uint2*>(a.p16 + i) = pk;
+      }
+    } else {
+      for (int e = 0; e < cnt; ++e) {
+        a.p[i + e] = pv[e]; a.m[i + e] = mv[e]; a.v[i + e] = vv[e];
+        if (a.p16) a.p16[i + e] = f32_to_bf16(pv[e]);
+      }
+    }
+  }
+}
+
+inline int grid_for(long n, int per_thread) {
+  long b = (n + 256L * per_thread - 1) / (256L * per_thread);
+  if (b > 2048) b = 2048;   // grid-stride the rest (256 CUs x 8 blocks)
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace
+
+int neko_cast_f32_bf16_impl(const float* x, bf16_t* y, long n, hipStream_t s) {
+  if (n <= 0) return NEKO_OK;
+  if (!x || !y) return NEKO_ERR_ARG;
+  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(n, 8)), dim3(256), 0, s, x, y, n);
+  NEKO_CHECK_LAUNCH();
+  return NEKO_OK;
+}
+
+int neko_colsum_bf16_impl(const bf16_t* x, long ld, int M, int N, float* out, int accumulate, hipStream_t s) {
+  if (M <= 0 || N <= 0) return NEKO_OK;
+  if (!x || !out || (ld & 7) || (N & 7)) return NEKO_ERR_ARG;
+  if (!accumulate) {
+    if (hipMemsetAsync(out, 0, sizeof(float) * (size_t)N, s) != hipSuccess) return NEKO_ERR_LAUNCH;
+  }
+  const int gx = (N + 511) / 512;
+  int gy = (M + 63) / 64;
+  if (gy > 256) gy = 256;
+  if (gy < 1) gy = 1;
+  hipLaunchKernelGGL(colsum_bf16_kernel, dim3(gx, gy), dim3(256), 0, s, x, ld, M, N, out);
+  NEKO_CHECK_LAUNCH();
+  return NEKO_OK;
+}
+
+int neko_mask_bias_impl(const float* mask, float* kbias, int* kstart, int B, int T, hipStream_t s) {
+  if (B <= 0 || T <= 0) return NEKO_OK;
+  if (!mask || !kbias) return NEKO_ERR_ARG;
+  hipLaunchKernelGGL(mask_bias_kernel, dim3(B), dim3(256), 0, s, mask, kbias, kstart, T);
+  NEKO_CHECK_LAUNCH();
+  return NEKO_OK;
+}
+
+int neko_sqnorm_f32_impl(const float* g, long n, double* out_accum, hipStream_t s) {
+  if (n <= 0) return NEKO_OK;
+  if (!g || !out_accum) return NEKO_ERR_ARG;
+  hipLaunchKernelGGL(sqnorm_kernel, dim3(grid_for(n, 16)), dim3(256), 0, s, g, n, out_accum);
+  NEKO_CHECK_LAUNCH();
+  return NEKO_OK;
+}
+
+int neko_adamw_step_impl(float* p, const float* g, float* m, float* v, bf16_t* p16, long n, float lr, float beta1,
+                         float beta2, float eps, float wd, const double* gnorm_sq, float max_norm,
+                         const float* grad_scale, int* step, const int* active, hipStream_t s) {
+  if (n <= 0) return NEKO_OK;
+  if (!p || !g || !m || !v || !step) return NEKO_ERR_ARG;
+  hipLaunchKernelGGL(adam_step_inc_kernel, dim3(1), dim3(1), 0, s, step, active);
+  NEKO_CHECK_LAUNCH();
+  AdamArgs a{p, g, m, v, p16, n, lr, beta1, beta2, eps, wd, max_norm, gnorm_sq, grad_scale, step, active};
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n, 8)), dim3(256), 0, s, a);
+  NEKO_CHECK_LAUNCH();
+  return NEKO_OK;
+}

@@ -1,0 +1,234 @@
+// LayerNorm forward / backward over rows of the fp32 residual stream
+// (nn.LayerNorm eps 1e-5 affine: gato/transformers/trajectory_gpt2.py:301,303,323,353,543,779).
+//
+// HBM-bound: one wave64 per row, the row lives in registers (float4 per lane, d <= 4096),
+// statistics by wave shuffles in fp32 (two-pass mean / centred variance like ATen).
+// forward : x f32 [M,d] -> y bf16 (GEMM operand) and/or y f32, mean/rstd f32 [M]
+// backward: dy f32 [M,d], x, mean, rstd, gamma (+ g_in f32 residual-stream grad)
+//           -> dx f32 = g_in + LN'(dy), dx16 bf16 copy (next dgrad/wgrad operand),
+//              per-block partial dgamma/dbeta -> reduced by a second kernel into the grads.
+#include "neko_kernels.h"
+
+namespace {
+
+constexpr int LN_MAXV = 16;  // float4 per lane -> d <= 4096
+
+template <int NV>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, bf16_t* __restrict__ y16,
+                                                     float* __restrict__ y32, float* __restrict__ mean,
+                                                     float* __restrict__ rstd, int M, int d, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int nvec = d >> 2;
+  const float4* xr = reinterpret_cast<const float4*>(x + (long)row * d);
+  float4 v[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane + 64 * i;
+    v[i] = (c < nvec) ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  }
+  const float mu = wave_sum(s) / (float)d;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nvec) {
+      const float a = v[i].x - mu, b = v[i].y - mu, cc = v[i].z - mu, dd = v[i].w - mu;
+      q += (a * a + b * b) + (cc * cc + dd * dd);
+    }
+  }
+  const float var = wave_sum(q) / (float)d;
+  const float rs = rsqrtf(var + eps);
+  if (lane == 0) {
+    if (mean) mean[row] = mu;
+    if (rstd) rstd[row] = rs;
+  }
+  const float4* g4 = reinterpret_cast<const float4*>(gamma);
+  const float4* b4 = reinterpret_cast<const float4*>(beta);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nvec) {
+      const float4 g = g4[c], b = b4[c];
+      float4 o;
+      o.x = (v[i].x - mu) * rs * g.x + b.x;
+      o.y = (v[i].y - mu) * rs * g.y + b.y;
+      o.z = (v[i].z - mu) * rs * g.z + b.z;
+      o.w = (v[i].w - mu) * rs * g.w + b.w;
+      if (y32) reinterpret_cast<float4*>(y32 + (long)row * d)[c] = o;
+      if (y16) {
+        uint2 pk;
+        pk.x = pack_bf16x2(o.x, o.y);
+        pk.y = pack_bf16x2(o.z, o.w);
+        reinterpret_cast<uint2*>(y16 + (long)row * d)[c] = pk;
+      }
+    }
+  }
+}
+
+// Backward. Block = 4 waves; each wave walks rows (grid-stride) and keeps per-lane partial
+// dgamma/dbeta for its columns; the 4 waves are combined through LDS into one partial row per block.
+template <int NV>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                     const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, const float* __restrict__ g_in,
+                                                     float* __restrict__ dx, bf16_t* __restrict__ dx16,
+                                                     float* __restrict__ part, int M, int d) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // [4][2][d]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nvec = d >> 2;
+  const float4* g4 = reinterpret_cast<const float4*>(gamma);
+  float4 gm[NV], dg[NV], db[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane + 64 * i;
+    gm[i] = (c < nvec) ? g4[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    dg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    db[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const float inv_d = 1.0f / (float)d;
+  for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+    const float mu = mean[row], rs = rstd[row];
+    const float4* xr = reinterpret_cast<const float4*>(x + (long)row * d);
+    const float4* dr = reinterpret_cast<const float4*>(dy + (long)row * d);
+    float4 xh[NV], dv[NV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nvec) {
+        const float4 xv = xr[c];
+        dv[i] = dr[c];
+        xh[i].x = (xv.x - mu) * rs; xh[i].y = (xv.y - mu) * rs;
+        xh[i].z = (xv.z - mu) * rs; xh[i].w = (xv.w - mu) * rs;
+        dg[i].x += dv[i].x * xh[i].x; dg[i].y += dv[i].y * xh[i].y;
+        dg[i].z += dv[i].z * xh[i].z; dg[i].w += dv[i].w * xh[i].w;
+        db[i].x += dv[i].x; db[i].y += dv[i].y; db[i].z += dv[i].z; db[i].w += dv[i].w;
+        dv[i].x *= gm[i].x; dv[i].y *= gm[i].y; dv[i].z *= gm[i].z; dv[i].w *= gm[i].w;
+        s1 += (dv[i].x + dv[i].y) + (dv[i].z + dv[i].w);
+        s2 += (dv[i].x * xh[i].x + dv[i].y * xh[i].y) + (dv[i].z * xh[i].z + dv[i].w * xh[i].w);
+      } else {
+        xh[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        dv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    const float m1 = wave_sum(s1) * inv_d, m2 = wave_sum(s2) * inv_d;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nvec) {
+        float4 o;
+        o.x = rs * (dv[i].x - m1 - xh[i].x * m2);
+        o.y = rs * (dv[i].y - m1 - xh[i].y * m2);
+        o.z = rs * (dv[i].z - m1 - xh[i].z * m2);
+        o.w = rs * (dv[i].w - m1 - xh[i].w * m2);
+        if (g_in) {
+          const float4 g = reinterpret_cast<const float4*>(g_in + (long)row * d)[c];
+          o.x += g.x; o.y += g.y; o.z += g.z; o.w += g.w;
+        }
+        if (dx) reinterpret_cast<float4*>(dx + (long)row * d)[c] = o;
+        if (dx16) {
+          uint2 pk;
+          pk.x = pack_bf16x2(o.x, o.y);
+          pk.y = pack_bf16x2(o.z, o.w);
+          reinterpret_cast<uint2*>(dx16 + (long)row * d)[c] = pk;
+        }
+      }
+    }
+  }
+  // combine the 4 waves
+  float4* l4 = reinterpret_cast<float4*>(lds);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nvec) {
+      l4[(wave * 2 + 0) * nvec + c] = dg[i];
+      l4[(wave * 2 + 1) * nvec + c] = db[i];
+    }
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < 2 * nvec; idx += 256) {
+    float4 a = l4[idx];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      const float4 b = l4[w * 2 * nvec + idx];
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    reinterpret_cast<float4*>(part + (long)blockIdx.x * 2 * d)[idx] = a;   // [block][2][d]
+  }
+}
+
+// dgamma[d] (+)= sum_b part[b][0][:], dbeta likewise.  One thread per column, coalesced over b rows.
+__global__ void ln_param_reduce_kernel(const float* __restrict__ part, int nblk, int d, float* __restrict__ dgamma,
+                                       float* __restrict__ dbeta, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= 2 * d) return;
+  float s = 0.f;
+  for (int b = 0; b < nblk; ++b) s += part[(long)b * 2 * d + c];
+  float* dst = (c < d) ? (dgamma + c) : (dbeta + (c - d));
+  *dst = accumulate ? (*dst + s) : s;
+}
+
+template <int NV>
+int fwd_launch(const float* x, const float* g, const float* b, bf16_t* y16, float* y32, float* mean, float* rstd,
+               int M, int d, float eps, hipStream_t s) {
+  hipLaunchKernelGGL((ln_fwd_kernel<NV>), dim3((M + 3) / 4), dim3(256), 0, s, x, g, b, y16, y32, mean, rstd, M, d, eps);
+  NEKO_CHECK_LAUNCH();
+  return NEKO_OK;
+}
+template <int NV>
+int bwd_launch(const float* dy, const float* x, const float* g, const float* mean, const float* rstd,
+               const float* g_in, float* dx, bf16_t* dx16, float* part, int nblk, int M, int d, hipStream_t s) {
+  hipLaunchKernelGGL((ln_bwd_kernel<NV>), dim3(nblk), dim3(256), (size_t)8 * d * sizeof(float), s, dy, x, g, mean,
+                     rstd, g_in, dx, dx16, part, M, d);
+  NEKO_CHECK_LAUNCH();
+  return NEKO_OK;
+}
+
+}  // namespace
+
+int neko_layernorm_fwd_impl(const float* x, const float* gamma, const float* beta, bf16_t* y16, float* y32,
+                            float* mean, float* rstd, int M, int d, float eps, hipStream_t s) {
+  if (M <= 0) return NEKO_OK;
+  if (!x || !gamma || !beta || (!y16 && !y32)) return NEKO_ERR_ARG;
+  if ((d & 3) || d > 256 * LN_MAXV) return NEKO_ERR_UNSUPPORTED;
+  const int nv = (d / 4 + 63) / 64;
+  if (nv <= 1) return fwd_launch<1>(x, gamma, beta, y16, y32, mean, rstd, M, d, eps, s);
+  if (nv <= 2) return fwd_launch<2>(x, gamma, beta, y16, y32, mean, rstd, M, d, eps, s);
+  if (nv <= 3) return fwd_launch<3>(x, gamma, beta, y16, y32, mean, rstd, M, d, eps, s);
+  if (nv <= 4) return fwd_launch<4>(x, gamma, beta, y16, y32, mean, rstd, M, d, eps, s);
+  if (nv <= 8) return fwd_launch<8>(x, gamma, beta, y16, y32, mean, rstd, M, d, eps, s);
+  return fwd_launch<16>(x, gamma, beta, y16, y32, mean, rstd, M, d, eps, s);
+}
+
+// number of partial rows the backward writes for a given M (workspace = nblk*2*d floats)
+int neko_layernorm_bwd_blocks_impl(int M) {
+  int nb = (M + 3) / 4;
+  return nb < 1024 ? (nb < 1 ? 1 : nb) : 1024;
+}
+
+int neko_layernorm_bwd_impl(const float* dy, const float* x, const float* gamma, const float* mean,
+                            const float* rstd, const float* g_in, float* dx, bf16_t* dx16, float* dgamma,
+                            float* dbeta, int accumulate, float* workspace, int M, int d, hipStream_t s) {
+  if (M <= 0) return NEKO_OK;
+  if (!dy || !x || !gamma || !mean || !rstd || !workspace || !dgamma || !dbeta) return NEKO_ERR_ARG;
+  if ((d & 3) || d > 256 * LN_MAXV) return NEKO_ERR_UNSUPPORTED;
+  const int nblk = neko_layernorm_bwd_blocks_impl(M);
+  const int nv = (d / 4 + 63) / 64;
+  int rc;
+  if (nv <= 1) rc = bwd_launch<1>(dy, x, gamma, mean, rstd, g_in, dx, dx16, workspace, nblk, M, d, s);
+  else if (nv <= 2) rc = bwd_launch<2>(dy, x, gamma, mean, rstd, g_in, dx, dx16, workspace, nblk, M, d, s);
+  else if (nv <= 3) rc = bwd_launch<3>(dy, x, gamma, mean, rstd, g_in, dx, dx16, workspace, nblk, M, d, s);
+  else if (nv <= 4) rc = bwd_launch<4>(dy, x, gamma, mean, rstd, g_in, dx, dx16, workspace, nblk, M, d, s);
+  else if (nv <= 8) rc = bwd_launch<8>(dy, x, gamma, mean, rstd, g_in, dx, dx16, workspace, nblk, M, d, s);
+  else rc = bwd_launch<16>(dy, x, gamma, mean, rstd, g_in, dx, dx16, workspace, nblk, M, d, s);
+  if (rc != NEKO_OK) return rc;
+  hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * d + 255) / 256), dim3(256), 0, s, workspace, nblk, d, dgamma,
+                     dbeta, accumulate);
+  NEKO_CHECK_LAUNCH();
+  return NEKO_OK;
+}

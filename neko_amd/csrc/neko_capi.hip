@@ -1,0 +1,114 @@
+// extern "C" surface of libneko_hip.so (declared in include/neko_hip.h).  Thin argument
+// marshalling only; kernels live in the sibling .hip files.
+#include "neko_kernels.h"
+#include "../../include/neko_hip.h"
+
+#define S(x) reinterpret_cast<hipStream_t>(x)
+
+extern "C" {
+
+int neko_abi_version(void) { return NEKO_ABI_VERSION; }
+
+const char* neko_status_string(int code) {
+  if (code == NEKO_OK) return "ok";
+  if (code == NEKO_ERR_ARG) return "invalid argument (null pointer, misaligned or inconsistent size)";
+  if (code == NEKO_ERR_UNSUPPORTED) return "unsupported shape for this kernel";
+  if (code <= NEKO_ERR_LAUNCH) return hipGetErrorString((hipError_t)(NEKO_ERR_LAUNCH - code));
+  return "unknown";
+}
+
+int neko_gemm_bf16(const uint16_t* A, long lda, int a_kstrided, const uint16_t* B, long ldb, int b_kstrided, int M,
+                   int N, int K, float alpha, const float* alpha_dev, const float* bias, const float* resid, long ldr, int act,
+                   const uint16_t* act_in, long ldact, uint16_t* pre_out, long ldpre, float* Cf, long ldcf,
+                   int accumulate, uint16_t* Cb, long ldcb, int splitk, int k_per_split, int safe_transpose,
+                   void* stream) {
+  GemmArgs a{A, B, lda, ldb, M, N, K, alpha, alpha_dev, bias, resid, ldr, act_in, ldact, pre_out, ldpre, act,
+             Cf, ldcf, accumulate, Cb, ldcb, splitk, k_per_split};
+  return neko_gemm_bf16_impl(a, a_kstrided, b_kstrided, safe_transpose, S(stream));
+}
+
+int neko_layernorm_fwd(const float* x, const float* gamma, const float* beta, uint16_t* y16, float* y32, float* mean,
+                       float* rstd, int M, int d, float eps, void* stream) {
+  return neko_layernorm_fwd_impl(x, gamma, beta, y16, y32, mean, rstd, M, d, eps, S(stream));
+}
+int neko_layernorm_bwd_blocks(int M) { return neko_layernorm_bwd_blocks_impl(M); }
+int neko_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                       const float* g_in, float* dx, uint16_t* dx16, float* dgamma, float* dbeta, int accumulate,
+                       float* workspace, int M, int d, void* stream) {
+  return neko_layernorm_bwd_impl(dy, x, gamma, mean, rstd, g_in, dx, dx16, dgamma, dbeta, accumulate, workspace, M, d,
+                                 S(stream));
+}
+
+int neko_mask_bias(const float* mask, float* kbias, int* kstart, int B, int T, void* stream) {
+  return neko_mask_bias_impl(mask, kbias, kstart, B, T, S(stream));
+}
+int neko_attn_fwd(const uint16_t* qkv, const float* kbias, const int* kstart, uint16_t* out, float* lse, int B, int T,
+                  int H, int hd, void* stream) {
+  return neko_attn_fwd_impl(qkv, kbias, kstart, out, lse, B, T, H, hd, S(stream));
+}
+int neko_attn_bwd(const uint16_t* qkv, const uint16_t* out, const uint16_t* dout, const float* kbias,
+                  const int* kstart, const float* lse, float* D, int* qflags, uint16_t* dqkv, int B, int T, int H,
+                  int hd, void* stream) {
+  return neko_attn_bwd_impl(qkv, out, dout, kbias, kstart, lse, D, qflags, dqkv, B, T, H, hd, S(stream));
+}
+
+int neko_ce_fwd_bwd(const float* logits, long ldl, int V, int Vpad, const long long* target, const float* weight,
+                    float* loss_row, uint16_t* dlogits, long ldd, int R, void* stream) {
+  return neko_ce_fwd_bwd_impl(logits, ldl, V, Vpad, target, weight, loss_row, dlogits, ldd, R, S(stream));
+}
+
+int neko_pack_embed_fwd(const int* desc, const float* cont_vals, const int* disc_vals, const float* img_emb,
+                        const float* embed, const float* pos_embed, const float* sep, float* x, long long* tokens,
+                        float* tmask, float* pmask, int ntok, int d, float mu, float M, int n_bins, int cont_start,
+                        int disc_start, void* stream) {
+  return neko_pack_embed_fwd_impl(desc, cont_vals, disc_vals, img_emb, embed, pos_embed, sep, x, tokens, tmask, pmask,
+                                  ntok, d, mu, M, n_bins, cont_start, disc_start, S(stream));
+}
+int neko_pack_embed_bwd(const int* desc, const long long* tokens, const float* dx, float* d_embed, float* d_pos,
+                        float* d_sep, float* d_img, int ntok, int d, void* stream) {
+  return neko_pack_embed_bwd_impl(desc, tokens, dx, d_embed, d_pos, d_sep, d_img, ntok, d, S(stream));
+}
+int neko_tokenize_continuous(const float* x, int* ids, long n, int use_mu_law, float mu, float M, int n_bins,
+                             int offset, void* stream) {
+  return neko_tokenize_continuous_impl(x, ids, n, use_mu_law, mu, M, n_bins, offset, S(stream));
+}
+
+int neko_cast_f32_bf16(const float* x, uint16_t* y, long n, void* stream) {
+  return neko_cast_f32_bf16_impl(x, y, n, S(stream));
+}
+int neko_colsum_bf16(const uint16_t* x, long ld, int M, int N, float* out, int accumulate, void* stream) {
+  return neko_colsum_bf16_impl(x, ld, M, N, out, accumulate, S(stream));
+}
+int neko_sqnorm_f32(const float* g, long n, double* out_accum, void* stream) {
+  return neko_sqnorm_f32_impl(g, n, out_accum, S(stream));
+}
+int neko_adamw_step(float* p, const float* g, float* m, float* v, uint16_t* p16, long n, float lr, float beta1,
+                    float beta2, float eps, float weight_decay, const double* gnorm_sq, float max_norm,
+                    const float* grad_scale, int* step, const int* active, void* stream) {
+  return neko_adamw_step_impl(p, g, m, v, p16, n, lr, beta1, beta2, eps, weight_decay, gnorm_sq, max_norm, grad_scale,
+                              step, active, S(stream));
+}
+
+int neko_patch_resblock_fwd(const void* images, int images_are_u8, int n, int H, int W, const float* w1,
+                            const float* b1, const float* gn_w, const float* gn_b, const float* w2, const float* b2,
+                            int mid_channels, int num_groups, uint16_t* y16, float* x_patches, void* stream) {
+  return neko_patch_resblock_fwd_impl(images, images_are_u8, n, H, W, w1, b1, gn_w, gn_b, w2, b2, mid_channels,
+                                      num_groups, y16, x_patches, S(stream));
+}
+int neko_patch_resblock_bwd(const float* x_patches, const float* dy, int P, const float* w1, const float* b1,
+                            const float* gn_w, const float* gn_b, const float* w2, const float* b2, int mid_channels,
+                            int num_groups, float* dw1, float* db1, float* dgn_w, float* dgn_b, float* dw2, float* db2,
+                            void* stream) {
+  return neko_patch_resblock_bwd_impl(x_patches, dy, P, w1, b1, gn_w, gn_b, w2, b2, mid_channels, num_groups, dw1, db1,
+                                      dgn_w, dgn_b, dw2, db2, S(stream));
+}
+int neko_patch_pos_add(float* out, const int* hpos, const int* wpos, const float* row_emb, const float* col_emb,
+                       int P, int d, void* stream) {
+  return neko_patch_pos_add_impl(out, hpos, wpos, row_emb, col_emb, P, d, S(stream));
+}
+int neko_patch_pos_add_bwd(const float* dout, const int* hpos, const int* wpos, float* d_row_emb, float* d_col_emb,
+                           int P, int d, void* stream) {
+  return neko_patch_pos_add_bwd_impl(dout, hpos, wpos, d_row_emb, d_col_emb, P, d, S(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,69 @@
+// Shared device/host helpers for the neko_amd HIP kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define NEKO_OK 0
+#define NEKO_ERR_ARG (-1)
+#define NEKO_ERR_UNSUPPORTED (-2)
+#define NEKO_ERR_LAUNCH (-3)
+
+typedef uint16_t bf16_t;  // storage type: raw bf16 bits
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_v;   // MFMA A/B fragment (4 VGPRs)
+typedef __attribute__((ext_vector_type(4))) short s16x4;       // ds_read_b64_tr_b16 result
+typedef __attribute__((ext_vector_type(16))) float f32x16;     // 32x32 MFMA accumulator
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define NEKO_WAVE 64
+
+#define NEKO_CHECK_LAUNCH()                                   \
+  do {                                                        \
+    hipError_t e__ = hipGetLastError();                       \
+    if (e__ != hipSuccess) return NEKO_ERR_LAUNCH - (int)e__; \
+  } while (0)
+
+// ---- bf16 <-> f32 (round to nearest even; NaN preserved) ---------------------------------
+__device__ __forceinline__ float bf16_to_f32(bf16_t h) {
+  return __uint_as_float(((uint32_t)h) << 16);
+}
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // quiet NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+
+// ---- wave64 reductions ---------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// exact (erf) GELU and its derivative -- ACT2FN['gelu'] == F.gelu (trajectory_gpt2.py:266)
+__device__ __forceinline__ float gelu_f(float x) {
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+__device__ __forceinline__ float gelu_grad_f(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+// XCD-aware bijective block remap (8 XCDs, block b runs on XCD b%8): give every XCD a
+// contiguous range of logical tile ids so neighbouring tiles share an L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7;
+  const int xcd = bid & 7, idx = bid >> 3;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}

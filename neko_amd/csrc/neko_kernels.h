@@ -1,0 +1,69 @@
+// Internal declarations shared by the kernel translation units and neko_capi.hip.
+#pragma once
+#include "neko_common.h"
+
+struct GemmArgs {
+  const bf16_t* A;
+  const bf16_t* B;
+  long lda, ldb;
+  int M, N, K;
+  float alpha;
+  const float* alpha_dev; // optional device scalar multiplied into alpha (autograd grad_output) or null
+  const float* bias;      // [N] or null
+  const float* resid;     // f32 [M, ldr] or null
+  long ldr;
+  const bf16_t* act_in;   // bf16 [M, ldact] pre-activation (act == 2)
+  long ldact;
+  bf16_t* pre_out;        // bf16 [M, ldpre] pre-activation store (act == 1) or null
+  long ldpre;
+  int act;                // 0 none, 1 gelu forward, 2 multiply by gelu'(act_in)
+  float* Cf;              // f32 out or null
+  long ldcf;
+  int accumulate;         // Cf += result
+  bf16_t* Cb;             // bf16 out or null
+  long ldcb;
+  int splitk;             // >1: each grid.y slice handles k_per_split of K, atomicAdd into Cf
+  int k_per_split;        // multiple of 64
+};
+
+int neko_gemm_bf16_impl(GemmArgs a, int a_kstrided, int b_kstrided, int safe_transpose, hipStream_t s);
+int neko_layernorm_fwd_impl(const float* x, const float* gamma, const float* beta, bf16_t* y16, float* y32,
+                            float* mean, float* rstd, int M, int d, float eps, hipStream_t s);
+int neko_layernorm_bwd_blocks_impl(int M);
+int neko_layernorm_bwd_impl(const float* dy, const float* x, const float* gamma, const float* mean,
+                            const float* rstd, const float* g_in, float* dx, bf16_t* dx16, float* dgamma,
+                            float* dbeta, int accumulate, float* workspace, int M, int d, hipStream_t s);
+int neko_attn_fwd_impl(const bf16_t* qkv, const float* kbias, const int* kstart, bf16_t* out, float* lse, int B, int T,
+                       int H, int hd, hipStream_t s);
+int neko_attn_bwd_impl(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const float* kbias, const int* kstart,
+                       const float* lse, float* D, int* qflags, bf16_t* dqkv, int B, int T, int H, int hd,
+                       hipStream_t s);
+int neko_ce_fwd_bwd_impl(const float* logits, long ldl, int V, int Vpad, const long long* target, const float* weight,
+                         float* loss_row, bf16_t* dlogits, long ldd, int R, hipStream_t s);
+int neko_pack_embed_fwd_impl(const int* desc, const float* cont_vals, const int* disc_vals, const float* img_emb,
+                             const float* embed, const float* pos_embed, const float* sep, float* x,
+                             long long* tokens, float* tmask, float* pmask, int ntok, int d, float mu, float M,
+                             int n_bins, int cont_start, int disc_start, hipStream_t s);
+int neko_pack_embed_bwd_impl(const int* desc, const long long* tokens, const float* dx, float* d_embed, float* d_pos,
+                             float* d_sep, float* d_img, int ntok, int d, hipStream_t s);
+int neko_tokenize_continuous_impl(const float* x, int* ids, long n, int use_mu_law, float mu, float M, int n_bins,
+                                  int offset, hipStream_t s);
+int neko_cast_f32_bf16_impl(const float* x, bf16_t* y, long n, hipStream_t s);
+int neko_colsum_bf16_impl(const bf16_t* x, long ld, int M, int N, float* out, int accumulate, hipStream_t s);
+int neko_mask_bias_impl(const float* mask, float* kbias, int* kstart, int B, int T, hipStream_t s);
+int neko_sqnorm_f32_impl(const float* g, long n, double* out_accum, hipStream_t s);
+int neko_adamw_step_impl(float* p, const float* g, float* m, float* v, bf16_t* p16, long n, float lr, float beta1,
+                         float beta2, float eps, float wd, const double* gnorm_sq, float max_norm,
+                         const float* grad_scale, int* step, const int* active, hipStream_t s);
+int neko_patch_resblock_fwd_impl(const void* images, int images_are_u8, int n, int H, int W, const float* w1,
+                                 const float* b1, const float* gn_w, const float* gn_b, const float* w2,
+                                 const float* b2, int mid_channels, int num_groups, bf16_t* y16, float* x_patches,
+                                 hipStream_t s);
+int neko_patch_resblock_bwd_impl(const float* x_patches, const float* dy, int P, const float* w1, const float* b1,
+                                 const float* gn_w, const float* gn_b, const float* w2, const float* b2,
+                                 int mid_channels, int num_groups, float* dw1, float* db1, float* dgn_w, float* dgn_b,
+                                 float* dw2, float* db2, hipStream_t s);
+int neko_patch_pos_add_impl(float* out, const int* hpos, const int* wpos, const float* row_emb, const float* col_emb,
+                            int P, int d, hipStream_t s);
+int neko_patch_pos_add_bwd_impl(const float* dout, const int* hpos, const int* wpos, float* d_row_emb,
+                                float* d_col_emb, int P, int d, hipStream_t s);

@@ -1,0 +1,173 @@
+// Front-end of GatoPolicy.forward: tokenise + embed + interleave + left-pad in ONE pass over a
+// per-position descriptor table, and its backward (scatter of d_x into the embedding tables).
+// Replaces the per-example Python loop of tokenize_input_dicts (gato/policy/gato_policy.py:245-432),
+// ContinuousTokenizer.encode + mu_law (gato/policy/input_tokenizers.py:5-30), embed_token /
+// pos_embed_observation / separator_token lookups (gato_policy.py:117,124,149,275,300,311,321,334,343,380-385).
+//
+// The host builds, per batch, one int4 descriptor per (b,t) position {kind, src, pos, target}:
+//   kind 0 PAD       : zeros, token 0, pad mask 0                      (left / right padding :408-431)
+//   kind 1 TOKEN     : token id = src                                   (text ids are host lists :264-277)
+//   kind 2 CONT_OBS  : id = bin(mu_law(cont[src])) + continuous_start   (:298-300)
+//   kind 3 CONT_ACT  : id = bin(cont[src]) + continuous_start           (:319-321)
+//   kind 4 DISCRETE  : id = disc[src] + discrete_start                  (:308-311, :329-334)
+//   kind 5 SEP       : separator_token vector, token 0                  (:343-345)
+//   kind 6 IMAGE     : row src of the patch-embedding buffer, token 0   (:282-292)
+//   kind 7 DEVID     : token id = disc[src] (ids handed over as a device tensor, :268-274)
+//   pos >= 0 adds pos_embed_observation[pos] (observation tokens only, :380-385); target -> target mask.
+// HBM-bound gather: one wave64 per position, float4 per lane, d*4 B read + d*4 B written per token.
+#include "neko_kernels.h"
+
+namespace {
+
+enum { K_PAD = 0, K_TOKEN = 1, K_CONT_OBS = 2, K_CONT_ACT = 3, K_DISC = 4, K_SEP = 5, K_IMAGE = 6, K_DEVID = 7 };
+
+struct PackArgs {
+  const int4* desc;
+  const float* cont_vals;
+  const int* disc_vals;
+  const float* img_emb;     // [n_img_rows, d]
+  const float* embed;       // [V, d]
+  const float* pos_embed;   // [ctx, d]
+  const float* sep;         // [d]
+  float* x;                 // [ntok, d]
+  long long* tokens;        // [ntok]
+  float* tmask;             // [ntok]
+  float* pmask;             // [ntok]
+  int ntok, d;
+  float mu, inv_log_den;    // mu-law: log(1+mu|x|) / log(1+mu*M)   (denominator passed as fp32 value)
+  float log_den;
+  float half_bins;          // n_bins / 2
+  int cont_start, disc_start;
+};
+
+// ContinuousTokenizer.encode (input_tokenizers.py:17-30) with torch's fp32 op order:
+//   t = sign(x) * log(1 + mu*|x|) / log_den ; clamp(-1,1) ; (t+1)*(n_bins/2) ; trunc to int32
+// log is evaluated in fp64 and rounded once (correctly-rounded logf), mul/add kept un-fused.
+__device__ __forceinline__ int tokenize_cont(float x, bool mu_law, float mu, float log_den, float half_bins) {
+  float t = x;
+  if (mu_law) {
+    const float a = fabsf(x);
+    const float arg = __fadd_rn(1.0f, __fmul_rn(mu, a));
+    const float l = (float)log((double)arg);
+    const float sgn = (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f);
+    t = __fdiv_rn(__fmul_rn(sgn, l), log_den);
+  }
+  t = fminf(fmaxf(t, -1.f), 1.f);
+  t = __fmul_rn(__fadd_rn(t, 1.0f), half_bins);
+  return (int)t;   // truncation toward zero (values are >= 0)
+}
+
+__global__ __launch_bounds__(256) void pack_embed_fwd_kernel(PackArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tok >= a.ntok) return;
+  const int4 ds = a.desc[tok];
+  const int kind = ds.x, src = ds.y, pos = ds.z;
+  long long id = 0;
+  const float* row = nullptr;
+  if (kind == K_TOKEN) id = src;
+  else if (kind == K_CONT_OBS) id = a.cont_start + tokenize_cont(a.cont_vals[src], true, a.mu, a.log_den, a.half_bins);
+  else if (kind == K_CONT_ACT) id = a.cont_start + tokenize_cont(a.cont_vals[src], false, a.mu, a.log_den, a.half_bins);
+  else if (kind == K_DISC) id = (long long)a.disc_vals[src] + a.disc_start;
+  else if (kind == K_DEVID) id = (long long)a.disc_vals[src];   // token ids that live on the device (text as a device tensor)
+  if ((kind >= K_TOKEN && kind <= K_DISC) || kind == K_DEVID) row = a.embed + id * (long)a.d;
+  else if (kind == K_SEP) row = a.sep;
+  else if (kind == K_IMAGE) row = a.img_emb + (long)src * a.d;
+  if (lane == 0) {
+    a.tokens[tok] = id;
+    a.tmask[tok] = ds.w ? 1.f : 0.f;
+    a.pmask[tok] = (kind == K_PAD) ? 0.f : 1.f;
+  }
+  const float4* r4 = reinterpret_cast<const float4*>(row);
+  const float4* p4 = (pos >= 0 && kind != K_PAD) ? reinterpret_cast<const float4*>(a.pos_embed + (long)pos * a.d) : nullptr;
+  float4* o4 = reinterpret_cast<float4*>(a.x + (long)tok * a.d);
+  for (int c = lane; c < (a.d >> 2); c += 64) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row) v = r4[c];
+    if (p4) { const float4 p = p4[c]; v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w; }
+    o4[c] = v;
+  }
+}
+
+struct PackBwdArgs {
+  const int4* desc;
+  const long long* tokens;
+  const float* dx;          // [ntok, d]
+  float* d_embed;           // [V, d]      (+=, atomics)
+  float* d_pos;             // [ctx, d]    (+=)
+  float* d_sep;             // [d]         (+=)
+  float* d_img;             // [n_img_rows, d]  (=, each row written once) or null
+  int ntok, d;
+};
+
+__global__ __launch_bounds__(256) void pack_embed_bwd_kernel(PackBwdArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tok >= a.ntok) return;
+  const int4 ds = a.desc[tok];
+  const int kind = ds.x, src = ds.y, pos = ds.z;
+  if (kind == K_PAD) return;
+  const float* g = a.dx + (long)tok * a.d;
+  float* dst = nullptr;
+  if ((kind >= K_TOKEN && kind <= K_DISC) || kind == K_DEVID) dst = a.d_embed + a.tokens[tok] * (long)a.d;
+  else if (kind == K_SEP) dst = a.d_sep;
+  float* dpos = (pos >= 0) ? a.d_pos + (long)pos * a.d : nullptr;
+  float* dimg = (kind == K_IMAGE && a.d_img) ? a.d_img + (long)src * a.d : nullptr;
+  for (int c = lane * 4; c < a.d; c += 256) {
+    const float4 v = *reinterpret_cast<const float4*>(g + c);
+    if (dst) { atomicAdd(dst + c, v.x); atomicAdd(dst + c + 1, v.y); atomicAdd(dst + c + 2, v.z); atomicAdd(dst + c + 3, v.w); }
+    if (dpos) { atomicAdd(dpos + c, v.x); atomicAdd(dpos + c + 1, v.y); atomicAdd(dpos + c + 2, v.z); atomicAdd(dpos + c + 3, v.w); }
+    if (dimg) *reinterpret_cast<float4*>(dimg + c) = v;
+  }
+}
+
+// standalone tokenizer (predict_* / tests): ids[i] = offset + bin(x[i])
+__global__ void tokenize_cont_kernel(const float* __restrict__ x, int* __restrict__ ids, long n, int use_mu_law, float mu,
+                                     float log_den, float half_bins, int offset) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) ids[i] = offset + tokenize_cont(x[i], use_mu_law != 0, mu, log_den, half_bins);
+}
+
+}  // namespace
+
+int neko_pack_embed_fwd_impl(const int* desc, const float* cont_vals, const int* disc_vals, const float* img_emb,
+                             const float* embed, const float* pos_embed, const float* sep, float* x,
+                             long long* tokens, float* tmask, float* pmask, int ntok, int d, float mu, float M,
+                             int n_bins, int cont_start, int disc_start, hipStream_t s) {
+  if (ntok <= 0) return NEKO_OK;
+  if (!desc || !embed || !pos_embed || !sep || !x || !tokens || !tmask || !pmask || (d & 3)) return NEKO_ERR_ARG;
+  PackArgs a;
+  a.desc = reinterpret_cast<const int4*>(desc);
+  a.cont_vals = cont_vals; a.disc_vals = disc_vals; a.img_emb = img_emb;
+  a.embed = embed; a.pos_embed = pos_embed; a.sep = sep;
+  a.x = x; a.tokens = tokens; a.tmask = tmask; a.pmask = pmask;
+  a.ntok = ntok; a.d = d; a.mu = mu;
+  a.log_den = (float)log(1.0 + (double)mu * (double)M);   // math.log(1 + mu*M) as the fp32 divisor torch uses
+  a.inv_log_den = 1.0f / a.log_den;
+  a.half_bins = (float)n_bins / 2.0f;
+  a.cont_start = cont_start; a.disc_start = disc_start;
+  hipLaunchKernelGGL(pack_embed_fwd_kernel, dim3((ntok + 3) / 4), dim3(256), 0, s, a);
+  NEKO_CHECK_LAUNCH();
+  return NEKO_OK;
+}
+
+int neko_pack_embed_bwd_impl(const int* desc, const long long* tokens, const float* dx, float* d_embed, float* d_pos,
+                             float* d_sep, float* d_img, int ntok, int d, hipStream_t s) {
+  if (ntok <= 0) return NEKO_OK;
+  if (!desc || !tokens || !dx || !d_embed || !d_pos || !d_sep || (d & 3)) return NEKO_ERR_ARG;
+  PackBwdArgs a{reinterpret_cast<const int4*>(desc), tokens, dx, d_embed, d_pos, d_sep, d_img, ntok, d};
+  hipLaunchKernelGGL(pack_embed_bwd_kernel, dim3((ntok + 3) / 4), dim3(256), 0, s, a);
+  NEKO_CHECK_LAUNCH();
+  return NEKO_OK;
+}
+
+int neko_tokenize_continuous_impl(const float* x, int* ids, long n, int use_mu_law, float mu, float M, int n_bins,
+                                  int offset, hipStream_t s) {
+  if (n <= 0) return NEKO_OK;
+  if (!x || !ids) return NEKO_ERR_ARG;
+  const float log_den = (float)log(1.0 + (double)mu * (double)M);
+  hipLaunchKernelGGL(tokenize_cont_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, ids, n, use_mu_law,
+                     mu, log_den, (float)n_bins / 2.0f, offset);
+  NEKO_CHECK_LAUNCH();
+  return NEKO_OK;
+}

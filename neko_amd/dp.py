@@ -1,0 +1,79 @@
+"""Data-parallel gradient reduction over RCCL/xGMI (torch.distributed backend "nccl" == RCCL on ROCm).
+
+Replaces what Accelerate/DDP does implicitly for the reference: one all-reduce of the
+gradients per step, averaged with equal weight per rank.  MI355X-first differences:
+  * gradients already live in ONE flat fp32 buffer laid out in reverse order of completion, so a
+    bucket is a contiguous slice -- no bucket packing copies, no autograd hooks;
+  * a bucket's all-reduce is enqueued on torch.distributed's communication stream the moment the
+    backward of its layers has been *enqueued* (stream-ordered by an event, never a host wait), so
+    the reduction of layer i overlaps the backward kernels of layers < i;
+  * the per-forward buffer broadcast (6 MB of causal masks) and the per-step "unused parameter"
+    bitmap all-reduce of DDP are gone: masks are computed from indices, and the set of ranges that
+    took part is a handful of ints reduced (MAX) asynchronously and read on the device by the optimiser;
+  * averaging is folded into the optimiser's gradient scale (1/world) instead of a divide pass.
+Works with backend "gloo" on CPU tensors too (used by the world_size-2 CPU tests).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+class GradReducer:
+    def __init__(self, flat, bucket_bytes: int = 64 << 20, group=None):
+        self.flat = flat
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.bucket_elems = max(1, bucket_bytes // 4)
+        self.handles: List = []
+        self.pending: Dict[str, bool] = {}
+        self.grad_scale = torch.full((1,), 1.0 / self.world, dtype=torch.float32, device=flat.grad.device)
+
+    def broadcast_parameters(self, src: int = 0) -> None:
+        """One-time parameter broadcast rank0 -> all (DDP constructor semantics)."""
+        if self.world > 1:
+            dist.broadcast(self.flat.data, src=src, group=self.group)
+
+    #: ranges that do not take part in every step on every rank (no image in the batch, embeddings
+    #: passed in directly).  Collectives must be issued in the same order on all ranks, so these are
+    #: never reduced from inside backward: `flush()` reduces them unconditionally at the end.
+    DEFERRED = ("frontend", "image")
+
+    def group_ready(self, gname: str) -> None:
+        """All gradient kernels of flat group `gname` are enqueued: launch its all-reduce(s)."""
+        if self.world == 1 or gname not in self.flat.group_ranges or gname in self.DEFERRED:
+            return
+        self._reduce(gname)
+
+    def flush(self) -> None:
+        """After backward: reduce the ranges that are not guaranteed to be touched on every rank."""
+        if self.world == 1:
+            return
+        for g in self.DEFERRED:
+            if g in self.flat.group_ranges:
+                self._reduce(g)
+
+    def _reduce(self, gname: str) -> None:
+        a, b = self.flat.group_ranges[gname]
+        for s in range(a, b, self.bucket_elems):
+            e = min(b, s + self.bucket_elems)
+            self.handles.append(dist.all_reduce(self.flat.grad[s:e], op=dist.ReduceOp.SUM, group=self.group,
+                                                async_op=True))
+
+    def reduce_flags(self, flags: torch.Tensor) -> None:
+        if self.world > 1:   # stream-ordered (NCCL: the current stream waits on the comm stream, the host does not)
+            dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=self.group)
+
+    def finish(self) -> None:
+        """Make the current stream wait for every outstanding reduction (no host block on CUDA)."""
+        for h in self.handles:
+            h.wait()
+        self.handles.clear()
+
+    def attach(self, model, optimizer) -> None:
+        model._dp = self
+        model.image_embedding._on_grads_ready = lambda: self.group_ready("image")
+        optimizer.grad_scale = self.grad_scale
+        optimizer.flags_reduce = self.reduce_flags

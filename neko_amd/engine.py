@@ -1,0 +1,229 @@
+"""Kernel orchestration of the hot path: transformer stack forward/backward and LM head + masked CE.
+
+This is the host side of the HIP path: it only allocates device buffers (torch caching allocator)
+and enqueues libneko_hip.so kernels on the current stream.  Follows the op sequence of SURVEY.md 2.2:
+Block.forward (gato/transformers/trajectory_gpt2.py:311-359), GPT2Model.forward (:611-795), LM head and
+loss (gato/policy/gato_policy.py:172-186).
+
+Numerics ("bf16 autocast-equivalent, fp32 accumulate everywhere"): the residual stream, LayerNorm
+statistics, softmax, logits, loss and all gradients of parameters are fp32; MFMA operands
+(LayerNorm outputs, qkv, attention output, MLP hidden, weights, upstream gradients) are bf16.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Callable, List, Optional
+
+import torch
+
+from . import ops
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+
+@dataclass
+class LayerParams:
+    """Views into the flat buffers for one Block (fp32 params, bf16 weight shadows, fp32 grads)."""
+    ln1_w: torch.Tensor; ln1_b: torch.Tensor; ln2_w: torch.Tensor; ln2_b: torch.Tensor
+    b_qkv: torch.Tensor; b_o: torch.Tensor; b_fc: torch.Tensor; b_pr: torch.Tensor
+    w_qkv: torch.Tensor; w_o: torch.Tensor; w_fc: torch.Tensor; w_pr: torch.Tensor   # bf16 shadows, (in,out)
+    g_ln1_w: torch.Tensor; g_ln1_b: torch.Tensor; g_ln2_w: torch.Tensor; g_ln2_b: torch.Tensor
+    g_b_qkv: torch.Tensor; g_b_o: torch.Tensor; g_b_fc: torch.Tensor; g_b_pr: torch.Tensor
+    g_w_qkv: torch.Tensor; g_w_o: torch.Tensor; g_w_fc: torch.Tensor; g_w_pr: torch.Tensor
+
+
+@dataclass
+class StackParams:
+    d: int
+    heads: int
+    eps: float
+    layers: List[LayerParams]
+    lnf_w: torch.Tensor; lnf_b: torch.Tensor; g_lnf_w: torch.Tensor; g_lnf_b: torch.Tensor
+
+
+@dataclass
+class HeadParams:
+    V: int
+    Vpad: int
+    w: torch.Tensor      # bf16 shadow [Vpad, d] (rows >= V are zero)
+    g_w: torch.Tensor    # fp32 grad   [Vpad, d]
+
+
+@dataclass
+class LayerCtx:
+    x: torch.Tensor = None; a1: torch.Tensor = None; mean1: torch.Tensor = None; rstd1: torch.Tensor = None
+    qkv: torch.Tensor = None; o: torch.Tensor = None; lse: torch.Tensor = None
+    x1: torch.Tensor = None; a2: torch.Tensor = None; mean2: torch.Tensor = None; rstd2: torch.Tensor = None
+    pre: torch.Tensor = None; h: torch.Tensor = None
+
+
+@dataclass
+class StackCtx:
+    B: int = 0
+    T: int = 0
+    kbias: torch.Tensor = None
+    kstart: torch.Tensor = None
+    layers: List[LayerCtx] = field(default_factory=list)
+    xf: torch.Tensor = None          # residual stream entering ln_f
+    meanf: torch.Tensor = None
+    rstdf: torch.Tensor = None
+
+
+def _wgrad(A: torch.Tensor, Bm: torch.Tensor, Mout: int, N: int, K: int, out: torch.Tensor,
+           alpha_dev: Optional[torch.Tensor] = None) -> None:
+    """out[Mout,N] += A^T @ B with A stored [K, Mout], B stored [K, N] (both k-strided)."""
+    sk, kps = ops.pick_splitk(Mout, N, K)
+    ops.gemm(A, Bm, Mout, N, K, a_kstrided=True, b_kstrided=True, lda=A.stride(0), ldb=Bm.stride(0),
+             out_f32=out, ldcf=out.stride(0), accumulate=(sk == 1), splitk=sk, k_per_split=kps,
+             alpha_dev=alpha_dev)
+
+
+def stack_forward(P: StackParams, x: torch.Tensor, mask: torch.Tensor, save: bool,
+                  want_f32: bool = False, want_bf16: bool = True):
+    """x (B,T,d) fp32 residual stream, mask (B,T) fp32 0/1.  Returns (hf16 [M,d] bf16 | None,
+    hf32 [M,d] fp32 | None, ctx | None) where hf = ln_f(h_L)."""
+    B, T, d = x.shape
+    M = B * T
+    H = P.heads
+    hd = d // H
+    dev = x.device
+    x = x.reshape(M, d).contiguous()
+    kbias, kstart = ops.mask_bias(mask.to(F32))
+    ctx = StackCtx(B=B, T=T, kbias=kbias, kstart=kstart) if save else None
+    for lp in P.layers:
+        a1 = torch.empty(M, d, dtype=BF16, device=dev)
+        mean1 = torch.empty(M, dtype=F32, device=dev)
+        rstd1 = torch.empty(M, dtype=F32, device=dev)
+        ops.layernorm_fwd(x, lp.ln1_w, lp.ln1_b, y16=a1, mean=mean1, rstd=rstd1, eps=P.eps)
+        qkv = torch.empty(M, 3 * d, dtype=BF16, device=dev)
+        ops.gemm(a1, lp.w_qkv, M, 3 * d, d, b_kstrided=True, bias=lp.b_qkv, out_bf16=qkv)
+        o, lse = ops.attn_fwd(qkv, kbias, kstart, B, T, H, hd)
+        x1 = torch.empty(M, d, dtype=F32, device=dev)
+        ops.gemm(o, lp.w_o, M, d, d, b_kstrided=True, bias=lp.b_o, resid=x, out_f32=x1)
+        a2 = torch.empty(M, d, dtype=BF16, device=dev)
+        mean2 = torch.empty(M, dtype=F32, device=dev)
+        rstd2 = torch.empty(M, dtype=F32, device=dev)
+        ops.layernorm_fwd(x1, lp.ln2_w, lp.ln2_b, y16=a2, mean=mean2, rstd=rstd2, eps=P.eps)
+        pre = torch.empty(M, 4 * d, dtype=BF16, device=dev) if save else None
+        h = torch.empty(M, 4 * d, dtype=BF16, device=dev)
+        ops.gemm(a2, lp.w_fc, M, 4 * d, d, b_kstrided=True, bias=lp.b_fc, act=1, pre_out=pre, out_bf16=h)
+        x2 = torch.empty(M, d, dtype=F32, device=dev)
+        ops.gemm(h, lp.w_pr, M, d, 4 * d, b_kstrided=True, bias=lp.b_pr, resid=x1, out_f32=x2)
+        if save:
+            ctx.layers.append(LayerCtx(x=x, a1=a1, mean1=mean1, rstd1=rstd1, qkv=qkv, o=o, lse=lse, x1=x1, a2=a2,
+                                       mean2=mean2, rstd2=rstd2, pre=pre, h=h))
+        x = x2
+    hf16 = torch.empty(M, d, dtype=BF16, device=dev) if want_bf16 else None
+    hf32 = torch.empty(M, d, dtype=F32, device=dev) if want_f32 else None
+    meanf = torch.empty(M, dtype=F32, device=dev)
+    rstdf = torch.empty(M, dtype=F32, device=dev)
+    ops.layernorm_fwd(x, P.lnf_w, P.lnf_b, y16=hf16, y32=hf32, mean=meanf, rstd=rstdf, eps=P.eps)
+    if save:
+        ctx.xf, ctx.meanf, ctx.rstdf = x, meanf, rstdf
+    return hf16, hf32, ctx
+
+
+def stack_backward(P: StackParams, ctx: StackCtx, dhf: torch.Tensor,
+                   on_layer_done: Optional[Callable[[int], None]] = None) -> torch.Tensor:
+    """dhf [M,d] fp32 = gradient wrt ln_f output.  Accumulates every parameter gradient of the stack
+    into the flat gradient views and returns the gradient wrt the input embeddings [M,d] fp32.
+    on_layer_done(i) is called after layer i's gradient kernels are enqueued (i = L for ln_f):
+    the data-parallel reducer hooks its bucket launches there."""
+    B, T = ctx.B, ctx.T
+    M = B * T
+    d, H = P.d, P.heads
+    hd = d // H
+    dev = dhf.device
+    g = torch.empty(M, d, dtype=F32, device=dev)
+    g16 = torch.empty(M, d, dtype=BF16, device=dev)
+    ops.layernorm_bwd(dhf, ctx.xf, P.lnf_w, ctx.meanf, ctx.rstdf, P.g_lnf_w, P.g_lnf_b, g_in=None, dx=g, dx16=g16)
+    if on_layer_done:
+        on_layer_done(len(P.layers))
+    for i in range(len(P.layers) - 1, -1, -1):
+        lp, c = P.layers[i], ctx.layers[i]
+        # ---- MLP: x2 = x1 + gelu(a2 Wfc + bfc) Wpr + bpr ------------------------------------------
+        d_pre = torch.empty(M, 4 * d, dtype=BF16, device=dev)
+        ops.gemm(g16, lp.w_pr, M, 4 * d, d, ldb=d, act=2, act_in=c.pre, out_bf16=d_pre)       # dgrad * gelu'
+        _wgrad(c.h, g16, 4 * d, d, M, lp.g_w_pr)
+        ops.colsum_bf16(g16, M, d, lp.g_b_pr)
+        d_a2 = torch.empty(M, d, dtype=F32, device=dev)
+        ops.gemm(d_pre, lp.w_fc, M, d, 4 * d, ldb=4 * d, out_f32=d_a2)
+        _wgrad(c.a2, d_pre, d, 4 * d, M, lp.g_w_fc)
+        ops.colsum_bf16(d_pre, M, 4 * d, lp.g_b_fc)
+        g1 = torch.empty(M, d, dtype=F32, device=dev)
+        g1_16 = torch.empty(M, d, dtype=BF16, device=dev)
+        ops.layernorm_bwd(d_a2, c.x1, lp.ln2_w, c.mean2, c.rstd2, lp.g_ln2_w, lp.g_ln2_b, g_in=g, dx=g1, dx16=g1_16)
+        # ---- attention: x1 = x + attn(a1 Wqkv + bqkv) Wo + bo -----------------------------------------
+        d_o = torch.empty(M, d, dtype=BF16, device=dev)
+        ops.gemm(g1_16, lp.w_o, M, d, d, ldb=d, out_bf16=d_o)
+        _wgrad(c.o, g1_16, d, d, M, lp.g_w_o)
+        ops.colsum_bf16(g1_16, M, d, lp.g_b_o)
+        dqkv = ops.attn_bwd(c.qkv, c.o, d_o, ctx.kbias, ctx.kstart, c.lse, B, T, H, hd)
+        d_a1 = torch.empty(M, d, dtype=F32, device=dev)
+        ops.gemm(dqkv, lp.w_qkv, M, d, 3 * d, ldb=3 * d, out_f32=d_a1)
+        _wgrad(c.a1, dqkv, d, 3 * d, M, lp.g_w_qkv)
+        ops.colsum_bf16(dqkv, M, 3 * d, lp.g_b_qkv)
+        g0 = torch.empty(M, d, dtype=F32, device=dev)
+        g0_16 = torch.empty(M, d, dtype=BF16, device=dev) if i > 0 else None
+        ops.layernorm_bwd(d_a1, c.x, lp.ln1_w, c.mean1, c.rstd1, lp.g_ln1_w, lp.g_ln1_b, g_in=g1, dx=g0, dx16=g0_16)
+        g, g16 = g0, g0_16
+        if on_layer_done:
+            on_layer_done(i)
+    return g
+
+
+# ------------------------------------------------------------------------------------------------------
+# LM head + masked cross-entropy (gato_policy.py:172-186)
+# ------------------------------------------------------------------------------------------------------
+def shift_targets(tokens: torch.Tensor, tmask: torch.Tensor, pmask: torch.Tensor):
+    """Position t predicts token t+1 (gato_policy.py:176-181): returns (target [M] int64,
+    sel [M] fp32 0/1 = pad_mask[:, :-1]*target_mask[:, 1:] with the last position 0, count)."""
+    B, T = tokens.shape
+    target = torch.zeros_like(tokens)
+    target[:, :-1] = tokens[:, 1:]
+    sel = torch.zeros(B, T, dtype=F32, device=tokens.device)
+    sel[:, :-1] = pmask[:, :-1] * tmask[:, 1:]
+    sel = (sel > 0).to(F32)
+    return target.reshape(-1).contiguous(), sel.reshape(-1).contiguous(), sel.sum()
+
+
+def lm_head_logits(Hp: HeadParams, hf16: torch.Tensor) -> torch.Tensor:
+    """Full logits [M,V] fp32 (predict_token, gato_policy.py:172)."""
+    M, d = hf16.shape
+    logits = torch.empty(M, Hp.V, dtype=F32, device=hf16.device)
+    ops.gemm(hf16, Hp.w, M, Hp.V, d, ldb=d, out_f32=logits, ldcf=Hp.V)
+    return logits
+
+
+def lm_head_loss(Hp: HeadParams, hf16: torch.Tensor, target: torch.Tensor, sel: torch.Tensor, count: torch.Tensor,
+                 want_grad: bool, chunk_rows: int = 4096):
+    """Chunked LM head + CE.  Never materialises (B,T,V) fp32 logits nor the (N,V) gathered copy
+    (gato_policy.py:184-185): per chunk of rows it runs logits GEMM -> CE (loss rows + bf16 dlogits).
+    Returns (loss scalar tensor, dlogits bf16 [M,Vpad] | None)."""
+    M, d = hf16.shape
+    dev = hf16.device
+    weight = sel / count.clamp(min=1.0)
+    loss_rows = torch.empty(M, dtype=F32, device=dev)
+    dlogits = torch.empty(M, Hp.Vpad, dtype=BF16, device=dev) if want_grad else None
+    R = min(chunk_rows, M)
+    logits = torch.empty(R, Hp.Vpad, dtype=F32, device=dev)
+    for r0 in range(0, M, R):
+        r1 = min(M, r0 + R)
+        n = r1 - r0
+        ops.gemm(hf16[r0:r1], Hp.w, n, Hp.V, d, ldb=d, out_f32=logits, ldcf=Hp.Vpad)
+        ops.ce_fwd_bwd(logits[:n], Hp.V, Hp.Vpad, target[r0:r1], weight[r0:r1], loss_row=loss_rows[r0:r1],
+                       dlogits=None if dlogits is None else dlogits[r0:r1])
+    loss = torch.dot(loss_rows, weight)
+    return loss, dlogits
+
+
+def lm_head_backward(Hp: HeadParams, hf16: torch.Tensor, dlogits: torch.Tensor, grad_out: torch.Tensor) -> torch.Tensor:
+    """dH = (dlogits @ W) * grad_out  [M,d] fp32;  dW += (dlogits^T @ H) * grad_out.
+    grad_out stays on the device (GEMM alpha_dev): no host sync in backward."""
+    M, d = hf16.shape
+    go = grad_out.reshape(1).to(F32)
+    dhf = torch.empty(M, d, dtype=F32, device=hf16.device)
+    ops.gemm(dlogits, Hp.w, M, d, Hp.Vpad, b_kstrided=True, ldb=d, out_f32=dhf, alpha_dev=go)
+    _wgrad(dlogits, hf16, Hp.Vpad, d, M, Hp.g_w, alpha_dev=go)
+    return dhf

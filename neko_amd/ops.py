@@ -1,0 +1,219 @@
+"""Tensor-level wrappers over the C ABI (one Python function per entry point of include/neko_hip.h).
+
+PyTorch is only plumbing here: it owns device memory and the stream; every computation is a
+libneko_hip.so kernel.  All functions enqueue on ``torch.cuda.current_stream()`` and return
+immediately.  Shape/dtype preconditions are asserted before the call.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+BF16 = torch.bfloat16
+SAFE_TRANSPOSE = int(os.environ.get("NEKO_GEMM_SAFE_T", "0"))
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(t: torch.Tensor, dtype, name: str):
+    assert t.is_cuda, f"{name} must be a device tensor"
+    assert t.dtype == dtype, f"{name} must be {dtype}, got {t.dtype}"
+
+
+def pick_splitk(M: int, N: int, K: int, target_blocks: int = 512) -> tuple:
+    """Split-K factor for skinny-output / long-K GEMMs (wgrad): enough blocks to fill 256 CUs."""
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    if tiles >= target_blocks // 2 or K <= 512:
+        return 1, 0
+    sk = min((target_blocks + tiles - 1) // tiles, (K + 255) // 256)
+    if sk <= 1:
+        return 1, 0
+    kps = ((K + sk - 1) // sk + 63) // 64 * 64
+    sk = (K + kps - 1) // kps
+    return (sk, kps) if sk > 1 else (1, 0)
+
+
+def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, a_kstrided=False, b_kstrided=False,
+         lda: Optional[int] = None, ldb: Optional[int] = None, alpha: float = 1.0,
+         alpha_dev: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None,
+         resid: Optional[torch.Tensor] = None, act: int = 0, act_in: Optional[torch.Tensor] = None,
+         pre_out: Optional[torch.Tensor] = None, out_f32: Optional[torch.Tensor] = None, ldcf: Optional[int] = None,
+         accumulate: bool = False, out_bf16: Optional[torch.Tensor] = None, ldcb: Optional[int] = None,
+         splitk: int = 1, k_per_split: int = 0, safe_transpose: Optional[int] = None) -> None:
+    """C[M,N] = alpha * opA(A) @ opB(B) (+bias)(act)(+resid)(+C).  See neko_gemm_bf16 in include/neko_hip.h."""
+    _chk(A, BF16, "A"); _chk(B, BF16, "B")
+    if lda is None:
+        lda = A.stride(0) if A.dim() == 2 else (M if a_kstrided else K)
+    if ldb is None:
+        ldb = B.stride(0) if B.dim() == 2 else (N if b_kstrided else K)
+    if bias is not None:
+        _chk(bias, torch.float32, "bias"); assert bias.numel() >= N
+    ldr = 0
+    if resid is not None:
+        _chk(resid, torch.float32, "resid"); ldr = resid.stride(0) if resid.dim() == 2 else N
+    ldact = ldpre = 0
+    if act_in is not None:
+        _chk(act_in, BF16, "act_in"); ldact = act_in.stride(0) if act_in.dim() == 2 else N
+    if pre_out is not None:
+        _chk(pre_out, BF16, "pre_out"); ldpre = pre_out.stride(0) if pre_out.dim() == 2 else N
+    if out_f32 is not None:
+        _chk(out_f32, torch.float32, "out_f32")
+        if ldcf is None:
+            ldcf = out_f32.stride(0) if out_f32.dim() == 2 else N
+    if out_bf16 is not None:
+        _chk(out_bf16, BF16, "out_bf16")
+        if ldcb is None:
+            ldcb = out_bf16.stride(0) if out_bf16.dim() == 2 else N
+    if alpha_dev is not None:
+        _chk(alpha_dev, torch.float32, "alpha_dev")
+    st = SAFE_TRANSPOSE if safe_transpose is None else safe_transpose
+    _lib.call("neko_gemm_bf16", _p(A), lda, int(a_kstrided), _p(B), ldb, int(b_kstrided), M, N, K, float(alpha),
+              _p(alpha_dev), _p(bias), _p(resid), ldr, act, _p(act_in), ldact, _p(pre_out), ldpre, _p(out_f32),
+              ldcf or 0, int(accumulate), _p(out_bf16), ldcb or 0, splitk, k_per_split, st, _stream())
+
+
+def layernorm_fwd(x, gamma, beta, y16=None, y32=None, mean=None, rstd=None, eps: float = 1e-5):
+    _chk(x, torch.float32, "x")
+    M, d = x.shape[0], x.shape[1]
+    assert x.is_contiguous()
+    _lib.call("neko_layernorm_fwd", _p(x), _p(gamma), _p(beta), _p(y16), _p(y32), _p(mean), _p(rstd), M, d,
+              float(eps), _stream())
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, g_in=None, dx=None, dx16=None, accumulate=True):
+    _chk(dy, torch.float32, "dy")
+    M, d = x.shape[0], x.shape[1]
+    nblk = _lib.load().neko_layernorm_bwd_blocks(M)
+    ws = torch.empty(nblk * 2 * d, dtype=torch.float32, device=x.device)
+    _lib.call("neko_layernorm_bwd", _p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(g_in), _p(dx), _p(dx16),
+              _p(dgamma), _p(dbeta), int(accumulate), _p(ws), M, d, _stream())
+
+
+def mask_bias(mask: torch.Tensor):
+    """(B,T) 0/1 float mask -> additive key bias (B,T) f32 and first-real-key index (B,) int32."""
+    _chk(mask, torch.float32, "mask")
+    B, T = mask.shape
+    mask = mask.contiguous()
+    kb = torch.empty(B, T, dtype=torch.float32, device=mask.device)
+    ks = torch.empty(B, dtype=torch.int32, device=mask.device)
+    _lib.call("neko_mask_bias", _p(mask), _p(kb), _p(ks), B, T, _stream())
+    return kb, ks
+
+
+def attn_fwd(qkv, kbias, kstart, B, T, H, hd):
+    _chk(qkv, BF16, "qkv")
+    out = torch.empty(B * T, H * hd, dtype=BF16, device=qkv.device)
+    lse = torch.empty(B, H, T, dtype=torch.float32, device=qkv.device)
+    _lib.call("neko_attn_fwd", _p(qkv), _p(kbias), _p(kstart), _p(out), _p(lse), B, T, H, hd, _stream())
+    return out, lse
+
+
+def attn_bwd(qkv, out, dout, kbias, kstart, lse, B, T, H, hd):
+    _chk(dout, BF16, "dout")
+    dev = qkv.device
+    D = torch.empty(B * H * T, dtype=torch.float32, device=dev)
+    qflags = torch.empty(B * ((T + 63) // 64), dtype=torch.int32, device=dev)
+    dqkv = torch.empty(B * T, 3 * H * hd, dtype=BF16, device=dev)
+    _lib.call("neko_attn_bwd", _p(qkv), _p(out), _p(dout), _p(kbias), _p(kstart), _p(lse), _p(D), _p(qflags),
+              _p(dqkv), B, T, H, hd, _stream())
+    return dqkv
+
+
+def ce_fwd_bwd(logits, V, Vpad, target, weight, loss_row=None, dlogits=None):
+    _chk(logits, torch.float32, "logits"); _chk(target, torch.int64, "target"); _chk(weight, torch.float32, "weight")
+    R = logits.shape[0]
+    _lib.call("neko_ce_fwd_bwd", _p(logits), logits.stride(0), V, Vpad, _p(target), _p(weight), _p(loss_row),
+              _p(dlogits), dlogits.stride(0) if dlogits is not None else 0, R, _stream())
+
+
+def pack_embed_fwd(desc, cont_vals, disc_vals, img_emb, embed, pos_embed, sep, ntok, d, mu, M, n_bins, cont_start,
+                   disc_start):
+    _chk(desc, torch.int32, "desc")
+    dev = embed.device
+    x = torch.empty(ntok, d, dtype=torch.float32, device=dev)
+    tokens = torch.empty(ntok, dtype=torch.int64, device=dev)
+    tmask = torch.empty(ntok, dtype=torch.float32, device=dev)
+    pmask = torch.empty(ntok, dtype=torch.float32, device=dev)
+    _lib.call("neko_pack_embed_fwd", _p(desc), _p(cont_vals), _p(disc_vals), _p(img_emb), _p(embed), _p(pos_embed),
+              _p(sep), _p(x), _p(tokens), _p(tmask), _p(pmask), ntok, d, float(mu), float(M), n_bins, cont_start,
+              disc_start, _stream())
+    return x, tokens, tmask, pmask
+
+
+def pack_embed_bwd(desc, tokens, dx, d_embed, d_pos, d_sep, d_img, ntok, d):
+    _chk(dx, torch.float32, "dx")
+    _lib.call("neko_pack_embed_bwd", _p(desc), _p(tokens), _p(dx), _p(d_embed), _p(d_pos), _p(d_sep), _p(d_img),
+              ntok, d, _stream())
+
+
+def tokenize_continuous(x, use_mu_law, mu, M, n_bins, offset):
+    _chk(x, torch.float32, "x")
+    x = x.contiguous()
+    ids = torch.empty(x.shape, dtype=torch.int32, device=x.device)
+    _lib.call("neko_tokenize_continuous", _p(x), _p(ids), x.numel(), int(use_mu_law), float(mu), float(M), n_bins,
+              offset if offset is not None else 0, _stream())
+    return ids
+
+
+def cast_f32_bf16(x, y):
+    _chk(x, torch.float32, "x"); _chk(y, BF16, "y")
+    _lib.call("neko_cast_f32_bf16", _p(x), _p(y), x.numel(), _stream())
+
+
+def colsum_bf16(x, M, N, out, accumulate=True, ld=None):
+    _chk(x, BF16, "x"); _chk(out, torch.float32, "out")
+    _lib.call("neko_colsum_bf16", _p(x), ld if ld is not None else x.stride(0), M, N, _p(out), int(accumulate),
+              _stream())
+
+
+def sqnorm_f32(g, out_accum):
+    _chk(g, torch.float32, "g"); _chk(out_accum, torch.float64, "out_accum")
+    _lib.call("neko_sqnorm_f32", _p(g), g.numel(), _p(out_accum), _stream())
+
+
+def adamw_step(p, g, m, v, p16, lr, beta1, beta2, eps, wd, gnorm_sq, max_norm, grad_scale, step, active):
+    _lib.call("neko_adamw_step", _p(p), _p(g), _p(m), _p(v), _p(p16), p.numel(), float(lr), float(beta1),
+              float(beta2), float(eps), float(wd), _p(gnorm_sq), float(max_norm), _p(grad_scale), _p(step),
+              _p(active), _stream())
+
+
+def patch_resblock_fwd(images, w1, b1, gw, gb, w2, b2, mid, groups, want_x=True):
+    assert images.is_cuda and images.dim() == 4 and images.shape[1] == 3
+    assert images.dtype in (torch.float32, torch.uint8)
+    images = images.contiguous()
+    n, _, H, W = images.shape
+    if H % 16 or W % 16:
+        raise AssertionError("Image dimensions must be divisible by patch size")
+    P = n * (H // 16) * (W // 16)
+    y16 = torch.empty(P, 768, dtype=BF16, device=images.device)
+    xp = torch.empty(P, 768, dtype=torch.float32, device=images.device) if want_x else None
+    _lib.call("neko_patch_resblock_fwd", _p(images), int(images.dtype == torch.uint8), n, H, W, _p(w1), _p(b1),
+              _p(gw), _p(gb), _p(w2), _p(b2), mid, groups, _p(y16), _p(xp), _stream())
+    return y16, xp
+
+
+def patch_resblock_bwd(xp, dy, w1, b1, gw, gb, w2, b2, mid, groups, dw1, db1, dgw, dgb, dw2, db2):
+    _chk(dy, torch.float32, "dy")
+    _lib.call("neko_patch_resblock_bwd", _p(xp), _p(dy), xp.shape[0], _p(w1), _p(b1), _p(gw), _p(gb), _p(w2), _p(b2),
+              mid, groups, _p(dw1), _p(db1), _p(dgw), _p(dgb), _p(dw2), _p(db2), _stream())
+
+
+def patch_pos_add(out, hpos, wpos, row_emb, col_emb):
+    P, d = out.shape
+    _lib.call("neko_patch_pos_add", _p(out), _p(hpos), _p(wpos), _p(row_emb), _p(col_emb), P, d, _stream())
+
+
+def patch_pos_add_bwd(dout, hpos, wpos, d_row, d_col):
+    P, d = dout.shape
+    _lib.call("neko_patch_pos_add_bwd", _p(dout), _p(hpos), _p(wpos), _p(d_row), _p(d_col), P, d, _stream())

@@ -1,0 +1,534 @@
+"""GatoPolicy on the MI355X HIP path -- drop-in for gato/policy/gato_policy.py:18-614.
+
+Same constructor signature, attributes (``.module``, ``.device``, ``.context_len``, ``.embed_dim``,
+``.transformer``, ``.text_tokenizer``, ``.token_starts/.token_ends``, ``.continuous_action_tokenizer``,
+``.image_embedding``, ``.embed_token``), ``state_dict`` keys/shapes and call signatures
+(``forward(inputs, compute_loss, **kwargs) -> (logits, loss)``, ``tokenize_input_dicts``, ``predict_*``).
+The nn.Modules are parameter containers; all compute between the batch dicts and the loss is
+hand-written HIP (neko_amd/csrc) driven by neko_amd.engine.  There is no CPU / eager fallback.
+
+Extra (optional, keyword-only) knobs that the reference does not have:
+  text_tokenizer=   an object with ``vocab_size`` (+ ``encode``/``decode``) used instead of
+                    ``AutoTokenizer.from_pretrained`` (no network on the GPU box);
+  forward(..., return_logits=False)  skips materialising the (B,T,V) fp32 logits that
+                    ``Trainer.train_step`` discards anyway (trainer.py:178).
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from typing import List, Optional, Sequence, Union
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import engine, ops
+from ..flat import FlatParams
+from ..transformers.trajectory_gpt2 import GPT2Config, GPT2Model
+from .embeddings import ImageEmbedding
+from .input_tokenizers import ContinuousTokenizer
+
+# descriptor kinds (neko_amd/csrc/pack_embed.hip)
+K_PAD, K_TOKEN, K_CONT_OBS, K_CONT_ACT, K_DISC, K_SEP, K_IMAGE, K_DEVID = 0, 1, 2, 3, 4, 5, 6, 7
+VPAD_ALIGN = 128
+
+
+class PackedBatch:
+    """Host-side result of laying out a list of batch dicts (gato_policy.py:245-431)."""
+
+    def __init__(self):
+        self.B = 0
+        self.T = 0
+        self.desc: Optional[np.ndarray] = None      # [B*T, 4] int32
+        self.cont: List[torch.Tensor] = []          # flattened continuous sources (obs and actions)
+        self.disc: List[torch.Tensor] = []          # flattened discrete / device-id sources
+        self.images: List[torch.Tensor] = []        # per image example: (n_ts,3,H,W)
+        self.given_img_emb: List[torch.Tensor] = [] # per example with precomputed embeddings: (n, P, d)
+        self.img_order: List[tuple] = []            # ('img', idx) | ('emb', idx) in example order
+
+
+def _as_2d_ids(t):
+    """gato_policy.py:264-273: list -> (1,L); 1-D tensor -> (1,L); 2-D kept."""
+    if isinstance(t, list):
+        a = np.asarray(t, dtype=np.int64)
+        return a.reshape(1, -1) if a.ndim == 1 else a
+    if t.dim() == 1:
+        return t.unsqueeze(0)
+    return t
+
+
+def build_layout(inputs: Sequence[dict], use_pos_encoding: bool, context_len: int, pad_seq: bool,
+                 n_patches_of=None) -> PackedBatch:
+    """Turn the list of example dicts into one descriptor table + source lists (host only, numpy).
+    Per timestep order [image patches | text | continuous obs | discrete obs | SEP | continuous act |
+    discrete act] (gato_policy.py:355); positions 0..n_obs-1 get a local position (:380-385);
+    left-pad to the longest example (:408-416); optional right-pad to context_len (:423-431)."""
+    pb = PackedBatch()
+    per_ex = []
+    cont_off = disc_off = img_off = 0
+    for ex in inputs:
+        n_ts = None
+
+        def set_ts(n):
+            nonlocal n_ts
+            if n_ts is None:
+                n_ts = n
+            else:
+                assert n_ts == n, "number of timesteps must be the same for all modalities"
+
+        segs = []   # (kind, per-ts count, src_base, host_ids or None, target)
+        text_seg = None
+        if ex.get("text") is not None:
+            ids = _as_2d_ids(ex["text"])
+            if isinstance(ids, np.ndarray) or not ids.is_cuda:
+                arr = ids if isinstance(ids, np.ndarray) else ids.to(torch.int64).numpy()
+                text_seg = (K_TOKEN, arr.shape[1], 0, arr.astype(np.int64), 1)
+            else:
+                flat = ids.to(torch.int32).reshape(-1)
+                text_seg = (K_DEVID, ids.shape[1], disc_off, None, 1)
+                pb.disc.append(flat)
+                disc_off += flat.numel()
+            n_ts = ids.shape[0]
+        if ex.get("images") is not None or ex.get("image_embeddings") is not None:
+            if ex.get("image_embeddings") is not None:
+                e = ex["image_embeddings"]
+                n_img, n_patch = e.shape[0], e.shape[1]
+                pb.given_img_emb.append(e)
+                pb.img_order.append(("emb", len(pb.given_img_emb) - 1))
+            else:
+                im = ex["images"]
+                n_img = im.shape[0]
+                n_patch = (im.shape[2] // 16) * (im.shape[3] // 16)
+                assert im.shape[2] % 16 == 0 and im.shape[3] % 16 == 0, "Image dimensions must be divisible by patch size"
+                pb.images.append(im)
+                pb.img_order.append(("img", len(pb.images) - 1))
+            segs.append((K_IMAGE, n_patch, img_off, None, 0))
+            img_off += n_img * n_patch
+            set_ts(n_img)
+        if text_seg is not None:
+            segs.append(text_seg)
+        if ex.get("continuous_obs") is not None:
+            t = ex["continuous_obs"]
+            segs.append((K_CONT_OBS, t.shape[1], cont_off, None, 0))
+            pb.cont.append(t.reshape(-1))
+            cont_off += t.numel()
+            set_ts(t.shape[0])
+        if ex.get("discrete_obs") is not None:
+            t = ex["discrete_obs"]
+            segs.append((K_DISC, t.shape[1], disc_off, None, 0))
+            pb.disc.append(t.reshape(-1))
+            disc_off += t.numel()
+            set_ts(t.shape[0])
+        n_obs = sum(s[1] for s in segs)
+        segs.append((K_SEP, 1, 0, None, 0))
+        if ex.get("continuous_actions") is not None:
+            t = ex["continuous_actions"]
+            segs.append((K_CONT_ACT, t.shape[1], cont_off, None, 1))
+            pb.cont.append(t.reshape(-1))
+            cont_off += t.numel()
+            set_ts(t.shape[0])
+        if ex.get("discrete_actions") is not None:
+            t = ex["discrete_actions"]
+            segs.append((K_DISC, t.shape[1], disc_off, None, 1))
+            pb.disc.append(t.reshape(-1))
+            disc_off += t.numel()
+            set_ts(t.shape[0])
+        assert n_ts is not None, "example has no modality"
+        tp = sum(s[1] for s in segs)
+        d = np.zeros((n_ts, tp, 4), dtype=np.int64)
+        col = 0
+        ts = np.arange(n_ts, dtype=np.int64)[:, None]
+        for kind, cnt, base, host_ids, tgt in segs:
+            j = np.arange(cnt, dtype=np.int64)[None, :]
+            d[:, col:col + cnt, 0] = kind
+            if kind == K_TOKEN:
+                d[:, col:col + cnt, 1] = host_ids
+            elif kind != K_SEP:
+                d[:, col:col + cnt, 1] = base + ts * cnt + j
+            d[:, col:col + cnt, 3] = tgt
+            col += cnt
+        d[:, :, 2] = -1
+        if use_pos_encoding:
+            d[:, :n_obs, 2] = np.arange(n_obs, dtype=np.int64)[None, :]
+        per_ex.append(d.reshape(n_ts * tp, 4))
+    T = max(e.shape[0] for e in per_ex)
+    T_out = context_len if (pad_seq and context_len > T) else T
+    B = len(per_ex)
+    desc = np.zeros((B, T_out, 4), dtype=np.int32)
+    desc[:, :, 2] = -1
+    for i, e in enumerate(per_ex):
+        desc[i, T - e.shape[0]:T] = e
+    pb.B, pb.T, pb.desc = B, T_out, desc.reshape(B * T_out, 4)
+    return pb
+
+
+class _PolicyCoreFn(torch.autograd.Function):
+    """packed embeddings -> (logits | empty, loss | empty): transformer stack + LM head + masked CE."""
+
+    @staticmethod
+    def forward(ctx, policy: "GatoPolicy", x, pmask, tokens, tmask, compute_loss: bool, return_logits: bool, *params):
+        need = torch.is_grad_enabled() and compute_loss and (x.requires_grad or any(p.requires_grad for p in params))
+        f = policy._flat
+        f.ensure_shadow()
+        B, T, d = x.shape
+        sp = policy.transformer._stack_params()
+        hf16, _, sctx = engine.stack_forward(sp, x.detach().to(torch.float32), pmask, save=need)
+        hp = policy._head_params()
+        logits = engine.lm_head_logits(hp, hf16).view(B, T, hp.V) if return_logits else x.new_zeros(0)
+        loss = x.new_zeros(())
+        dlogits = None
+        if compute_loss:
+            target, sel, count = engine.shift_targets(tokens, tmask, pmask)
+            loss, dlogits = engine.lm_head_loss(hp, hf16, target, sel, count, want_grad=need,
+                                                chunk_rows=policy.lm_head_chunk_rows)
+        ctx.policy, ctx.sctx, ctx.hf16, ctx.dlogits, ctx.shape = policy, sctx, hf16 if need else None, dlogits, (B, T, d)
+        ctx.mark_non_differentiable(logits)
+        return logits, loss
+
+    @staticmethod
+    def backward(ctx, _g_logits, g_loss):
+        policy = ctx.policy
+        f = policy._flat
+        B, T, d = ctx.shape
+        names = policy.transformer._param_names() + ["predict_token.weight"]
+        f.prepare_backward(names)
+        dp = policy._dp
+        dhf = engine.lm_head_backward(policy._head_params(), ctx.hf16, ctx.dlogits, g_loss)
+        if dp is not None:
+            dp.group_ready("head")
+
+        def layer_done(i):
+            if dp is not None:
+                dp.group_ready("lnf" if i == len(policy.transformer.h) else f"layer{i}")
+
+        gx = engine.stack_backward(policy.transformer._stack_params(), ctx.sctx, dhf, on_layer_done=layer_done)
+        f.attach_grads(names)
+        ctx.sctx = ctx.hf16 = ctx.dlogits = None
+        return (None, gx.view(B, T, d)) + (None,) * (len(ctx.needs_input_grad) - 2)
+
+
+class _StubTokenizer:
+    def __init__(self, vocab_size):
+        self.vocab_size = vocab_size
+
+    def encode(self, s):
+        raise RuntimeError("no text tokenizer loaded (offline); pass text_tokenizer=...")
+
+    def decode(self, ids):
+        return " ".join(str(int(i)) for i in ids)
+
+
+class GatoPolicy(nn.Module):
+    def __init__(
+        self,
+        device: Union[torch.device, str],
+        embed_dim: int,
+        layers: int,
+        heads: int,
+        dropout: float,
+        activation_fn="gelu",
+        mu: int = 100,
+        M: int = 256,
+        patch_size: int = 16,
+        resid_mid_channels: int = 132,
+        num_groups: int = 32,
+        position_vocab_size: int = 128,
+        continuous_tokens: int = 1024,
+        discrete_tokens: int = 1024,
+        context_len=1024,
+        use_pos_encoding: bool = True,
+        use_patch_pos_encoding: bool = True,
+        pretrained_lm: Optional[str] = None,
+        flash: bool = False,
+        tokenizer_model_name: str = "gpt2",
+        pad_seq: bool = False,
+        *,
+        text_tokenizer=None,
+    ):
+        super().__init__()
+        self.device = device
+        self.context_len = context_len
+        self.pad_seq = pad_seq
+        self.mu, self.M = mu, M
+
+        # Text tokenizer (gato_policy.py:57): only vocab_size / encode / decode are used
+        if text_tokenizer is None:
+            try:
+                from transformers import AutoTokenizer
+                text_tokenizer = AutoTokenizer.from_pretrained(tokenizer_model_name)
+            except Exception as e:  # offline box
+                raise RuntimeError(
+                    f"could not load tokenizer '{tokenizer_model_name}' ({type(e).__name__}); pass "
+                    "text_tokenizer=<object with vocab_size/encode/decode> when there is no network") from e
+        elif isinstance(text_tokenizer, int):
+            text_tokenizer = _StubTokenizer(text_tokenizer)
+        self.text_tokenizer = text_tokenizer
+
+        self.text_tokens = self.text_tokenizer.vocab_size                            # :60-63
+        self.continuous_tokens = continuous_tokens
+        self.discrete_tokens = discrete_tokens
+        self.vocab_size = self.text_tokens + self.discrete_tokens + self.continuous_tokens
+        self.token_starts = {"text": 0, "continuous": self.text_tokens,
+                             "discrete": self.text_tokens + self.continuous_tokens}   # :66-70
+        self.token_ends = {"text": self.text_tokens - 1,
+                           "continuous": self.text_tokens + self.continuous_tokens - 1,
+                           "discrete": self.text_tokens + self.continuous_tokens + self.discrete_tokens - 1}
+
+        if pretrained_lm is not None:
+            raise NotImplementedError("pretrained_lm / LoRA (gato_policy.py:79-95) needs downloaded weights; "
+                                      "out of scope of the HIP hot path (SURVEY.md 2.1 #16)")
+        if activation_fn == "geglu":
+            raise NotImplementedError("activation_fn='geglu' is not on the HIP path (no BASELINE config uses it)")
+        if embed_dim % heads != 0:
+            raise AssertionError("embed_dim must be divisible by heads")   # trajectory_gpt2.py:126
+        if embed_dim // heads not in (32, 64, 128) or embed_dim % 8:
+            raise NotImplementedError(f"head dim {embed_dim // heads} unsupported by the HIP attention kernel "
+                                      "(supported: 32, 64, 128)")
+        if resid_mid_channels % num_groups != 0:
+            # the reference's own default (132, 32) dies inside nn.GroupNorm with this error
+            raise ValueError("num_channels must be divisible by num_groups")
+        config = GPT2Config(vocab_size=1, n_embd=embed_dim, n_head=heads, n_layer=layers, resid_pdrop=dropout,
+                            attn_pdrop=dropout, n_positions=context_len, n_inner=embed_dim * 4,
+                            activation_function=activation_fn, n_ctx=context_len, flash=flash, gate=False)
+        self.transformer = GPT2Model(config)                                         # :115
+        self.embed_token = nn.Embedding(self.vocab_size, embed_dim)                  # :117
+        self.embed_dim = embed_dim
+        self.predict_token = nn.Linear(embed_dim, self.vocab_size, bias=False)       # :122
+        self.separator_token = nn.Parameter(torch.zeros(embed_dim))                  # :124
+        self.continuous_action_tokenizer = ContinuousTokenizer(
+            use_mu_law=False, mu=mu, M=M, n_bins=self.continuous_tokens, offset=self.token_starts["continuous"])
+        self.continuous_obs_tokenizer = ContinuousTokenizer(
+            use_mu_law=True, mu=mu, M=M, n_bins=self.continuous_tokens, offset=self.token_starts["continuous"])
+        self.use_patch_pos_encoding = use_patch_pos_encoding
+        self.image_embedding = ImageEmbedding(embed_dim=embed_dim, patch_size=patch_size,
+                                              resid_mid_channels=resid_mid_channels, num_groups=num_groups,
+                                              position_vocab_size=position_vocab_size,
+                                              use_pos_encoding=self.use_patch_pos_encoding)
+        self.use_pos_encoding = use_pos_encoding
+        self.pos_embed_observation = nn.Embedding(context_len, embed_dim)            # :149
+
+        self.lm_head_chunk_rows = 4096
+        self._dp = None
+        self._hp = None
+        self._flat: Optional[FlatParams] = None
+        self._flatten(torch.device(device))
+
+    # ---- flat storage ----------------------------------------------------------------------------
+    def _flatten(self, device: torch.device) -> None:
+        named = dict(self.named_parameters())
+        groups: "OrderedDict[str, list]" = OrderedDict()
+        groups["frontend"] = [(n, named[n]) for n in ("embed_token.weight", "pos_embed_observation.weight",
+                                                      "separator_token")]
+        groups["image"] = [(n, named[n]) for n in self.image_embedding.flat_param_names("image_embedding.")]
+        for g, plist in self.transformer.param_groups_for_flat("transformer.").items():
+            groups[g] = plist
+        groups["head"] = [("predict_token.weight", named["predict_token.weight"])]
+        groups["never"] = [("transformer.wte.weight", named["transformer.wte.weight"])]
+        self.Vpad = (self.vocab_size + VPAD_ALIGN - 1) // VPAD_ALIGN * VPAD_ALIGN
+        self._flat = FlatParams(groups, device, padded_numel={"predict_token.weight": self.Vpad * self.embed_dim})
+        self.transformer.attach_flat(self._flat, "transformer.")
+        self.image_embedding.attach_flat(self._flat, "image_embedding.")
+        self._hp = None
+
+    def _apply(self, fn, *a, **k):
+        # .to()/.cuda()/.float() re-materialise parameters: rebuild the flat storage afterwards
+        super()._apply(fn, *a, **k)
+        if getattr(self, "_flat", None) is not None:
+            dev = next(self.parameters()).device
+            if dev != self._flat.device:
+                self.device = dev
+            self._flatten(dev)
+        return self
+
+    def _frontend_names(self) -> List[str]:
+        n = ["embed_token.weight", "separator_token"]
+        if self.use_pos_encoding:
+            n.append("pos_embed_observation.weight")
+        return n
+
+    def _head_params(self) -> engine.HeadParams:
+        if self._hp is None:
+            self._hp = engine.HeadParams(V=self.vocab_size, Vpad=self.Vpad,
+                                         w=self._flat.sview("predict_token.weight", padded_rows=self.Vpad),
+                                         g_w=self._flat.gview("predict_token.weight", padded_rows=self.Vpad))
+        return self._hp
+
+    @property
+    def module(self):
+        return self
+
+    def _dev(self) -> torch.device:
+        return self._flat.device
+
+    # ---- packing (gato_policy.py:195-432) -----------------------------------------------------------
+    def tokenize_input_dicts(self, inputs: list):
+        """Returns (token_embeddings (B,T,d) f32, tokens (B,T) i64, token_target_masks (B,T) f32,
+        token_masks (B,T) f32) like the reference; the work is one descriptor upload + HIP kernels."""
+        dev = self._dev()
+        if dev.type != "cuda":
+            raise RuntimeError("neko_amd.GatoPolicy computes on the GPU only (no CPU fallback)")
+        pb = build_layout(inputs, self.use_pos_encoding, self.context_len, self.pad_seq)
+        desc = torch.from_numpy(pb.desc).pin_memory().to(dev, non_blocking=True)
+        cont = (torch.cat([t.to(dev, torch.float32) for t in pb.cont]) if pb.cont else None)
+        disc = (torch.cat([t.to(dev, torch.int32) for t in pb.disc]) if pb.disc else None)
+        img_emb = None
+        if pb.img_order:
+            parts = []
+            for kind, idx in pb.img_order:
+                if kind == "img":
+                    e = self.image_embedding(pb.images[idx])          # (n, P, d), positions drawn per example
+                else:
+                    e = pb.given_img_emb[idx].to(dev, torch.float32)
+                parts.append(e.reshape(-1, self.embed_dim))
+            img_emb = parts[0] if len(parts) == 1 else torch.cat(parts, dim=0)
+        params = [self._flat.param_of[n] for n in self._frontend_names()]
+        x, tokens, tmask, pmask = _PackEmbedV2.apply(self, desc, cont, disc, img_emb, pb.B * pb.T, *params)
+        B, T, d = pb.B, pb.T, self.embed_dim
+        return x.view(B, T, d), tokens.view(B, T), tmask.view(B, T), pmask.view(B, T)
+
+    # ---- forward (gato_policy.py:156-192) -------------------------------------------------------------
+    def forward(self, inputs: Optional[list] = None, compute_loss=False, **kwargs):
+        return_logits = kwargs.pop("return_logits", True)
+        if inputs is not None:
+            token_embeddings, tokens, token_target_masks, token_masks = self.tokenize_input_dicts(inputs)
+        else:
+            assert ("token_embeddings" in kwargs and "tokens" in kwargs and "token_target_masks" in kwargs
+                    and "token_masks" in kwargs), "if inputs is None, must provide embeddings, tokens, and masks"
+            token_embeddings = kwargs["token_embeddings"]
+            tokens = kwargs["tokens"]
+            token_target_masks = kwargs["token_target_masks"]
+            token_masks = kwargs["token_masks"]
+        if not token_embeddings.is_cuda:
+            raise RuntimeError("neko_amd.GatoPolicy computes on the GPU only (no CPU fallback)")
+        self.transformer.check_dropout()
+        if compute_loss:
+            assert tokens is not None and token_target_masks is not None, "compute_loss needs tokens and target masks"
+        names = self.transformer._param_names() + ["predict_token.weight"]
+        params = [self._flat.param_of[n] for n in names]
+        logits, loss = _PolicyCoreFn.apply(self, token_embeddings, token_masks.to(torch.float32), tokens,
+                                           token_target_masks, bool(compute_loss), bool(return_logits), *params)
+        return (logits if return_logits else None), (loss if compute_loss else None)
+
+    # ---- inference helpers (gato_policy.py:434-614): same loops, full forward per token -----------------
+    @torch.no_grad()
+    def predict_text(self, batch_dict, max_length=20, deterministic=True):
+        start_token, end_token = self.token_starts["text"], self.token_ends["text"]
+        token_embeddings, _, _, token_masks = self.tokenize_input_dicts([batch_dict])
+        concat_logits, predicted_tokens = None, []
+        for _ in range(max_length):
+            logits, _ = self.forward(token_embeddings=token_embeddings, token_masks=token_masks,
+                                     token_target_masks=None, tokens=None)
+            logits = logits[0, -1, start_token:(end_token + 1)]
+            concat_logits = logits.unsqueeze(0) if concat_logits is None else torch.cat([concat_logits, logits.unsqueeze(0)], dim=0)
+            if deterministic:
+                token = torch.argmax(logits, dim=-1)
+            else:
+                token = torch.multinomial(torch.nn.functional.softmax(logits, dim=-1), num_samples=1)[0]
+            token = token + start_token
+            token_masks = torch.cat([token_masks, torch.ones(token_masks.shape[0], 1, device=token_masks.device)], dim=1)
+            new_embedding = self._flat.view("embed_token.weight")[token]
+            token_embeddings = torch.cat([token_embeddings, new_embedding.reshape(1, 1, -1)], dim=1)
+            token_embeddings = token_embeddings[:, -self.context_len:, :]
+            token_masks = token_masks[:, -self.context_len:]
+            predicted_tokens.append(token)
+        return concat_logits, predicted_tokens
+
+    @torch.no_grad()
+    def predict_response(self, image, prompt_tokens=[], max_length=128, deterministic=True):
+        start_token, end_token = self.token_starts["text"], self.token_ends["text"]
+        image_embeddings = self.image_embedding(image)
+        n_images, n_patches = image_embeddings.shape[0], image_embeddings.shape[1]
+        assert n_images == 1, "number of images should always be 1 for predicting response"
+        pred_logits, response_tokens = None, []
+        for idx in range(max_length):
+            batch_dict = {"image_embeddings": image_embeddings, "text": torch.tensor(prompt_tokens + response_tokens)}
+            logits, _ = self.forward([batch_dict])
+            assert logits.shape[0] == 1, "batch size should always be 1 for predicting response"
+            nxt = logits[0, n_patches - 1 + len(prompt_tokens) + idx, start_token:(end_token + 1)]
+            if deterministic:
+                next_token = torch.argmax(nxt).item()
+            else:
+                next_token = torch.multinomial(torch.nn.functional.softmax(nxt, dim=-1), num_samples=1).item()
+            pred_logits = nxt.unsqueeze(0) if pred_logits is None else torch.cat([pred_logits, nxt.unsqueeze(0)], dim=0)
+            response_tokens.append(next_token)
+        return pred_logits, self.text_tokenizer.decode(response_tokens)
+
+    def predict_caption(self, image, max_length=128, deterministic=True):
+        return self.predict_response(image, prompt_tokens=[], max_length=max_length, deterministic=deterministic)
+
+    def predict_answer(self, image, question, max_length=16, deterministic=True):
+        return self.predict_response(image, prompt_tokens=self.text_tokenizer.encode(question), max_length=max_length,
+                                     deterministic=deterministic)
+
+    @torch.no_grad()
+    def predict_control(self, input: dict, task, deterministic: bool = True):
+        """gato_policy.py:556-614.  ``task.action_type`` is compared by class name (gymnasium is not a dependency)."""
+        kind = getattr(task.action_type, "__name__", str(task.action_type))
+        action_tokens = task.action_tokens
+        if kind == "Discrete":
+            action_str = "discrete"
+            assert action_tokens == 1, "only support 1 discrete action token"
+        else:
+            action_str = "continuous"
+        start_token, end_token = self.token_starts[action_str], self.token_ends[action_str]
+        if action_str == "discrete":
+            assert task.env.action_space.n <= self.discrete_tokens, "discrete action space too large for model"
+            end_token = start_token + task.env.action_space.n - 1
+        token_embeddings, _, _, token_masks = self.tokenize_input_dicts([input])
+        token_embeddings = token_embeddings[:, :-action_tokens, :]
+        token_masks = token_masks[:, :-action_tokens]
+        predicted_tokens = []
+        for _ in range(action_tokens):
+            logits, _ = self.forward(token_embeddings=token_embeddings.contiguous(), token_masks=token_masks.contiguous(),
+                                     token_target_masks=None, tokens=None)
+            logits = logits[0, -1, start_token:(end_token + 1)]
+            if deterministic:
+                token = torch.argmax(logits, dim=-1)
+            else:
+                token = torch.multinomial(torch.nn.functional.softmax(logits, dim=-1), num_samples=1)[0]
+            token = token + start_token
+            token_masks = torch.cat([token_masks, torch.ones(token_masks.shape[0], 1, device=token_masks.device)], dim=1)
+            new_embedding = self._flat.view("embed_token.weight")[token]
+            token_embeddings = torch.cat([token_embeddings, new_embedding.reshape(1, 1, -1)], dim=1)
+            token_embeddings = token_embeddings[:, -self.context_len:, :]
+            token_masks = token_masks[:, -self.context_len:]
+            predicted_tokens.append(token)
+        if kind == "Discrete":
+            return predicted_tokens[0] - start_token
+        return self.continuous_action_tokenizer.decode(torch.stack(predicted_tokens, dim=0))
+
+
+class _PackEmbedV2(torch.autograd.Function):
+    """Packing front-end: descriptor table -> (x, tokens, target mask, pad mask); backward scatters
+    d_x into embed_token / pos_embed_observation / separator_token grads and returns d(img_emb)."""
+
+    @staticmethod
+    def forward(ctx, policy: GatoPolicy, desc, cont, disc, img_emb, ntok, *params):
+        f = policy._flat
+        d = policy.embed_dim
+        img = None if img_emb is None else img_emb.detach().contiguous()
+        x, tokens, tmask, pmask = ops.pack_embed_fwd(
+            desc, cont, disc, img, f.view("embed_token.weight"), f.view("pos_embed_observation.weight"),
+            f.view("separator_token"), ntok, d, policy.mu, policy.M, policy.continuous_tokens,
+            policy.token_starts["continuous"], policy.token_starts["discrete"])
+        ctx.policy, ctx.desc, ctx.tokens, ctx.ntok = policy, desc, tokens, ntok
+        ctx.img_rows = 0 if img_emb is None else img_emb.shape[0]
+        ctx.mark_non_differentiable(tokens, tmask, pmask)
+        return x, tokens, tmask, pmask
+
+    @staticmethod
+    def backward(ctx, gx, *_unused):
+        policy = ctx.policy
+        f, d = policy._flat, policy.embed_dim
+        names = policy._frontend_names()
+        f.prepare_backward(names + ([] if policy.use_pos_encoding else ["pos_embed_observation.weight"]))
+        gx = gx.contiguous().to(torch.float32)
+        d_img = None
+        if ctx.img_rows > 0 and ctx.needs_input_grad[4]:
+            d_img = torch.zeros(ctx.img_rows, d, dtype=torch.float32, device=gx.device)
+        ops.pack_embed_bwd(ctx.desc, ctx.tokens, gx.view(-1, d), f.gview("embed_token.weight"),
+                           f.gview("pos_embed_observation.weight"), f.gview("separator_token"), d_img, ctx.ntok, d)
+        f.attach_grads(names)
+        if policy._dp is not None:
+            policy._dp.group_ready("frontend")
+        return (None, None, None, None, d_img, None) + (None,) * (len(ctx.needs_input_grad) - 6)

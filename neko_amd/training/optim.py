@@ -1,0 +1,94 @@
+"""Fused optimiser tail of Trainer.train_step (gato/training/trainer.py:181-186, train.py:127-133):
+global grad-norm -> clip -> AdamW -> bf16 weight-shadow refresh, as a few HIP launches over the flat
+parameter ranges, with no host synchronisation (norm, clip coefficient, step counters and the
+"range took part in this step" flags live on the device).
+
+torch semantics kept: decoupled weight decay on every parameter (no groups), bias correction with a
+per-range step count, parameters whose grad is None this step (transformer.wte always;
+image_embedding.* on image-free batches; the embedding tables when the caller passed embeddings
+directly) are skipped entirely -- no decay, no moment update, no step increment.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+
+from .. import ops
+
+
+class NekoAdamW(torch.optim.Optimizer):
+    """Drop-in for ``torch.optim.AdamW(model.parameters(), lr, betas, eps, weight_decay)`` on a neko_amd
+    GatoPolicy.  ``step()`` = clip (if ``clip_grad_norm_`` was called since the last step) + AdamW."""
+
+    def __init__(self, model, lr=1e-4, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.1):
+        params = [p for p in model.parameters() if p.requires_grad]
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.model = model
+        f = model._flat
+        self.flat = f
+        dev = f.device
+        self.m = torch.zeros_like(f.data)
+        self.v = torch.zeros_like(f.data)
+        self.groups = [g for g in f.group_ranges if g != "never"]
+        self.steps: Dict[str, torch.Tensor] = {g: torch.zeros(1, dtype=torch.int32, device=dev) for g in self.groups}
+        self.active = torch.zeros(len(self.groups), dtype=torch.int32, device=dev)
+        self._active_host = torch.zeros(len(self.groups), dtype=torch.int32)
+        if dev.type == "cuda":
+            self._active_host = self._active_host.pin_memory()
+        self.gnorm_sq = torch.zeros(1, dtype=torch.float64, device=dev)
+        self._pending_clip: Optional[float] = None
+        self.grad_scale: Optional[torch.Tensor] = None    # set by the DP reducer (1/world)
+        self.flags_reduce = None                          # DP: callable(active tensor) -> union over ranks
+
+    # which ranges received gradients this step (host knowledge: param.grad attached by the backward)
+    def _active_groups(self):
+        f = self.flat
+        act = []
+        for g in self.groups:
+            a, b = f.group_ranges[g]
+            has = any(f.param_of[n].grad is not None for n, (o, _, _) in f.offsets.items() if a <= o < b)
+            act.append(1 if has else 0)
+        return act
+
+    def clip_grad_norm_(self, max_norm: float) -> torch.Tensor:
+        """Like ``accelerator.clip_grad_norm_(model.parameters(), max_norm)`` (trainer.py:182): computes the global
+        L2 norm now (device scalar, returned without sync) and applies the clip inside the next ``step()``."""
+        f = self.flat
+        act = self._active_groups()
+        self.gnorm_sq.zero_()
+        for g, on in zip(self.groups, act):
+            if on or self.flags_reduce is not None:    # DP: another rank may have used the range (zeros add 0)
+                a, b = f.group_ranges[g]
+                ops.sqnorm_f32(f.grad[a:b], self.gnorm_sq)
+        self._pending_clip = float(max_norm)
+        gs = 1.0 if self.grad_scale is None else self.grad_scale
+        return self.gnorm_sq.sqrt().to(torch.float32) * gs
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        f = self.flat
+        grp = self.param_groups[0]
+        lr, (b1, b2), eps, wd = grp["lr"], grp["betas"], grp["eps"], grp["weight_decay"]
+        act = self._active_groups()
+        self._active_host.copy_(torch.tensor(act, dtype=torch.int32))
+        self.active.copy_(self._active_host, non_blocking=True)
+        if self.flags_reduce is not None:
+            self.flags_reduce(self.active)
+        clip = self._pending_clip
+        for i, g in enumerate(self.groups):
+            if not act[i] and self.flags_reduce is None:
+                continue
+            a, b = f.group_ranges[g]
+            ops.adamw_step(f.data[a:b], f.grad[a:b], self.m[a:b], self.v[a:b], f.shadow[a:b], lr, b1, b2, eps, wd,
+                           self.gnorm_sq if clip is not None else None, clip if clip is not None else 0.0,
+                           self.grad_scale, self.steps[g], self.active[i:i + 1])
+        self._pending_clip = None
+        f.mark_shadow_fresh()
+
+    def zero_grad(self, set_to_none: bool = True):
+        """One memset of the flat gradient; ``.grad`` of every parameter is detached again (set to None) so the
+        next backward knows which parameters took part (torch's set_to_none semantics)."""
+        self.flat.zero_grad()
+        for p in self.flat.param_of.values():
+            p.grad = None

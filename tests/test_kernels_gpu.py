@@ -1,0 +1,319 @@
+"""Kernel-level parity: every HIP entry point (through the C ABI) against the CPU oracle / a plain
+torch fp32 reference on the same seeded inputs.  Inputs of bf16 kernels are pre-rounded to bf16 so
+the only differences are fp32 summation order and the documented bf16 output rounding.
+
+Tolerances (stated per test): fp32 outputs of bf16-operand GEMMs rtol 2e-4 of the row scale;
+bf16 outputs 2^-8 relative (one bf16 ulp) + the same; fp32 kernels (LayerNorm, CE, AdamW) 1e-5.
+"""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import neko_oracle as O  # noqa: E402
+
+DEV = "cuda"
+
+
+def rb(x):
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+def bf(x):
+    return x.to(torch.bfloat16).to(DEV).contiguous()
+
+
+def close(a, b, rtol, atol, what=""):
+    a = a.detach().float().cpu()
+    b = b.detach().float().cpu()
+    err = (a - b).abs()
+    tol = atol + rtol * b.abs()
+    bad = err > tol
+    assert not bad.any(), (f"{what}: {int(bad.sum())}/{bad.numel()} mismatches, max err {float(err.max()):.4g} "
+                           f"(tol at worst {float(tol[bad].min()):.4g}), ref scale {float(b.abs().max()):.4g}")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from neko_amd import ops as o
+    return o
+
+
+# ----------------------------------------------------------------------------------------------------
+# GEMM
+# ----------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("safe", [0, 1])
+@pytest.mark.parametrize("layout", ["nt", "nn", "tn"])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 136, 264), (77, 520, 1000), (512, 2304, 768)])
+def test_gemm_layouts(ops, layout, M, N, K, safe):
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    A = rb(torch.randn(M, K, generator=g))          # logical [M,K]
+    Bm = rb(torch.randn(K, N, generator=g) * 0.5)   # logical [K,N]  (asymmetric: transposes are visible)
+    ref = A @ Bm
+    if layout == "tn" and M % 8:
+        M8 = (M + 7) // 8 * 8
+        A = torch.cat([A, torch.zeros(M8 - M, K)]); ref = A @ Bm; M = M8
+    if layout in ("nn", "tn") and N % 8:
+        pytest.skip("contiguous extents must be multiples of 8")
+    a_ks = layout == "tn"
+    b_ks = layout in ("nn", "tn")
+    A_dev = bf(A.t()) if a_ks else bf(A)
+    B_dev = bf(Bm) if b_ks else bf(Bm.t())
+    if (not a_ks or not b_ks) and K % 8:
+        pytest.skip("K must be a multiple of 8 for k-contiguous operands")
+    out = torch.full((M, N), float("nan"), device=DEV)
+    ops.gemm(A_dev, B_dev, M, N, K, a_kstrided=a_ks, b_kstrided=b_ks, out_f32=out, safe_transpose=safe)
+    torch.cuda.synchronize()
+    close(out, ref, 2e-4, 2e-4 * math.sqrt(K), f"gemm {layout} safe={safe}")
+
+
+def test_gemm_epilogues(ops):
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 300, 256, 192
+    A, W = rb(torch.randn(M, K, generator=g)), rb(torch.randn(K, N, generator=g) * 0.1)
+    bias, resid = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    Ad, Wd = bf(A), bf(W)
+    # bias + GELU (+ pre-activation store), bf16 out
+    pre = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    h = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(Ad, Wd, M, N, K, b_kstrided=True, bias=bias.to(DEV), act=1, pre_out=pre, out_bf16=h)
+    pre_ref = rb(A @ W + bias)
+    close(pre, pre_ref, 2 ** -8, 1e-3, "pre")
+    close(h, torch.nn.functional.gelu(pre.float().cpu()), 2 ** -8, 1e-3, "gelu")
+    # bias + residual, f32 out
+    out = torch.empty(M, N, device=DEV)
+    ops.gemm(Ad, Wd, M, N, K, b_kstrided=True, bias=bias.to(DEV), resid=resid.to(DEV), out_f32=out)
+    close(out, A @ W + bias + resid, 1e-4, 1e-3, "bias+resid")
+    # accumulate + alpha + device alpha
+    acc0 = torch.randn(M, N, generator=g)
+    out = acc0.clone().to(DEV)
+    ad = torch.tensor([0.25], device=DEV)
+    ops.gemm(Ad, Wd, M, N, K, b_kstrided=True, alpha=2.0, alpha_dev=ad, out_f32=out, accumulate=True)
+    close(out, acc0 + 0.5 * (A @ W), 1e-4, 1e-3, "accumulate/alpha")
+    # gelu backward epilogue: dY @ W2^T * gelu'(pre)
+    dY = rb(torch.randn(M, K, generator=g))
+    W2 = rb(torch.randn(N, K, generator=g) * 0.1)         # (in=N, out=K) Conv1D layout -> dgrad uses it k-contiguous
+    dpre = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(bf(dY), bf(W2), M, N, K, act=2, act_in=pre, out_bf16=dpre)
+    x = pre.float().cpu()
+    gprime = 0.5 * (1 + torch.erf(x / math.sqrt(2))) + x * torch.exp(-0.5 * x * x) / math.sqrt(2 * math.pi)
+    close(dpre, (dY @ W2.t()) * gprime, 2 ** -8, 2e-3, "gelu bwd")
+    # split-K atomics (wgrad form)
+    Mk = 4096
+    X, dYk = rb(torch.randn(Mk, 64, generator=g)), rb(torch.randn(Mk, 136, generator=g))
+    dW = torch.zeros(64, 136, device=DEV)
+    sk, kps = ops.pick_splitk(64, 136, Mk)
+    assert sk > 1
+    ops.gemm(bf(X), bf(dYk), 64, 136, Mk, a_kstrided=True, b_kstrided=True, out_f32=dW, splitk=sk, k_per_split=kps)
+    close(dW, X.t() @ dYk, 1e-4, 2e-2, "split-K wgrad")
+
+
+# ----------------------------------------------------------------------------------------------------
+# LayerNorm
+# ----------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,d", [(5, 64), (333, 128), (1000, 768), (64, 2048)])
+def test_layernorm_fwd_bwd(ops, M, d):
+    g = torch.Generator().manual_seed(d + M)
+    x = torch.randn(M, d, generator=g) * 2 + 0.3
+    w, b = torch.randn(d, generator=g), torch.randn(d, generator=g)
+    dy, gin = torch.randn(M, d, generator=g), torch.randn(M, d, generator=g)
+    xr = x.clone().requires_grad_(True); wr = w.clone().requires_grad_(True); br = b.clone().requires_grad_(True)
+    y = torch.nn.functional.layer_norm(xr, (d,), wr, br, 1e-5)
+    y.backward(dy)
+    xd = x.to(DEV)
+    y16 = torch.empty(M, d, dtype=torch.bfloat16, device=DEV); y32 = torch.empty(M, d, device=DEV)
+    mean = torch.empty(M, device=DEV); rstd = torch.empty(M, device=DEV)
+    ops.layernorm_fwd(xd, w.to(DEV), b.to(DEV), y16=y16, y32=y32, mean=mean, rstd=rstd)
+    close(y32, y, 1e-5, 1e-5, "ln fwd f32")
+    close(y16, y, 2 ** -8, 1e-5, "ln fwd bf16")
+    dg = torch.ones(d, device=DEV); db = torch.ones(d, device=DEV)       # accumulate onto ones
+    dx = torch.empty(M, d, device=DEV); dx16 = torch.empty(M, d, dtype=torch.bfloat16, device=DEV)
+    ops.layernorm_bwd(dy.to(DEV), xd, w.to(DEV), mean, rstd, dg, db, g_in=gin.to(DEV), dx=dx, dx16=dx16)
+    close(dx, xr.grad + gin, 1e-4, 1e-4, "ln dx")
+    close(dx16, xr.grad + gin, 2 ** -8, 1e-4, "ln dx16")
+    close(dg, wr.grad + 1, 1e-4, 1e-3, "ln dgamma")
+    close(db, br.grad + 1, 1e-4, 1e-3, "ln dbeta")
+
+
+# ----------------------------------------------------------------------------------------------------
+# attention
+# ----------------------------------------------------------------------------------------------------
+def _masks(B, T, kind):
+    m = torch.ones(B, T)
+    if kind == "left":
+        for b in range(B):
+            m[b, : (7 + 37 * b) % max(1, T - 1)] = 0
+    elif kind == "right":                      # pad_seq=True style right padding (gato_policy.py:423-431)
+        m[0, T - 5:] = 0
+        if B > 1:
+            m[1, :3] = 0; m[1, T - 9:] = 0
+    elif kind == "holes":
+        m[0, 3] = 0; m[0, T // 2] = 0
+    return m
+
+
+@pytest.mark.parametrize("mask_kind", ["none", "left", "right", "holes"])
+@pytest.mark.parametrize("B,T,H,hd", [(2, 40, 2, 32), (3, 200, 4, 32), (2, 333, 2, 64), (1, 130, 2, 128),
+                                      (2, 256, 3, 32)])
+def test_attention_fwd_bwd(ops, B, T, H, hd, mask_kind):
+    g = torch.Generator().manual_seed(B * 1000 + T + hd)
+    d = H * hd
+    qkv = rb(torch.randn(B, T, 3 * d, generator=g))
+    mask = _masks(B, T, mask_kind)
+    do = rb(torch.randn(B, T, d, generator=g))
+    q, k, v = qkv.clone().requires_grad_(True).split(d, dim=2)
+    leaf = qkv.clone().requires_grad_(True)
+    q, k, v = leaf.split(d, dim=2)
+    sh = lambda t: t.view(B, T, H, hd).permute(0, 2, 1, 3)
+    o_ref = O.attention_core(sh(q), sh(k), sh(v), mask).permute(0, 2, 1, 3).reshape(B, T, d)
+    o_ref.backward(do)
+    kb, ks = ops.mask_bias(mask.to(DEV))
+    close(kb, (1 - mask) * -10000.0, 0, 0, "kbias")
+    first = torch.tensor([int((mask[b] != 0).nonzero()[0]) for b in range(B)])
+    assert torch.equal(ks.cpu().long(), first)
+    qkv_d = bf(qkv.view(B * T, 3 * d))
+    out, lse = ops.attn_fwd(qkv_d, kb, ks, B, T, H, hd)
+    scale = float(o_ref.abs().max())
+    # every row, including padded query rows (the reference's finite -1e4 semantics)
+    close(out.view(B, T, d), o_ref, 2 ** -7, 4e-3 * scale, "attn out")
+    dqkv = ops.attn_bwd(qkv_d, out, bf(do.view(B * T, d)), kb, ks, lse, B, T, H, hd)
+    gs = float(leaf.grad.abs().max())
+    close(dqkv.view(B, T, 3 * d), leaf.grad, 2 ** -6, 1e-2 * gs, "attn dqkv")
+
+
+# ----------------------------------------------------------------------------------------------------
+# cross entropy
+# ----------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("R,V", [(17, 1000), (64, 2176), (9, 52305)])
+def test_cross_entropy(ops, R, V):
+    g = torch.Generator().manual_seed(V)
+    Vpad = (V + 127) // 128 * 128
+    logits = torch.randn(R, V, generator=g) * 3
+    target = torch.randint(0, V, (R,), generator=g)
+    sel = (torch.rand(R, generator=g) > 0.3).float()
+    sel[0] = 1.0
+    weight = sel / sel.sum()
+    lr = logits.clone().requires_grad_(True)
+    loss_ref = (torch.nn.functional.cross_entropy(lr, target, reduction="none") * weight).sum()
+    loss_ref.backward()
+    buf = torch.zeros(R, Vpad, device=DEV); buf[:, :V] = logits.to(DEV)
+    loss_row = torch.empty(R, device=DEV)
+    dl = torch.full((R, Vpad), 7.0, dtype=torch.bfloat16, device=DEV)
+    ops.ce_fwd_bwd(buf, V, Vpad, target.to(DEV), weight.to(DEV), loss_row=loss_row, dlogits=dl)
+    row_ref = torch.nn.functional.cross_entropy(logits, target, reduction="none") * sel
+    close(loss_row, row_ref, 1e-5, 1e-5, "ce rows")
+    close(dl[:, :V], lr.grad, 2 ** -8, 1e-7, "dlogits")
+    assert float(dl[:, V:].float().abs().max()) == 0.0 if Vpad > V else True
+
+
+# ----------------------------------------------------------------------------------------------------
+# elementwise / optimiser
+# ----------------------------------------------------------------------------------------------------
+def test_cast_colsum_sqnorm(ops):
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(100003, generator=g)
+    y = torch.empty(100003, dtype=torch.bfloat16, device=DEV)
+    ops.cast_f32_bf16(x.to(DEV), y)
+    assert torch.equal(y.cpu(), x.to(torch.bfloat16))
+    m = rb(torch.randn(1000, 776, generator=g))
+    out = torch.ones(776, device=DEV)
+    ops.colsum_bf16(bf(m), 1000, 776, out, accumulate=True)
+    close(out, m.sum(0) + 1, 1e-4, 1e-3, "colsum")
+    acc = torch.zeros(1, dtype=torch.float64, device=DEV)
+    ops.sqnorm_f32(x.to(DEV), acc)
+    assert abs(float(acc) - float((x.double() ** 2).sum())) < 1e-6 * float((x.double() ** 2).sum())
+
+
+def test_adamw_matches_torch(ops):
+    g = torch.Generator().manual_seed(9)
+    n = 70001
+    p0 = torch.randn(n, generator=g)
+    p_ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([p_ref], lr=3e-3, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.1)
+    p = p0.clone().to(DEV); m = torch.zeros(n, device=DEV); v = torch.zeros(n, device=DEV)
+    p16 = torch.empty(n, dtype=torch.bfloat16, device=DEV)
+    step = torch.zeros(1, dtype=torch.int32, device=DEV)
+    for it in range(5):
+        grad = torch.randn(n, generator=g) * (3.0 if it % 2 == 0 else 0.01)
+        p_ref.grad = grad.clone()
+        norm_ref = torch.nn.utils.clip_grad_norm_([p_ref], 1.0)
+        opt.step()
+        gsq = torch.zeros(1, dtype=torch.float64, device=DEV)
+        gd = grad.to(DEV)
+        ops.sqnorm_f32(gd, gsq)
+        ops.adamw_step(p, gd, m, v, p16, 3e-3, 0.9, 0.95, 1e-8, 0.1, gsq, 1.0, None, step, None)
+        assert abs(math.sqrt(float(gsq)) - float(norm_ref)) < 1e-5 * float(norm_ref)
+        close(p, p_ref.data, 1e-5, 1e-6, f"adamw step {it}")
+    assert int(step) == 5
+    assert torch.equal(p16.cpu(), p.cpu().to(torch.bfloat16))
+    # inactive range is skipped entirely
+    before = p.clone()
+    active = torch.zeros(1, dtype=torch.int32, device=DEV)
+    ops.adamw_step(p, gd, m, v, p16, 3e-3, 0.9, 0.95, 1e-8, 0.1, None, 1.0, None, step, active)
+    assert torch.equal(p, before) and int(step) == 5
+
+
+# ----------------------------------------------------------------------------------------------------
+# continuous tokenizer (bit-exact) -- golden vectors of the reference + a wide random sweep vs the oracle
+# ----------------------------------------------------------------------------------------------------
+def test_tokenizer_golden_and_sweep(ops, golden):
+    f = golden("g1_tokenizer")
+    off = f["offset"]
+    for name in ("edge", "rnd"):
+        x = f[name].to(DEV)
+        assert torch.equal(ops.tokenize_continuous(x, False, 100, 256, 1024, off).cpu(), f[name + "_act"])
+        assert torch.equal(ops.tokenize_continuous(x, True, 100, 256, 1024, off).cpu(), f[name + "_obs"])
+    g = torch.Generator().manual_seed(1)
+    x = torch.cat([torch.randn(200000, generator=g) * 5, torch.rand(200000, generator=g) * 2 - 1,
+                   torch.randn(100000, generator=g) * 300])
+    for mu_law in (False, True):
+        ref = O.tokenize_continuous(x, mu_law, 100, 256, 1024, 50257)
+        got = ops.tokenize_continuous(x.to(DEV), mu_law, 100, 256, 1024, 50257).cpu()
+        assert torch.equal(got, ref), f"mu_law={mu_law}: {int((got != ref).sum())} of {x.numel()} bins differ"
+
+
+# ----------------------------------------------------------------------------------------------------
+# patch embedding residual block
+# ----------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("u8", [False, True])
+def test_patch_resblock_fwd_bwd(ops, u8):
+    cfg = O.OracleConfig(embed_dim=64, layers=1, heads=2, text_tokens=128, context_len=64)
+    sd = O.init_state_dict(cfg, 21)
+    g = torch.Generator().manual_seed(8)
+    imgs = torch.floor(torch.rand(3, 3, 32, 48, generator=g) * 256)
+    pe = "image_embedding.patch_embedding."
+    names = ["conv1.weight", "conv1.bias", "gn2.weight", "gn2.bias", "conv2.weight", "conv2.bias"]
+    leaf = {n: sd[pe + n].clone().requires_grad_(True) for n in names}
+    sd2 = dict(sd); sd2.update({pe + n: leaf[n] for n in names})
+    x = (imgs / 255.0 * 2 - 1) / 4.0
+    n, c, H, W = x.shape
+    xp = x.reshape(n, c, H // 16, 16, W // 16, 16).permute(0, 2, 4, 1, 3, 5).reshape(-1, 3, 16, 16)
+    y_ref = O.residual_block_v2(sd2, xp, 32).reshape(-1, 768)
+    dy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(dy)
+    dev = {n: sd[pe + n].to(DEV).contiguous() for n in names}
+    img_in = imgs.to(torch.uint8).to(DEV) if u8 else imgs.to(DEV)
+    y16, xpd = ops.patch_resblock_fwd(img_in, *[dev[n] for n in names], 128, 32)
+    close(xpd, xp.reshape(-1, 768), 1e-6, 1e-6, "normalised patches")
+    close(y16, y_ref, 2 ** -8, 2e-4, "resblock fwd")
+    grads = {n: torch.zeros_like(dev[n]) for n in names}
+    ops.patch_resblock_bwd(xpd, dy.to(DEV), *[dev[n] for n in names], 128, 32, *[grads[n] for n in names])
+    for nme in names:
+        ref = leaf[nme].grad
+        close(grads[nme], ref, 2e-3, 2e-4 * float(ref.abs().max()) + 1e-5, f"resblock d{nme}")
+
+
+def test_patch_pos_add(ops):
+    g = torch.Generator().manual_seed(2)
+    P, d = 37, 64
+    out = torch.randn(P, d, generator=g); row = torch.randn(128, d, generator=g); col = torch.randn(128, d, generator=g)
+    hp = torch.randint(0, 128, (P,), generator=g, dtype=torch.int32); wp = torch.randint(0, 128, (P,), generator=g, dtype=torch.int32)
+    o = out.clone().to(DEV)
+    ops.patch_pos_add(o, hp.to(DEV), wp.to(DEV), row.to(DEV), col.to(DEV))
+    close(o, out + (row[hp.long()] + col[wp.long()]), 1e-6, 1e-6, "pos add")
+    dr = torch.zeros(128, d, device=DEV); dc = torch.zeros(128, d, device=DEV)
+    ops.patch_pos_add_bwd(out.to(DEV), hp.to(DEV), wp.to(DEV), dr, dc)
+    ref_r = torch.zeros(128, d).index_add_(0, hp.long(), out); ref_c = torch.zeros(128, d).index_add_(0, wp.long(), out)
+    close(dr, ref_r, 1e-5, 1e-5, "pos bwd row"); close(dc, ref_c, 1e-5, 1e-5, "pos bwd col")
