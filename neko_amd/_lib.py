@@ -51,6 +51,9 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own libamdhip64: import it FIRST so libneko_hip.so binds to the same HIP runtime
+    # (loading ours first drags in /opt/rocm's copy -> two runtimes in one process, ours sees no device).
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise NekoHipError(
             f"{LIB_PATH} not found: the HIP extension is not built (run `python -m neko_amd.build`). "

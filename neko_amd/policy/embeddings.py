@@ -67,7 +67,7 @@ class _ImageEmbedFn(torch.autograd.Function):
     def forward(ctx, mod: "ImageEmbedding", images, hpos, wpos, *params):
         f = mod._flat
         pre = mod._prefix
-        need = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        need = any(ctx.needs_input_grad)
         f.ensure_shadow()
         pe = pre + "patch_embedding."
         w = lambda n: f.view(n)

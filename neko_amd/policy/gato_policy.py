@@ -167,7 +167,7 @@ class _PolicyCoreFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, policy: "GatoPolicy", x, pmask, tokens, tmask, compute_loss: bool, return_logits: bool, *params):
-        need = torch.is_grad_enabled() and compute_loss and (x.requires_grad or any(p.requires_grad for p in params))
+        need = bool(compute_loss) and any(ctx.needs_input_grad)   # grad mode is off inside Function.forward
         f = policy._flat
         f.ensure_shadow()
         B, T, d = x.shape

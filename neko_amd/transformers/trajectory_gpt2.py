@@ -108,7 +108,7 @@ class _TransformerFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, model: "GPT2Model", x: torch.Tensor, mask: torch.Tensor, *params):
-        need = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
+        need = any(ctx.needs_input_grad)   # grad mode is off inside Function.forward
         model._flat.ensure_shadow()
         _, hf32, sctx = engine.stack_forward(model._stack_params(), x.detach().to(torch.float32), mask, save=need,
                                              want_f32=True, want_bf16=False)
