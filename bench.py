@@ -29,9 +29,11 @@ MFMA_PEAK_TFLOPS = 2500.0      # dense bf16, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
 
 
-def flops_per_token_fwd(d=D, layers=L, t=T, v=V):
-    """linear layers 24 d^2, causal attention at its useful half 2 d (T+1), LM head 2 d V."""
-    return layers * (24 * d * d + 2 * d * (t + 1)) + 2 * d * v
+def flops_per_token_fwd(d=D, layers=L, t=T, v=V, lm_rows_frac=1.0):
+    """linear layers 24 d^2, causal attention at its useful half 2 d (T+1), LM head 2 d V --
+    the LM head counted only for the fraction of positions it is actually evaluated at (the build runs it on
+    the loss positions only; FLOPs that are not executed are not claimed)."""
+    return layers * (24 * d * d + 2 * d * (t + 1)) + 2 * d * v * lm_rows_frac
 
 
 def make_batch(workload: str, B: int, seed: int, device):
@@ -163,7 +165,8 @@ def main():
     if rank == 0:
         tokens = world * B * Tlen * args.steps
         value = tokens / el
-        fpt = 3 * flops_per_token_fwd(t=Tlen)
+        lm_frac = (model._loss_rows[3] / float(B * Tlen)) if (model._loss_rows and model.lm_head_selected_rows) else 1.0
+        fpt = 3 * flops_per_token_fwd(t=Tlen, lm_rows_frac=lm_frac)
         dom = time_dominant_kernel(model, min(4096, B * Tlen))
         out = {
             "metric": "multimodal tokens/sec (fwd+bwd+optimizer, whole job)", "value": value, "unit": "tokens/s",
@@ -178,6 +181,7 @@ def main():
             "final_loss": float(loss),
             "step_mfma_frac": value / world * fpt / (MFMA_PEAK_TFLOPS * 1e12),
             "flops_per_token_fwd_bwd": fpt,
+            "lm_head_rows_fraction": lm_frac,
             "roofline": {"bound": "mfma", "achieved": dom["tflops"], "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": dom["tflops"] / MFMA_PEAK_TFLOPS, "traffic": None, "kernel": dom["kernel"],
                          "shape_MNK": dom["shape"], "ms_per_launch": dom["ms"]},

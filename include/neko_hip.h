@@ -33,7 +33,7 @@ extern "C" {
 #define NEKO_ERR_UNSUPPORTED (-2)
 #define NEKO_ERR_LAUNCH (-3)
 
-#define NEKO_ABI_VERSION 1
+#define NEKO_ABI_VERSION 2
 
 int neko_abi_version(void);
 /* human-readable text for a return code (static storage) */
@@ -53,8 +53,9 @@ const char* neko_status_string(int code);
  *   act = 0 none | 1 GELU (pre-activation rounded to bf16 first; optionally stored to pre_out)
  *         | 2 multiply by GELU'(act_in[m,n])  (dgrad through the MLP activation)
  *   outputs: Cf (f32) and/or Cb (bf16); accumulate != 0: Cf += result.
- *   splitk > 1: K is cut in `splitk` slices of k_per_split (multiple of 64) reduced with f32
- *   atomics into Cf (caller zeroes Cf or wants accumulation; act must be 0, Cb null).
+ *   splitk > 1: K is cut in `splitk` slices of k_per_split (multiple of 64).  With splitk_ws (f32
+ *   [splitk*M*N], N % 4 == 0) the slices are written to the workspace and summed in a fixed order into Cf
+ *   (bit-reproducible); with splitk_ws == NULL they meet in f32 atomics on Cf.  act must be 0, Cb null.
  *   Contract: contiguous extents and leading dims are multiples of 8 elements.
  *   safe_transpose != 0 selects the transposing-store fallback for k-strided operands (debug).
  * ------------------------------------------------------------------------------------------- */
@@ -62,8 +63,8 @@ int neko_gemm_bf16(const uint16_t* A, long lda, int a_kstrided, const uint16_t* 
                    int M, int N, int K, float alpha, const float* alpha_dev, const float* bias, const float* resid,
                    long ldr, int act,
                    const uint16_t* act_in, long ldact, uint16_t* pre_out, long ldpre, float* Cf, long ldcf,
-                   int accumulate, uint16_t* Cb, long ldcb, int splitk, int k_per_split, int safe_transpose,
-                   void* stream);
+                   int accumulate, uint16_t* Cb, long ldcb, int splitk, int k_per_split, float* splitk_ws,
+                   int safe_transpose, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * LayerNorm -- nn.LayerNorm(d, eps) ln_1 / ln_2 / ln_f (trajectory_gpt2.py:301,303,323,353,543,779).
@@ -139,6 +140,10 @@ int neko_tokenize_continuous(const float* x, int* ids, long n, int use_mu_law, f
  *                        torch skips parameters whose grad is None; p16 (may be null) gets bf16(p).
  * ------------------------------------------------------------------------------------------- */
 int neko_cast_f32_bf16(const float* x, uint16_t* y, long n, void* stream);
+/* loss-position selection (gato_policy.py:183-185): dst[r,:] = r < n ? src[idx[r],:] : 0 (bf16 rows, d % 8 == 0);
+ * and its adjoint dst[idx[r],:] = src[r,:] (f32 rows, dst pre-zeroed, idx unique). */
+int neko_gather_rows_bf16(const uint16_t* src, const int* idx, uint16_t* dst, int n, int npad, int d, void* stream);
+int neko_scatter_rows_f32(const float* src, const int* idx, float* dst, int n, int d, void* stream);
 int neko_colsum_bf16(const uint16_t* x, long ld, int M, int N, float* out, int accumulate, void* stream);
 int neko_sqnorm_f32(const float* g, long n, double* out_accum, void* stream);
 int neko_adamw_step(float* p, const float* g, float* m, float* v, uint16_t* p16, long n, float lr, float beta1,

@@ -27,24 +27,45 @@ __global__ void cast_f32_bf16_kernel(const float* __restrict__ x, bf16_t* __rest
 // ---- out[N] (+)= column sums of a bf16 [M, ld] matrix (bias gradients) -------------------------------
 // block = 256 threads = 4 waves; a wave covers 512 columns (8 per lane, 16-B loads); blockIdx.x = column
 // group, blockIdx.y = row slice; partial sums meet in fp32 atomics (out zeroed by the host when !accumulate).
+// block = 256 threads = 32 column-chunks (8 bf16 = 16 B each -> 256 columns) x 8 row lanes; rows are walked 4 at a
+// time (4 independent 16-B loads in flight per thread), the 8 row lanes meet in LDS, one atomic per column per block.
 __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restrict__ x, long ld, int M, int N,
                                                           float* __restrict__ out) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int c0 = (blockIdx.x * 64 + lane) * 8;
-  if (c0 >= N) return;
+  __shared__ float red[8][256 + 8];
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int c0 = (blockIdx.x * 32 + cl) * 8;
+  const bool ok = c0 < N;
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (int r = blockIdx.y * 4 + wave; r < M; r += gridDim.y * 4) {
-    const uint4 v = *reinterpret_cast<const uint4*>(x + (long)r * ld + c0);
+  const int step = gridDim.y * 8;
+  auto add = [&](const uint4& v) {
     const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       acc[2 * e] += bf16_to_f32((bf16_t)(w[e] & 0xffff));
       acc[2 * e + 1] += bf16_to_f32((bf16_t)(w[e] >> 16));
     }
+  };
+  if (ok) {
+    int r = blockIdx.y * 8 + rl;
+    for (; r + 3 * step < M; r += 4 * step) {
+      const uint4 v0 = *reinterpret_cast<const uint4*>(x + (long)r * ld + c0);
+      const uint4 v1 = *reinterpret_cast<const uint4*>(x + (long)(r + step) * ld + c0);
+      const uint4 v2 = *reinterpret_cast<const uint4*>(x + (long)(r + 2 * step) * ld + c0);
+      const uint4 v3 = *reinterpret_cast<const uint4*>(x + (long)(r + 3 * step) * ld + c0);
+      add(v0); add(v1); add(v2); add(v3);
+    }
+    for (; r < M; r += step) add(*reinterpret_cast<const uint4*>(x + (long)r * ld + c0));
   }
 #pragma unroll
-  for (int e = 0; e < 8; ++e)
-    if (c0 + e < N) atomicAdd(out + c0 + e, acc[e]);
+  for (int e = 0; e < 8; ++e) red[rl][cl * 8 + e] = acc[e];
+  __syncthreads();
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c < N) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += red[i][threadIdx.x];
+    atomicAdd(out + c, s);
+  }
 }
 
 // ---- additive key bias (1-mask)*-1e4 and the number of leading masked keys per sequence ---------------
@@ -185,9 +206,10 @@ int neko_colsum_bf16_impl(const bf16_t* x, long ld, int M, int N, float* out, in
   if (!accumulate) {
     if (hipMemsetAsync(out, 0, sizeof(float) * (size_t)N, s) != hipSuccess) return NEKO_ERR_LAUNCH;
   }
-  const int gx = (N + 511) / 512;
-  int gy = (M + 63) / 64;
-  if (gy > 256) gy = 256;
+  const int gx = (N + 255) / 256;
+  int gy = (M + 255) / 256;           // >= 32 rows per thread at full size
+  const int cap = 768 / gx > 0 ? 768 / gx : 1;   // ~3 blocks per CU in total
+  if (gy > cap) gy = cap;
   if (gy < 1) gy = 1;
   hipLaunchKernelGGL(colsum_bf16_kernel, dim3(gx, gy), dim3(256), 0, s, x, ld, M, N, out);
   NEKO_CHECK_LAUNCH();

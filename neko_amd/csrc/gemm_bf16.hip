@@ -195,7 +195,11 @@ __global__ __launch_bounds__(NT) void gemm_bf16_kernel(GemmArgs p) {
 
   // ---- epilogue ------------------------------------------------------------------------------
   const float alpha = p.alpha_dev ? p.alpha * (*p.alpha_dev) : p.alpha;
-  const bool atomic = p.splitk > 1;
+  const bool to_ws = p.splitk > 1 && p.splitk_ws;   // split-K slices go to a workspace, reduced in fixed order afterwards
+  const bool atomic = p.splitk > 1 && !to_ws;
+  float* const Cf_out = to_ws ? p.splitk_ws + (long)blockIdx.y * p.M * p.N : p.Cf;
+  const long ldcf_out = to_ws ? p.N : p.ldcf;
+  const int acc_out = to_ws ? 0 : p.accumulate;
   const bool lead = !atomic || blockIdx.y == 0;   // bias/resid added once under split-K
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -217,10 +221,10 @@ __global__ __launch_bounds__(NT) void gemm_bf16_kernel(GemmArgs p) {
           v *= gelu_grad_f(bf16_to_f32(p.act_in[(long)row * p.ldact + col]));
         }
         if (p.resid && lead) v += p.resid[(long)row * p.ldr + col];
-        if (p.Cf) {
-          float* dst = p.Cf + (long)row * p.ldcf + col;
+        if (Cf_out) {
+          float* dst = Cf_out + (long)row * ldcf_out + col;
           if (atomic) atomicAdd(dst, v);
-          else if (p.accumulate) *dst += v;
+          else if (acc_out) *dst += v;
           else *dst = v;
         }
         if (p.Cb) p.Cb[(long)row * p.ldcb + col] = f32_to_bf16(v);
@@ -254,6 +258,12 @@ int neko_gemm_bf16_impl(GemmArgs a, int a_kstrided, int b_kstrided, int safe_tra
     if (!a.Cf || a.Cb || a.act != 0) return NEKO_ERR_ARG;  // atomics need a linear f32 epilogue
     if (a.k_per_split <= 0 || (a.k_per_split % BK)) return NEKO_ERR_ARG;
   }
+  // safe_transpose: 0 = fastest available, 1 = transposing-store fallback, 2 = register-staged kernel only
+  if (safe_transpose == 0) {
+    const int rc = neko_gemm_glds_try(a, a_kstrided, b_kstrided, s);   // direct-to-LDS fast path (gemm_glds.hip)
+    if (rc != 1) return rc;
+  }
+  safe_transpose = (safe_transpose == 1);
   if (a_kstrided && b_kstrided)
     return safe_transpose ? launch<false, false, true>(a, s) : launch<false, false, false>(a, s);
   if (a_kstrided)
@@ -261,4 +271,12 @@ int neko_gemm_bf16_impl(GemmArgs a, int a_kstrided, int b_kstrided, int safe_tra
   if (b_kstrided)
     return safe_transpose ? launch<true, false, true>(a, s) : launch<true, false, false>(a, s);
   return launch<true, true, false>(a, s);
+}
+
+int neko_gemm_bf16_full(GemmArgs a, int a_kstrided, int b_kstrided, int safe_transpose, hipStream_t s) {
+  if (a.splitk > 1 && a.splitk_ws && (a.N & 3)) a.splitk_ws = nullptr;   // reduce kernel wants N % 4 == 0
+  if (a.splitk <= 1) a.splitk_ws = nullptr;
+  const int rc = neko_gemm_bf16_impl(a, a_kstrided, b_kstrided, safe_transpose, s);
+  if (rc != NEKO_OK || !a.splitk_ws || a.M <= 0 || a.N <= 0 || a.K <= 0) return rc;
+  return neko_splitk_reduce_impl(a.splitk_ws, a.splitk, a.M, a.N, a.Cf, a.ldcf, a.accumulate, s);
 }

@@ -163,14 +163,32 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
 }
 
 // dgamma[d] (+)= sum_b part[b][0][:], dbeta likewise.  One thread per column, coalesced over b rows.
-__global__ void ln_param_reduce_kernel(const float* __restrict__ part, int nblk, int d, float* __restrict__ dgamma,
-                                       float* __restrict__ dbeta, int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= 2 * d) return;
-  float s = 0.f;
-  for (int b = 0; b < nblk; ++b) s += part[(long)b * 2 * d + c];
-  float* dst = (c < d) ? (dgamma + c) : (dbeta + (c - d));
-  *dst = accumulate ? (*dst + s) : s;
+// block = 64 columns x 4 row slices (256 threads); 4 independent loads in flight per thread.
+__global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float* __restrict__ part, int nblk, int d,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                              int accumulate) {
+  __shared__ float red[4][64];
+  const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < 2 * d) {
+    const long ld = 2L * d;
+    int b = sl;
+    for (; b + 12 < nblk; b += 16) {
+      s0 += part[(long)b * ld + c];
+      s1 += part[(long)(b + 4) * ld + c];
+      s2 += part[(long)(b + 8) * ld + c];
+      s3 += part[(long)(b + 12) * ld + c];
+    }
+    for (; b < nblk; b += 4) s0 += part[(long)b * ld + c];
+  }
+  red[sl][cl] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (sl == 0 && c < 2 * d) {
+    const float s = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+    float* dst = (c < d) ? (dgamma + c) : (dbeta + (c - d));
+    *dst = accumulate ? (*dst + s) : s;
+  }
 }
 
 template <int NV>
@@ -208,7 +226,7 @@ int neko_layernorm_fwd_impl(const float* x, const float* gamma, const float* bet
 // number of partial rows the backward writes for a given M (workspace = nblk*2*d floats)
 int neko_layernorm_bwd_blocks_impl(int M) {
   int nb = (M + 3) / 4;
-  return nb < 1024 ? (nb < 1 ? 1 : nb) : 1024;
+  return nb < 512 ? (nb < 1 ? 1 : nb) : 512;
 }
 
 int neko_layernorm_bwd_impl(const float* dy, const float* x, const float* gamma, const float* mean,
@@ -227,7 +245,7 @@ int neko_layernorm_bwd_impl(const float* dy, const float* x, const float* gamma,
   else if (nv <= 8) rc = bwd_launch<8>(dy, x, gamma, mean, rstd, g_in, dx, dx16, workspace, nblk, M, d, s);
   else rc = bwd_launch<16>(dy, x, gamma, mean, rstd, g_in, dx, dx16, workspace, nblk, M, d, s);
   if (rc != NEKO_OK) return rc;
-  hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * d + 255) / 256), dim3(256), 0, s, workspace, nblk, d, dgamma,
+  hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * d + 63) / 64), dim3(256), 0, s, workspace, nblk, d, dgamma,
                      dbeta, accumulate);
   NEKO_CHECK_LAUNCH();
   return NEKO_OK;

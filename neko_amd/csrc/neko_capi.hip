@@ -20,11 +20,11 @@ const char* neko_status_string(int code) {
 int neko_gemm_bf16(const uint16_t* A, long lda, int a_kstrided, const uint16_t* B, long ldb, int b_kstrided, int M,
                    int N, int K, float alpha, const float* alpha_dev, const float* bias, const float* resid, long ldr, int act,
                    const uint16_t* act_in, long ldact, uint16_t* pre_out, long ldpre, float* Cf, long ldcf,
-                   int accumulate, uint16_t* Cb, long ldcb, int splitk, int k_per_split, int safe_transpose,
-                   void* stream) {
+                   int accumulate, uint16_t* Cb, long ldcb, int splitk, int k_per_split, float* splitk_ws,
+                   int safe_transpose, void* stream) {
   GemmArgs a{A, B, lda, ldb, M, N, K, alpha, alpha_dev, bias, resid, ldr, act_in, ldact, pre_out, ldpre, act,
-             Cf, ldcf, accumulate, Cb, ldcb, splitk, k_per_split};
-  return neko_gemm_bf16_impl(a, a_kstrided, b_kstrided, safe_transpose, S(stream));
+             Cf, ldcf, accumulate, Cb, ldcb, splitk, k_per_split, splitk_ws};
+  return neko_gemm_bf16_full(a, a_kstrided, b_kstrided, safe_transpose, S(stream));
 }
 
 int neko_layernorm_fwd(const float* x, const float* gamma, const float* beta, uint16_t* y16, float* y32, float* mean,
@@ -73,6 +73,12 @@ int neko_tokenize_continuous(const float* x, int* ids, long n, int use_mu_law, f
   return neko_tokenize_continuous_impl(x, ids, n, use_mu_law, mu, M, n_bins, offset, S(stream));
 }
 
+int neko_gather_rows_bf16(const uint16_t* src, const int* idx, uint16_t* dst, int n, int npad, int d, void* stream) {
+  return neko_gather_rows_bf16_impl(src, idx, dst, n, npad, d, S(stream));
+}
+int neko_scatter_rows_f32(const float* src, const int* idx, float* dst, int n, int d, void* stream) {
+  return neko_scatter_rows_f32_impl(src, idx, dst, n, d, S(stream));
+}
 int neko_cast_f32_bf16(const float* x, uint16_t* y, long n, void* stream) {
   return neko_cast_f32_bf16_impl(x, y, n, S(stream));
 }

@@ -50,13 +50,30 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // exact (erf) GELU and its derivative -- ACT2FN['gelu'] == F.gelu (trajectory_gpt2.py:266)
+// erf is evaluated branch-free with Abramowitz-Stegun 7.1.26 (|abs err| < 1.5e-7, i.e. fp32 rounding level):
+// libm's erff expands to a divergent multi-branch polynomial that made the GELU epilogues VALU-bound.
+//   erf(z) = sign(z) * (1 - (a1 t + ... + a5 t^5) * exp(-z^2)),  t = 1/(1 + p|z|)
+// gelu and gelu' share one exponential: exp(-(x/sqrt2)^2) == exp(-x^2/2).
+__device__ __forceinline__ void erf_exp_parts(float x, float& erf_z, float& e) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
+  e = __expf(-z * z);
+  float poly = fmaf(t, 1.061405429f, -1.453152027f);
+  poly = fmaf(poly, t, 1.421413741f);
+  poly = fmaf(poly, t, -0.284496736f);
+  poly = fmaf(poly, t, 0.254829592f);
+  poly *= t;
+  erf_z = copysignf(fmaf(-poly, e, 1.0f), x);
+}
 __device__ __forceinline__ float gelu_f(float x) {
-  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+  float er, e;
+  erf_exp_parts(x, er, e);
+  return 0.5f * x * (1.0f + er);
 }
 __device__ __forceinline__ float gelu_grad_f(float x) {
-  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
-  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
-  return cdf + x * pdf;
+  float er, e;
+  erf_exp_parts(x, er, e);
+  return fmaf(x * 0.39894228040143267794f, e, 0.5f * (1.0f + er));
 }
 
 // XCD-aware bijective block remap (8 XCDs, block b runs on XCD b%8): give every XCD a

@@ -24,9 +24,15 @@ struct GemmArgs {
   long ldcb;
   int splitk;             // >1: each grid.y slice handles k_per_split of K, atomicAdd into Cf
   int k_per_split;        // multiple of 64
+  float* splitk_ws;       // optional [splitk, M, N] f32 workspace: slices reduced in fixed order (no atomics)
 };
 
 int neko_gemm_bf16_impl(GemmArgs a, int a_kstrided, int b_kstrided, int safe_transpose, hipStream_t s);
+int neko_gemm_bf16_full(GemmArgs a, int a_kstrided, int b_kstrided, int safe_transpose, hipStream_t s);
+int neko_gather_rows_bf16_impl(const bf16_t* src, const int* idx, bf16_t* dst, int n, int npad, int d, hipStream_t s);
+int neko_scatter_rows_f32_impl(const float* src, const int* idx, float* dst, int n, int d, hipStream_t s);
+int neko_splitk_reduce_impl(const float* ws, int S, int M, int N, float* C, long ldc, int accumulate, hipStream_t s);
+int neko_gemm_glds_try(const GemmArgs& a, int a_kstrided, int b_kstrided, hipStream_t s);   // 1 = not applicable
 int neko_layernorm_fwd_impl(const float* x, const float* gamma, const float* beta, bf16_t* y16, float* y32,
                             float* mean, float* rstd, int M, int d, float eps, hipStream_t s);
 int neko_layernorm_bwd_blocks_impl(int M);

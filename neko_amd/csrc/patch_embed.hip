@@ -4,14 +4,16 @@
 // x + conv3x3(3<-C)(GELU(GroupNorm(conv3x3(C<-3)(GELU(x)))))), PatchPosEncoding's lookup/add (:101-110)
 // and their autograd.  The 768->d projection (:53) runs on the bf16 GEMM.
 //
-// One 256-thread block = one 16x16 patch, one thread = one pixel.  The C=128 mid channels of the
-// pixel live in registers (fully unrolled), conv weights are wave-uniform (scalar loads), GroupNorm
-// statistics are two-pass block reductions, and the second conv walks the channels through a haloed
-// LDS tile 32 at a time.  Nothing but the normalised patch (768 floats) is kept for backward: the
-// backward kernel recomputes the block and produces all six parameter gradients in one pass
-// (weight gradients by "one output per thread" sweeps over LDS tiles, accumulated in registers over
-// the patches a block walks, then f32 atomics).  <2 % of the model FLOPs: plain
-// fp32 VALU, no MFMA reshaping.
+// One 256-thread block = one 16x16 patch, one thread = one pixel.  The C=128 mid channels are processed in
+// 4 chunks of 32 (GroupNorm groups of 4 channels are chunk-local): conv1 writes the chunk's raw activations
+// into a haloed LDS tile, the group statistics are two-pass block reductions, GELU(GN(.)) is applied in
+// place and the second conv accumulates its 3 outputs over the chunk.  Conv/GN parameters are staged in LDS
+// once per block and read as wave-uniform broadcasts; every inner loop is dynamic with a small body (an
+// earlier fully-unrolled register-resident version spilled thousands of SGPRs/VGPRs).  Nothing but the
+// normalised patch (768 floats) is kept for backward: the backward kernel recomputes the block chunk by
+// chunk and produces all six parameter gradients in one pass (weight gradients by "one output per thread"
+// sweeps over LDS tiles, accumulated in registers over the patches a block walks, then f32 atomics).
+// <2 % of the model FLOPs: fp32 VALU, no MFMA reshaping.
 #include "neko_kernels.h"
 
 namespace {
@@ -25,78 +27,30 @@ constexpr int CHUNK = 32;     // channels per LDS chunk
 constexpr float GN_EPS = 1e-5f;
 
 struct Smem {
-  float gx[3][HALO][HALO];        // GELU(x) with zero halo              (3.9 KB)
+  float gx[3][HALO][HALO];        // GELU(x) with zero halo
   float dh3[3][HALO][HALO];       // d(conv2 out) with zero halo (bwd)
-  float tile[CHUNK][HALO][HALO];  // haloed channel chunk / scratch        (41.5 KB)
-  float red[4][2 * G];            // cross-wave reductions
-  float stat[2 * G];              // mean / rstd per group
-  float chan[2 * C];              // per-patch per-channel sums (bwd): [0,C) sum(du*xhat), [C,2C) sum(du)
-  float acc_gn[2 * C];            // block accumulators for dgamma / dbeta
+  float tile[CHUNK][HALO][HALO];  // haloed channel chunk: raw h1, then h2 = GELU(GN(h1))
+  float xh[CHUNK][PS * PS];       // bwd: xhat of the chunk
+  float du[CHUNK][PS * PS];       // bwd: d(GN out), then d(h1)
+  float red[4][2 * CHUNK];        // cross-wave partials
+  float mean[CHUNK / CPG], rstd[CHUNK / CPG];
+  float chan[2 * CHUNK];          // bwd per-patch per-channel sums: [cc] sum(du*xhat), [CHUNK+cc] sum(du)
+  float acc_gn[2 * C];            // bwd block accumulators for dgamma / dbeta
   float acc_b2[4];
+  // conv / GroupNorm parameters staged once per block (wave-uniform LDS broadcast reads)
+  float w1[C * 27];
+  float w2[3 * C * 9];
+  float b1[C];
+  float gw[C];
+  float gb[C];
 };
+// forward does not need xh/du: it is launched with a smaller dynamic LDS window (offsetof(Smem, xh) + tail)
 
-// reduce NV per-thread values over the 256 threads; result broadcast through s.red -> out[NV] (LDS)
-template <int NV>
-__device__ __forceinline__ void block_reduce(const float (&v)[NV], float* out, Smem& s, int tid) {
-  const int lane = tid & 63, wave = tid >> 6;
-#pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const float r = wave_sum(v[i]);
-    if (lane == 0) s.red[wave][i] = r;
-  }
-  __syncthreads();
-  if (tid < NV) out[tid] = (s.red[0][tid] + s.red[1][tid]) + (s.red[2][tid] + s.red[3][tid]);
-  __syncthreads();
-}
-
-// conv1 + GroupNorm statistics for this thread's pixel.  xh[c] returns the normalised value
-// xhat = (h1 - mean_g) * rstd_g ; s.stat holds mean/rstd.
-__device__ __forceinline__ void conv1_groupnorm(const Smem& cs, Smem& s, const float* __restrict__ w1,
-                                                const float* __restrict__ b1, int py, int px, int tid,
-                                                float (&xh)[C]) {
-  float nb[27];
-#pragma unroll
-  for (int i = 0; i < 3; ++i)
-#pragma unroll
-    for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-      for (int dx = 0; dx < 3; ++dx) nb[i * 9 + dy * 3 + dx] = cs.gx[i][py + dy][px + dx];
-#pragma unroll
-  for (int c = 0; c < C; ++c) {
-    float a = b1[c];
-#pragma unroll
-    for (int k = 0; k < 27; ++k) a = fmaf(w1[c * 27 + k], nb[k], a);
-    xh[c] = a;
-  }
-  float part[G];
-#pragma unroll
-  for (int g = 0; g < G; ++g) {
-    float t = 0.f;
-#pragma unroll
-    for (int j = 0; j < CPG; ++j) t += xh[g * CPG + j];
-    part[g] = t;
-  }
-  block_reduce<G>(part, s.stat, s, tid);
-  const float inv_n = 1.0f / (float)(CPG * PS * PS);
-#pragma unroll
-  for (int g = 0; g < G; ++g) {
-    const float mean = s.stat[g] * inv_n;
-    float t = 0.f;
-#pragma unroll
-    for (int j = 0; j < CPG; ++j) {
-      xh[g * CPG + j] -= mean;
-      t += xh[g * CPG + j] * xh[g * CPG + j];
-    }
-    part[g] = t;
-  }
-  __syncthreads();
-  block_reduce<G>(part, s.stat + G, s, tid);
-#pragma unroll
-  for (int g = 0; g < G; ++g) {
-    const float rstd = rsqrtf(s.stat[G + g] * inv_n + GN_EPS);
-#pragma unroll
-    for (int j = 0; j < CPG; ++j) xh[g * CPG + j] *= rstd;
-  }
+__device__ __forceinline__ void stage_params(Smem& s, const float* __restrict__ w1, const float* __restrict__ b1,
+                                             const float* __restrict__ gw, const float* __restrict__ gb,
+                                             const float* __restrict__ w2, int tid) {
+  for (int i = tid; i < C * 27; i += 256) { s.w1[i] = w1[i]; s.w2[i] = w2[i]; }
+  if (tid < C) { s.b1[tid] = b1[tid]; s.gw[tid] = gw[tid]; s.gb[tid] = gb[tid]; }
 }
 
 __device__ __forceinline__ void zero_halos(Smem& s, int tid) {
@@ -104,6 +58,50 @@ __device__ __forceinline__ void zero_halos(Smem& s, int tid) {
   for (int i = tid; i < 3 * HALO * HALO; i += 256) { z[i] = 0.f; (&s.dh3[0][0][0])[i] = 0.f; }
   float* t = &s.tile[0][0][0];
   for (int i = tid; i < CHUNK * HALO * HALO; i += 256) t[i] = 0.f;
+}
+
+// conv1 of channel chunk k for this thread's pixel -> raw h1 into the haloed tile, then the GroupNorm
+// statistics of the chunk's 8 groups (two-pass: mean, centred variance) into s.mean / s.rstd.
+// nb = the 27 GELU(x) neighbours of the pixel.  All loops are dynamic on purpose (small live ranges).
+__device__ __forceinline__ void conv1_stats_chunk(Smem& s, int k, const float (&nb)[27], int py, int px, int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+  constexpr int NG = CHUNK / CPG;
+#pragma unroll 1
+  for (int g = 0; g < NG; ++g) {
+    float gs = 0.f;
+#pragma unroll
+    for (int j = 0; j < CPG; ++j) {
+      const int cc = g * CPG + j, c = k * CHUNK + cc;
+      const float* w = &s.w1[c * 27];
+      float a = s.b1[c];
+#pragma unroll
+      for (int t = 0; t < 27; ++t) a = fmaf(w[t], nb[t], a);
+      s.tile[cc][py + 1][px + 1] = a;
+      gs += a;
+    }
+    gs = wave_sum(gs);
+    if (lane == 0) s.red[wave][g] = gs;
+  }
+  __syncthreads();
+  const float inv_n = 1.0f / (float)(CPG * PS * PS);
+  if (tid < NG) s.mean[tid] = ((s.red[0][tid] + s.red[1][tid]) + (s.red[2][tid] + s.red[3][tid])) * inv_n;
+  __syncthreads();
+#pragma unroll 1
+  for (int g = 0; g < NG; ++g) {
+    const float m = s.mean[g];
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < CPG; ++j) {
+      const float d = s.tile[g * CPG + j][py + 1][px + 1] - m;
+      q = fmaf(d, d, q);
+    }
+    q = wave_sum(q);
+    if (lane == 0) s.red[wave][CHUNK + g] = q;
+  }
+  __syncthreads();
+  if (tid < NG)
+    s.rstd[tid] = rsqrtf(((s.red[0][CHUNK + tid] + s.red[1][CHUNK + tid]) + (s.red[2][CHUNK + tid] + s.red[3][CHUNK + tid])) * inv_n + GN_EPS);
+  __syncthreads();
 }
 
 template <bool U8>
@@ -116,6 +114,7 @@ __global__ __launch_bounds__(256) void resblock_fwd_kernel(const void* __restric
   const int tid = threadIdx.x, py = tid >> 4, px = tid & 15;
   const int nh = H / PS, nw = W / PS, P = n * nh * nw;
   zero_halos(s, tid);
+  stage_params(s, w1, b1, gw, gb, w2, tid);
   for (int p = blockIdx.x; p < P; p += gridDim.x) {
     const int b = p / (nh * nw), ph = (p / nw) % nh, pw = p % nw;
     float xv[3];
@@ -132,32 +131,49 @@ __global__ __launch_bounds__(256) void resblock_fwd_kernel(const void* __restric
 #pragma unroll
     for (int i = 0; i < 3; ++i) s.gx[i][py + 1][px + 1] = gelu_f(xv[i]);
     __syncthreads();
-    float h[C];
-    conv1_groupnorm(s, s, w1, b1, py, px, tid, h);
+    float nb[27];
 #pragma unroll
-    for (int c = 0; c < C; ++c) h[c] = gelu_f(fmaf(h[c], gw[c], gb[c]));
-    float o[3] = {b2[0], b2[1], b2[2]};
+    for (int i = 0; i < 3; ++i)
 #pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) nb[i * 9 + dy * 3 + dx] = s.gx[i][py + dy][px + dx];
+    float o0 = b2[0], o1 = b2[1], o2 = b2[2];
+#pragma unroll 1
     for (int k = 0; k < C / CHUNK; ++k) {
-      __syncthreads();
+      conv1_stats_chunk(s, k, nb, py, px, tid);
+      // h2 = GELU(GN(h1)) in place (own pixel)
+#pragma unroll 1
+      for (int g = 0; g < CHUNK / CPG; ++g) {
+        const float m = s.mean[g], rs = s.rstd[g];
 #pragma unroll
-      for (int cc = 0; cc < CHUNK; ++cc) s.tile[cc][py + 1][px + 1] = h[k * CHUNK + cc];
+        for (int j = 0; j < CPG; ++j) {
+          const int cc = g * CPG + j, c = k * CHUNK + cc;
+          const float v = (s.tile[cc][py + 1][px + 1] - m) * rs;
+          s.tile[cc][py + 1][px + 1] = gelu_f(fmaf(v, s.gw[c], s.gb[c]));
+        }
+      }
       __syncthreads();
-#pragma unroll 4
+      // conv2 partial over the chunk's channels
+#pragma unroll 2
       for (int cc = 0; cc < CHUNK; ++cc) {
-        float nb[9];
+        const int c = k * CHUNK + cc;
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-          for (int dx = 0; dx < 3; ++dx) nb[dy * 3 + dx] = s.tile[cc][py + dy][px + dx];
-#pragma unroll
-        for (int oc = 0; oc < 3; ++oc)
-#pragma unroll
-          for (int t = 0; t < 9; ++t) o[oc] = fmaf(w2[(oc * C + k * CHUNK + cc) * 9 + t], nb[t], o[oc]);
+          for (int dx = 0; dx < 3; ++dx) {
+            const float v = s.tile[cc][py + dy][px + dx];
+            const int t = dy * 3 + dx;
+            o0 = fmaf(s.w2[(0 * C + c) * 9 + t], v, o0);
+            o1 = fmaf(s.w2[(1 * C + c) * 9 + t], v, o1);
+            o2 = fmaf(s.w2[(2 * C + c) * 9 + t], v, o2);
+          }
       }
+      __syncthreads();   // tile is rewritten by the next chunk
     }
-#pragma unroll
-    for (int oc = 0; oc < 3; ++oc) y16[(long)p * 768 + oc * 256 + tid] = f32_to_bf16(xv[oc] + o[oc]);
+    y16[(long)p * 768 + 0 * 256 + tid] = f32_to_bf16(xv[0] + o0);
+    y16[(long)p * 768 + 1 * 256 + tid] = f32_to_bf16(xv[1] + o1);
+    y16[(long)p * 768 + 2 * 256 + tid] = f32_to_bf16(xv[2] + o2);
   }
 }
 
@@ -171,66 +187,91 @@ __global__ __launch_bounds__(256) void resblock_bwd_kernel(const float* __restri
                                                            float* __restrict__ dgw, float* __restrict__ dgb,
                                                            float* __restrict__ dw2, float* __restrict__ db2) {
   __shared__ Smem s;
-  const int tid = threadIdx.x, py = tid >> 4, px = tid & 15;
+  const int tid = threadIdx.x, py = tid >> 4, px = tid & 15, lane = tid & 63, wave = tid >> 6;
   zero_halos(s, tid);
+  stage_params(s, w1, b1, gw, gb, w2, tid);
   for (int i = tid; i < 2 * C; i += 256) s.acc_gn[i] = 0.f;
   if (tid < 4) s.acc_b2[tid] = 0.f;
-  // register accumulators: output slot j of chunk k is (tid + 256*j) within the chunk's output list
+  // register accumulators over the patches this block walks: output slot j of chunk k is (tid + 256*j)
   float aw2[C / CHUNK][4], aw1[C / CHUNK][4];
 #pragma unroll
   for (int k = 0; k < C / CHUNK; ++k)
 #pragma unroll
     for (int j = 0; j < 4; ++j) { aw2[k][j] = 0.f; aw1[k][j] = 0.f; }
+  const float inv_n = 1.0f / (float)(CPG * PS * PS);
 
   for (int p = blockIdx.x; p < P; p += gridDim.x) {
-    float xv[3], g3[3];
+    float g3[3];
+    {
+      float xv[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        xv[i] = xp[(long)p * 768 + i * 256 + tid];
+        g3[i] = dy[(long)p * 768 + i * 256 + tid];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        s.gx[i][py + 1][px + 1] = gelu_f(xv[i]);
+        s.dh3[i][py + 1][px + 1] = g3[i];
+      }
+    }
+    // db2
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-      xv[i] = xp[(long)p * 768 + i * 256 + tid];
-      g3[i] = dy[(long)p * 768 + i * 256 + tid];
+      const float r = wave_sum(g3[i]);
+      if (lane == 0) s.red[wave][i] = r;
     }
     __syncthreads();
+    if (tid < 3) s.acc_b2[tid] += (s.red[0][tid] + s.red[1][tid]) + (s.red[2][tid] + s.red[3][tid]);
+    float nb[27], nb3[27];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      s.gx[i][py + 1][px + 1] = gelu_f(xv[i]);
-      s.dh3[i][py + 1][px + 1] = g3[i];
-    }
-    __syncthreads();
-    float xh[C];
-    conv1_groupnorm(s, s, w1, b1, py, px, tid, xh);
-
-    // ---- db2 -----------------------------------------------------------------------------------
-    block_reduce<3>(g3, s.chan, s, tid);   // s.chan is free until the GroupNorm backward below
-    if (tid < 3) s.acc_b2[tid] += s.chan[tid];
-
-    // ---- dW2 (needs h2 = GELU(GN out) neighbourhoods) and d_h2 ------------------------------------
-    // d_h2[c] = sum_o sum_{dy,dx} w2[o][c][dy][dx] * dh3[o][py-dy+2][px-dx+2]
-    float nb3[27];
-#pragma unroll
-    for (int o = 0; o < 3; ++o)
+    for (int i = 0; i < 3; ++i)
 #pragma unroll
       for (int dy_ = 0; dy_ < 3; ++dy_)
 #pragma unroll
-        for (int dx_ = 0; dx_ < 3; ++dx_) nb3[o * 9 + dy_ * 3 + dx_] = s.dh3[o][py - dy_ + 2][px - dx_ + 2];
-    float du[C];
+        for (int dx_ = 0; dx_ < 3; ++dx_) {
+          nb[i * 9 + dy_ * 3 + dx_] = s.gx[i][py + dy_][px + dx_];
+          nb3[i * 9 + dy_ * 3 + dx_] = s.dh3[i][py - dy_ + 2][px - dx_ + 2];
+        }
+    __syncthreads();
+
 #pragma unroll
-    for (int c = 0; c < C; ++c) {
-      float a = 0.f;
+    for (int k = 0; k < C / CHUNK; ++k) {      // unrolled: aw1/aw2 stay in registers; inner loops are dynamic
+      conv1_stats_chunk(s, k, nb, py, px, tid);
+      // xhat -> s.xh ; h2 -> haloed tile ; du = d(h2)*GELU'(u) -> s.du ; per-channel sums
+#pragma unroll 1
+      for (int g = 0; g < CHUNK / CPG; ++g) {
+        const float m = s.mean[g], rs = s.rstd[g];
 #pragma unroll
-      for (int o = 0; o < 3; ++o)
+        for (int j = 0; j < CPG; ++j) {
+          const int cc = g * CPG + j, c = k * CHUNK + cc;
+          const float xh = (s.tile[cc][py + 1][px + 1] - m) * rs;
+          const float u = fmaf(xh, s.gw[c], s.gb[c]);
+          s.xh[cc][tid] = xh;
+          s.tile[cc][py + 1][px + 1] = gelu_f(u);
+          // d_h2[c] = sum_o sum_taps w2[o][c][tap] * dh3[o][pixel - tap + 1]
+          float a = 0.f;
 #pragma unroll
-        for (int t = 0; t < 9; ++t) a = fmaf(w2[(o * C + c) * 9 + t], nb3[o * 9 + t], a);
-      const float u = fmaf(xh[c], gw[c], gb[c]);
-      du[c] = a * gelu_grad_f(u);     // gradient wrt the GroupNorm output
-    }
+          for (int o = 0; o < 3; ++o) {
+            const float* w = &s.w2[(o * C + c) * 9];
 #pragma unroll
-    for (int k = 0; k < C / CHUNK; ++k) {
+            for (int t = 0; t < 9; ++t) a = fmaf(w[t], nb3[o * 9 + t], a);
+          }
+          const float du = a * gelu_grad_f(u);
+          s.du[cc][tid] = du;
+          const float r1 = wave_sum(du * xh), r2 = wave_sum(du);
+          if (lane == 0) { s.red[wave][cc] = r1; s.red[wave][CHUNK + cc] = r2; }
+        }
+      }
       __syncthreads();
-#pragma unroll
-      for (int cc = 0; cc < CHUNK; ++cc)
-        s.tile[cc][py + 1][px + 1] = gelu_f(fmaf(xh[k * CHUNK + cc], gw[k * CHUNK + cc], gb[k * CHUNK + cc]));
-      __syncthreads();
-      // outputs of this chunk: idx = (o*CHUNK + cc)*9 + t, 864 of them
+      if (tid < 2 * CHUNK) {
+        const float v = (s.red[0][tid] + s.red[1][tid]) + (s.red[2][tid] + s.red[3][tid]);
+        s.chan[tid] = v;
+        const int c = k * CHUNK + (tid & (CHUNK - 1));
+        s.acc_gn[(tid < CHUNK ? 0 : C) + c] += v;      // [0,C) dgamma, [C,2C) dbeta
+      }
+      // dW2 sweep: outputs idx = (o*CHUNK + cc)*9 + t over the chunk (864)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int idx = tid + 256 * j;
@@ -238,69 +279,33 @@ __global__ __launch_bounds__(256) void resblock_bwd_kernel(const float* __restri
           const int t = idx % 9, cc = (idx / 9) % CHUNK, o = idx / (9 * CHUNK);
           const int dy_ = t / 3, dx_ = t % 3;
           float a = 0.f;
+#pragma unroll 1
           for (int yy = 0; yy < PS; ++yy)
 #pragma unroll
             for (int xx = 0; xx < PS; ++xx) a = fmaf(s.dh3[o][yy + 1][xx + 1], s.tile[cc][yy + dy_][xx + dx_], a);
           aw2[k][j] += a;
         }
       }
-    }
-
-    // ---- GroupNorm backward ------------------------------------------------------------------------
-    // per-patch per-channel sums over pixels: chan[c] = sum du*xhat, chan[C+c] = sum du
-#pragma unroll
-    for (int k = 0; k < 2 * C / CHUNK; ++k) {   // 8 chunks of 32 values
       __syncthreads();
-      float* t = &s.tile[0][0][0];              // [32][256] scratch
+      // d_h1 = rstd_g * (du*gamma - A_g/N - xhat*B_g/N) in place of du (own pixel)
+#pragma unroll 1
+      for (int g = 0; g < CHUNK / CPG; ++g) {
+        float A = 0.f, Bv = 0.f;
 #pragma unroll
-      for (int v = 0; v < CHUNK; ++v) {
-        const int idx = k * CHUNK + v;
-        const float val = (idx < C) ? du[idx < C ? idx : 0] * xh[idx < C ? idx : 0] : du[idx >= C ? idx - C : 0];
-        t[v * 256 + tid] = val;
+        for (int j = 0; j < CPG; ++j) {
+          const int cc = g * CPG + j;
+          A = fmaf(s.gw[k * CHUNK + cc], s.chan[CHUNK + cc], A);
+          Bv = fmaf(s.gw[k * CHUNK + cc], s.chan[cc], Bv);
+        }
+        const float rs = s.rstd[g];
+#pragma unroll
+        for (int j = 0; j < CPG; ++j) {
+          const int cc = g * CPG + j;
+          s.du[cc][tid] = rs * (s.du[cc][tid] * s.gw[k * CHUNK + cc] - A * inv_n - s.xh[cc][tid] * Bv * inv_n);
+        }
       }
       __syncthreads();
-      // 8 threads per value row
-      const int row = tid >> 3, sub = tid & 7;
-      float a = 0.f;
-#pragma unroll 8
-      for (int i = 0; i < 32; ++i) a += t[row * 256 + sub * 32 + i];
-      a += __shfl_xor(a, 1, 64);
-      a += __shfl_xor(a, 2, 64);
-      a += __shfl_xor(a, 4, 64);
-      if (sub == 0) s.chan[k * CHUNK + row] = a;
-    }
-    __syncthreads();
-    if (tid < C) {
-      s.acc_gn[tid] += s.chan[tid];             // dgamma
-      s.acc_gn[C + tid] += s.chan[C + tid];     // dbeta
-    }
-    // d_h1[c] = rstd_g * (du*gamma - A_g/N - xhat * B_g/N),  A_g = sum_c gamma*sum(du), B_g = sum_c gamma*sum(du*xhat)
-    const float inv_n = 1.0f / (float)(CPG * PS * PS);
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-      float A = 0.f, Bv = 0.f;
-#pragma unroll
-      for (int j = 0; j < CPG; ++j) {
-        A = fmaf(gw[g * CPG + j], s.chan[C + g * CPG + j], A);
-        Bv = fmaf(gw[g * CPG + j], s.chan[g * CPG + j], Bv);
-      }
-      const float rstd = rsqrtf(s.stat[G + g] * inv_n + GN_EPS);
-#pragma unroll
-      for (int j = 0; j < CPG; ++j) {
-        const int c = g * CPG + j;
-        du[c] = rstd * (du[c] * gw[c] - A * inv_n - xh[c] * Bv * inv_n);   // now d_h1
-      }
-    }
-
-    // ---- dW1 / db1 -----------------------------------------------------------------------------------
-#pragma unroll
-    for (int k = 0; k < C / CHUNK; ++k) {
-      __syncthreads();
-      float* t = &s.tile[0][0][0];              // [32][256]
-#pragma unroll
-      for (int cc = 0; cc < CHUNK; ++cc) t[cc * 256 + tid] = du[k * CHUNK + cc];
-      __syncthreads();
-      // outputs: idx < 864: (cc, i, dy, dx) ; 864 <= idx < 896: bias of channel idx-864
+      // dW1 / db1 sweep: idx < 864: (cc, i, tap); 864 <= idx < 896: bias of channel idx-864
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int idx = tid + 256 * j;
@@ -308,24 +313,20 @@ __global__ __launch_bounds__(256) void resblock_bwd_kernel(const float* __restri
           const int t9 = idx % 9, i = (idx / 9) % 3, cc = idx / 27;
           const int dy_ = t9 / 3, dx_ = t9 % 3;
           float a = 0.f;
+#pragma unroll 1
           for (int yy = 0; yy < PS; ++yy)
 #pragma unroll
-            for (int xx = 0; xx < PS; ++xx) a = fmaf(t[cc * 256 + yy * 16 + xx], s.gx[i][yy + dy_][xx + dx_], a);
+            for (int xx = 0; xx < PS; ++xx) a = fmaf(s.du[cc][yy * 16 + xx], s.gx[i][yy + dy_][xx + dx_], a);
           aw1[k][j] += a;
         } else if (idx < CHUNK * 28) {
           const int cc = idx - CHUNK * 27;
           float a = 0.f;
 #pragma unroll 8
-          for (int q = 0; q < 256; ++q) a += t[cc * 256 + q];
+          for (int q = 0; q < 256; ++q) a += s.du[cc][q];
           aw1[k][j] += a;
         }
       }
-    }
-    __syncthreads();
-    // restore the zero halo of the scratch tile (the [32][256] scratch use overwrote it)
-    {
-      float* t = &s.tile[0][0][0];
-      for (int i = tid; i < CHUNK * HALO * HALO; i += 256) t[i] = 0.f;
+      __syncthreads();
     }
   }
 

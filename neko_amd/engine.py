@@ -218,6 +218,33 @@ def lm_head_loss(Hp: HeadParams, hf16: torch.Tensor, target: torch.Tensor, sel: 
     return loss, dlogits
 
 
+def lm_head_loss_selected(Hp: HeadParams, hf16: torch.Tensor, target: torch.Tensor, idx: torch.Tensor, n: int,
+                          want_grad: bool, chunk_rows: int = 4096):
+    """Same loss as lm_head_loss, but only the n selected positions (idx: int32 flat row indices, known on the
+    host from the packing descriptors) go through the LM head -- the HIP counterpart of the reference's
+    boolean-mask gather (gato_policy.py:183-185), done before the GEMM instead of after it.
+    Returns (loss, hsel bf16 [npad,d], dlogits bf16 [npad,Vpad] | None)."""
+    npad = max(64, (n + 63) // 64 * 64)        # multiple of 64: keeps the wgrad contraction on the fast GEMM path
+    dev = hf16.device
+    hsel = ops.gather_rows_bf16(hf16, idx, n, npad)
+    tsel = torch.zeros(npad, dtype=torch.int64, device=dev)
+    tsel[:n] = target.index_select(0, idx[:n].long())
+    sel = torch.zeros(npad, dtype=F32, device=dev)
+    sel[:n] = 1.0
+    count = torch.full((), float(max(n, 1)), dtype=F32, device=dev)
+    loss, dlogits = lm_head_loss(Hp, hsel, tsel, sel, count, want_grad, chunk_rows)
+    return loss, hsel, dlogits
+
+
+def lm_head_backward_selected(Hp: HeadParams, hsel: torch.Tensor, dlogits: torch.Tensor, grad_out: torch.Tensor,
+                              idx: torch.Tensor, n: int, M: int) -> torch.Tensor:
+    """Backward of lm_head_loss_selected: gradient rows are scattered back into a zero [M,d] buffer."""
+    dsel = lm_head_backward(Hp, hsel, dlogits, grad_out)
+    dhf = torch.zeros(M, hsel.shape[1], dtype=F32, device=hsel.device)
+    ops.scatter_rows_f32(dsel, idx, n, dhf)
+    return dhf
+
+
 def lm_head_backward(Hp: HeadParams, hf16: torch.Tensor, dlogits: torch.Tensor, grad_out: torch.Tensor) -> torch.Tensor:
     """dH = (dlogits @ W) * grad_out  [M,d] fp32;  dW += (dlogits^T @ H) * grad_out.
     grad_out stays on the device (GEMM alpha_dev): no host sync in backward."""

@@ -50,7 +50,8 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, a_kstrided
          resid: Optional[torch.Tensor] = None, act: int = 0, act_in: Optional[torch.Tensor] = None,
          pre_out: Optional[torch.Tensor] = None, out_f32: Optional[torch.Tensor] = None, ldcf: Optional[int] = None,
          accumulate: bool = False, out_bf16: Optional[torch.Tensor] = None, ldcb: Optional[int] = None,
-         splitk: int = 1, k_per_split: int = 0, safe_transpose: Optional[int] = None) -> None:
+         splitk: int = 1, k_per_split: int = 0, safe_transpose: Optional[int] = None,
+         deterministic_splitk: bool = True) -> None:
     """C[M,N] = alpha * opA(A) @ opB(B) (+bias)(act)(+resid)(+C).  See neko_gemm_bf16 in include/neko_hip.h."""
     _chk(A, BF16, "A"); _chk(B, BF16, "B")
     if lda is None:
@@ -78,9 +79,12 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, a_kstrided
     if alpha_dev is not None:
         _chk(alpha_dev, torch.float32, "alpha_dev")
     st = SAFE_TRANSPOSE if safe_transpose is None else safe_transpose
+    ws = None
+    if splitk > 1 and deterministic_splitk and N % 4 == 0:
+        ws = torch.empty(splitk * M * N, dtype=torch.float32, device=A.device)
     _lib.call("neko_gemm_bf16", _p(A), lda, int(a_kstrided), _p(B), ldb, int(b_kstrided), M, N, K, float(alpha),
               _p(alpha_dev), _p(bias), _p(resid), ldr, act, _p(act_in), ldact, _p(pre_out), ldpre, _p(out_f32),
-              ldcf or 0, int(accumulate), _p(out_bf16), ldcb or 0, splitk, k_per_split, st, _stream())
+              ldcf or 0, int(accumulate), _p(out_bf16), ldcb or 0, splitk, k_per_split, _p(ws), st, _stream())
 
 
 def layernorm_fwd(x, gamma, beta, y16=None, y32=None, mean=None, rstd=None, eps: float = 1e-5):
@@ -164,6 +168,20 @@ def tokenize_continuous(x, use_mu_law, mu, M, n_bins, offset):
     _lib.call("neko_tokenize_continuous", _p(x), _p(ids), x.numel(), int(use_mu_law), float(mu), float(M), n_bins,
               offset if offset is not None else 0, _stream())
     return ids
+
+
+def gather_rows_bf16(src, idx, n, npad):
+    """dst[r] = src[idx[r]] for r < n, zero rows up to npad."""
+    _chk(src, BF16, "src"); _chk(idx, torch.int32, "idx")
+    d = src.shape[1]
+    dst = torch.empty(npad, d, dtype=BF16, device=src.device)
+    _lib.call("neko_gather_rows_bf16", _p(src), _p(idx), _p(dst), n, npad, d, _stream())
+    return dst
+
+
+def scatter_rows_f32(src, idx, n, dst):
+    _chk(src, torch.float32, "src"); _chk(dst, torch.float32, "dst")
+    _lib.call("neko_scatter_rows_f32", _p(src), _p(idx), _p(dst), n, src.shape[1], _stream())
 
 
 def cast_f32_bf16(x, y):

@@ -177,10 +177,18 @@ class _PolicyCoreFn(torch.autograd.Function):
         logits = engine.lm_head_logits(hp, hf16).view(B, T, hp.V) if return_logits else x.new_zeros(0)
         loss = x.new_zeros(())
         dlogits = None
+        ctx.sel_idx = None
         if compute_loss:
             target, sel, count = engine.shift_targets(tokens, tmask, pmask)
-            loss, dlogits = engine.lm_head_loss(hp, hf16, target, sel, count, want_grad=need,
-                                                chunk_rows=policy.lm_head_chunk_rows)
+            cached = policy._loss_rows_for(tokens)
+            if cached is not None and policy.lm_head_selected_rows:
+                idx, n = cached
+                loss, hf16, dlogits = engine.lm_head_loss_selected(hp, hf16, target, idx, n, want_grad=need,
+                                                                   chunk_rows=policy.lm_head_chunk_rows)
+                ctx.sel_idx, ctx.sel_n = idx, n
+            else:
+                loss, dlogits = engine.lm_head_loss(hp, hf16, target, sel, count, want_grad=need,
+                                                    chunk_rows=policy.lm_head_chunk_rows)
         ctx.policy, ctx.sctx, ctx.hf16, ctx.dlogits, ctx.shape = policy, sctx, hf16 if need else None, dlogits, (B, T, d)
         ctx.mark_non_differentiable(logits)
         return logits, loss
@@ -193,7 +201,11 @@ class _PolicyCoreFn(torch.autograd.Function):
         names = policy.transformer._param_names() + ["predict_token.weight"]
         f.prepare_backward(names)
         dp = policy._dp
-        dhf = engine.lm_head_backward(policy._head_params(), ctx.hf16, ctx.dlogits, g_loss)
+        if ctx.sel_idx is not None:
+            dhf = engine.lm_head_backward_selected(policy._head_params(), ctx.hf16, ctx.dlogits, g_loss, ctx.sel_idx,
+                                                   ctx.sel_n, B * T)
+        else:
+            dhf = engine.lm_head_backward(policy._head_params(), ctx.hf16, ctx.dlogits, g_loss)
         if dp is not None:
             dp.group_ready("head")
 
@@ -308,6 +320,8 @@ class GatoPolicy(nn.Module):
         self.pos_embed_observation = nn.Embedding(context_len, embed_dim)            # :149
 
         self.lm_head_chunk_rows = 4096
+        self.lm_head_selected_rows = True   # LM head only at loss positions when they are known on the host
+        self._loss_rows = None
         self._dp = None
         self._hp = None
         self._flat: Optional[FlatParams] = None
@@ -353,6 +367,14 @@ class GatoPolicy(nn.Module):
                                          g_w=self._flat.gview("predict_token.weight", padded_rows=self.Vpad))
         return self._hp
 
+    def _loss_rows_for(self, tokens):
+        """(idx int32 device tensor, n) of the loss positions if `tokens` is the tensor the last
+        tokenize_input_dicts() produced (host-known selection), else None."""
+        c = getattr(self, "_loss_rows", None)
+        if c is None or tokens is None or tokens.data_ptr() != c[0] or tokens.numel() != c[1] or c[3] == 0:
+            return None
+        return c[2], c[3]
+
     @property
     def module(self):
         return self
@@ -384,6 +406,14 @@ class GatoPolicy(nn.Module):
         params = [self._flat.param_of[n] for n in self._frontend_names()]
         x, tokens, tmask, pmask = _PackEmbedV2.apply(self, desc, cont, disc, img_emb, pb.B * pb.T, *params)
         B, T, d = pb.B, pb.T, self.embed_dim
+        # loss positions are known on the host (gato_policy.py:176-183): row (b,t) is selected when position t is
+        # real and position t+1 is a target.  Uploaded once; lets the LM head run on the selected rows only.
+        dk = pb.desc.reshape(B, T, 4)
+        selm = np.zeros((B, T), dtype=bool)
+        selm[:, :-1] = (dk[:, :-1, 0] != K_PAD) & (dk[:, 1:, 3] != 0)
+        sel_idx = np.flatnonzero(selm.reshape(-1)).astype(np.int32)
+        idx_dev = torch.from_numpy(sel_idx if sel_idx.size else np.zeros(1, np.int32)).pin_memory().to(dev, non_blocking=True)
+        self._loss_rows = (tokens.data_ptr(), B * T, idx_dev, int(sel_idx.size))
         return x.view(B, T, d), tokens.view(B, T), tmask.view(B, T), pmask.view(B, T)
 
     # ---- forward (gato_policy.py:156-192) -------------------------------------------------------------

@@ -44,9 +44,10 @@ def ops():
 # ----------------------------------------------------------------------------------------------------
 # GEMM
 # ----------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("safe", [0, 1])
+@pytest.mark.parametrize("safe", [0, 1, 2])   # 0 direct-to-LDS fast path (when K%64==0), 1 transposing stores, 2 register-staged
 @pytest.mark.parametrize("layout", ["nt", "nn", "tn"])
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 136, 264), (77, 520, 1000), (512, 2304, 768)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 136, 264), (77, 520, 1000), (512, 2304, 768), (333, 776, 1024),
+                                   (1024, 52305, 128)])
 def test_gemm_layouts(ops, layout, M, N, K, safe):
     g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
     A = rb(torch.randn(M, K, generator=g))          # logical [M,K]

@@ -1,0 +1,91 @@
+#!/usr/bin/env python
+"""Per-shape timing of neko_gemm_bf16 on the GEMM shapes of the 768d/6L step (B*T = 32768 rows).
+    python tools/gemm_bench.py [--iters 20] [--only substr] [--safe N]
+Prints us / TFLOP/s per shape; run under rocprofv3 --pmc for counters."""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from neko_amd import ops  # noqa: E402
+
+M, D, V, VP = 32768, 768, 52305, 52352
+BF = torch.bfloat16
+
+# name, M, N, K, a_kstrided, b_kstrided, extras
+SHAPES = [
+    ("fwd qkv   NN", M, 3 * D, D, False, True, "bias,bf16"),
+    ("fwd proj  NN", M, D, D, False, True, "bias,resid,f32"),
+    ("fwd fc    NN", M, 4 * D, D, False, True, "bias,gelu,bf16"),
+    ("fwd pr    NN", M, D, 4 * D, False, True, "bias,resid,f32"),
+    ("dgrad pr  NT", M, 4 * D, D, False, False, "gelubwd,bf16"),
+    ("dgrad fc  NT", M, D, 4 * D, False, False, "f32"),
+    ("dgrad o   NT", M, D, D, False, False, "bf16"),
+    ("dgrad qkv NT", M, D, 3 * D, False, False, "f32"),
+    ("wgrad pr  TN", 4 * D, D, M, True, True, "splitk"),
+    ("wgrad fc  TN", D, 4 * D, M, True, True, "splitk"),
+    ("wgrad o   TN", D, D, M, True, True, "splitk"),
+    ("wgrad qkv TN", D, 3 * D, M, True, True, "splitk"),
+    ("lm logits NT", 4096, V, D, False, False, "f32,ldc=%d" % VP),
+    ("lm dH     NN", M, D, VP, False, True, "f32"),
+    ("lm dW     TN", VP, D, M, True, True, "acc"),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--only", default="")
+    ap.add_argument("--safe", type=int, default=0)
+    args = ap.parse_args()
+    dev = "cuda"
+    g = torch.Generator(device=dev).manual_seed(0)
+    tot_us = 0.0
+    for name, m, n, k, aks, bks, ex in SHAPES:
+        if args.only and args.only not in name:
+            continue
+        A = (torch.randn((k, m) if aks else (m, k), device=dev, generator=g)).to(BF)
+        Bm = (torch.randn((k, n) if bks else (n, k), device=dev, generator=g) * 0.05).to(BF)
+        kw = dict(a_kstrided=aks, b_kstrided=bks, safe_transpose=args.safe)
+        ldc = VP if "ldc=" in ex else n
+        if "bias" in ex:
+            kw["bias"] = torch.randn(n, device=dev)
+        if "resid" in ex:
+            kw["resid"] = torch.randn(m, n, device=dev)
+        if "gelu," in ex:
+            kw["act"] = 1
+            kw["pre_out"] = torch.empty(m, n, dtype=BF, device=dev)
+        if "gelubwd" in ex:
+            kw["act"] = 2
+            kw["act_in"] = torch.randn(m, n, device=dev).to(BF)
+        if "bf16" in ex:
+            kw["out_bf16"] = torch.empty(m, n, dtype=BF, device=dev)
+        else:
+            kw["out_f32"] = torch.zeros(m, ldc, device=dev)
+            kw["ldcf"] = ldc
+        if "splitk" in ex:
+            sk, kps = ops.pick_splitk(m, n, k)
+            kw.update(splitk=sk, k_per_split=kps, accumulate=(sk == 1))
+        if "acc" in ex:
+            kw["accumulate"] = True
+        for _ in range(3):
+            ops.gemm(A, Bm, m, n, k, **kw)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.iters):
+            ops.gemm(A, Bm, m, n, k, **kw)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / args.iters
+        tf = 2.0 * m * n * k / us / 1e6
+        tot_us += us
+        print(f"{name:14s} M={m:6d} N={n:6d} K={k:6d} {ex:22s} {us:9.1f} us  {tf:7.1f} TFLOP/s"
+              + (f"  splitk={kw['splitk']}" if kw.get("splitk", 1) > 1 else ""))
+        del A, Bm, kw
+    print(f"sum {tot_us:.1f} us")
+
+
+if __name__ == "__main__":
+    main()
