@@ -1,0 +1,78 @@
+"""world_size-2 tests of the data-parallel path on CPU (backend gloo): parameter broadcast, per-range
+gradient all-reduce in backward order + deferred ranges, identical collective order on ranks whose batches
+touch different parameter ranges, the reduced "range active" flags and the 1/world gradient scale."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, results):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from neko_amd.dp import GradReducer
+        from neko_amd.policy.gato_policy import GatoPolicy
+        torch.manual_seed(100 + rank)            # different initial weights per rank
+        m = GatoPolicy("cpu", 64, 2, 2, 0.0, resid_mid_channels=128, context_len=32, text_tokenizer=64)
+        flat = m._flat
+        dp = GradReducer(flat, bucket_bytes=64 * 1024)      # small buckets: several slices per range
+        dp.broadcast_parameters()
+        w0 = flat.data.clone()
+        # rank-specific gradients; rank 1 has "no images" (its image range stays zero and it never signals it)
+        g = torch.Generator().manual_seed(7 + rank)
+        flat.grad.copy_(torch.randn(flat.total, generator=g))
+        a, b = flat.group_ranges["image"]
+        if rank == 1:
+            flat.grad[a:b] = 0
+        local = flat.grad.clone()
+        # backward order: head, ln_f, layer1, layer0 ; rank 0 additionally reports the image range (ignored: deferred)
+        for name in ["head", "lnf", "layer1", "layer0"]:
+            dp.group_ready(name)
+        if rank == 0:
+            dp.group_ready("image")
+        dp.group_ready("frontend")
+        dp.flush()
+        dp.finish()
+        flags = torch.tensor([1, 1 if rank == 0 else 0, 1], dtype=torch.int32)
+        dp.reduce_flags(flags)
+        gathered = [torch.zeros_like(local) for _ in range(world)]
+        dist.all_gather(gathered, local)
+        expect = sum(gathered)
+        na, nb = flat.group_ranges["never"]
+        ok_sum = torch.allclose(flat.grad[:na], expect[:na], rtol=1e-6, atol=1e-6)
+        ok_never = torch.equal(flat.grad[na:nb], local[na:nb])       # the never-used range is not reduced
+        w_all = [torch.zeros_like(w0) for _ in range(world)]
+        dist.all_gather(w_all, w0)
+        results[rank] = dict(ok_sum=bool(ok_sum), ok_never=bool(ok_never), same_w=bool(torch.equal(w_all[0], w_all[1])),
+                             flags=flags.tolist(), scale=float(dp.grad_scale))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_grad_reducer_world2_gloo():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as mgr:
+        results = mgr.dict()
+        procs = [ctx.Process(target=_worker, args=(r, world, port, results)) for r in range(world)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(timeout=240)
+            assert p.exitcode == 0, f"worker exit code {p.exitcode}"
+        for r in range(world):
+            res = results[r]
+            assert res["ok_sum"] and res["ok_never"] and res["same_w"], res
+            assert res["flags"] == [1, 1, 1]          # union over ranks of "range took part in this step"
+            assert abs(res["scale"] - 0.5) < 1e-12    # averaging folded into the optimiser's gradient scale

