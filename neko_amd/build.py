@@ -22,6 +22,7 @@ SOURCES = ["gemm_bf16.hip", "gemm_glds.hip", "layernorm.hip", "attention.hip", "
 HEADERS = ["neko_common.h", "neko_kernels.h", os.path.join("..", "..", "include", "neko_hip.h")]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=on", "-Wno-unused-result"]
+FLAGS += os.environ.get("NEKO_EXTRA_HIPCC_FLAGS", "").split()
 
 
 def _hipcc() -> str:

@@ -25,6 +25,10 @@ constexpr int NT = 256;
 constexpr int KT = 64;          // keys (or queries, in dK/dV) per inner tile
 constexpr int TSTR = KT * 2 + 8;  // transposed image row stride in bytes (136: conflict-free ds_read_b64)
 constexpr float MASK_VAL = -10000.0f;
+constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+// the softmax runs in the exp2 domain: scores are pre-multiplied by log2(e) (folded into the 1/sqrt(hd) scale),
+// v_exp_f32 is 2^x natively, and LSE is converted back to natural log when stored.
+__device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }
 
 template <int HD> struct Cfg {
   static constexpr int NSTR = HD * 2 + 16;    // natural image row stride (bytes)
@@ -90,10 +94,9 @@ __device__ __forceinline__ bf16x8_v frag_tr(const char* lds, int hdbase, int s, 
 __device__ __forceinline__ bf16x8_v frag_from_acc(const f32x16 (&t)[2], int s) {
   const f32x16& a = t[s >> 1];
   const int o = 8 * (s & 1);
-  bf16x8_v r;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) r[j] = (__bf16)a[o + j];
-  return r;
+  const uint4 r = make_uint4(pack_bf16x2(a[o + 0], a[o + 1]), pack_bf16x2(a[o + 2], a[o + 3]),
+                             pack_bf16x2(a[o + 4], a[o + 5]), pack_bf16x2(a[o + 6], a[o + 7]));
+  return __builtin_bit_cast(bf16x8_v, r);
 }
 // own-row B fragments (lane's query/key row, head-dim slots ks*16 + 8*(lane/32)..+7) straight from HBM
 template <int HD>
@@ -113,7 +116,7 @@ __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (
 // forward
 // =====================================================================================================
 template <int HD>
-__global__ __launch_bounds__(NT) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ kbias,
+__global__ __launch_bounds__(NT, (HD <= 32 ? 4 : (HD <= 64 ? 3 : 2))) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ kbias,
                                                       const int* __restrict__ kstart, bf16_t* __restrict__ out,
                                                       float* __restrict__ lse, int B, int T, int H, float scale) {
   using C = Cfg<HD>;
@@ -154,6 +157,7 @@ __global__ __launch_bounds__(NT) void attn_fwd_kernel(const bf16_t* __restrict__
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
+  const float scale2 = scale * LOG2E;
 
   uint4 rk[C::LPT], rv[C::LPT];
   float rkb = 0.f;
@@ -172,68 +176,65 @@ __global__ __launch_bounds__(NT) void attn_fwd_kernel(const bf16_t* __restrict__
     tile_store_tr<HD>(ldsVt, tid, rv);
     if (tid < KT) ldsKb[tid] = rkb;
     const int has_pad = __syncthreads_or(tid < KT && rkb != 0.f);
+#ifndef NEKO_ATTN_DIAG_NOLOAD
     if (kt + 1 < kt_end) prefetch(kt + 1);
+#endif
 
-    // S^T = K . Q^T : two 32-key tiles
-    f32x16 s[2];
+    // two 32-key sub-tiles, one at a time (only 16 score registers live): S^T = K.Q^T -> masks -> online
+    // softmax (lane pair (l, l^32) shares a query) -> O^T += V^T.P^T
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
+      f32x16 st;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
+      for (int r = 0; r < 16; ++r) st[r] = 0.f;
 #pragma unroll
       for (int ks = 0; ks < C::KS; ++ks)
-        s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_nat<HD>(ldsK, t * 32, ks, lane), qf[ks], s[t], 0, 0, 0);
-    }
-    // scale + masks (wave-uniform choice of the cheap path)
-    const bool interior = (k0 + KT - 1 <= qw0) && !has_pad && (k0 + KT <= T);
-    if (interior) {
+        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_nat<HD>(ldsK, t * 32, ks, lane), qf[ks], st, 0, 0, 0);
+      // wave-uniform choice of the cheap path: every key of the sub-tile is visible to every query of the wave
+      const bool interior = (k0 + t * 32 + 31 <= qw0) && !has_pad && (k0 + KT <= T);
+      if (interior) {
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[t][r] *= scale;
-    } else {
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
+        for (int r = 0; r < 16; ++r) st[r] *= scale2;
+      } else {
+        const int lim_causal = q - k0 - t * 32 - 4 * (lane >> 5);        // key <= q  <=>  c(r) <= lim_causal
+        const int lim_len = T - 1 - k0 - t * 32 - 4 * (lane >> 5);       // key <  T  <=>  c(r) <= lim_len
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int kl = t * 32 + acc_row(r, lane);
-          const int key = k0 + kl;
-          float v = (key <= q) ? s[t][r] * scale : MASK_VAL;
-          v += ldsKb[kl];
-          s[t][r] = (key < T) ? v : -INFINITY;
+          const int c = (r & 3) + 8 * (r >> 2);
+          float v = (c <= lim_causal) ? st[r] * scale2 : MASK_VAL * LOG2E;
+          v = fmaf(ldsKb[t * 32 + c + 4 * (lane >> 5)], LOG2E, v);
+          st[r] = (c <= lim_len) ? v : -INFINITY;
         }
-    }
-    // online softmax: lane pair (l, l^32) shares a query
-    float mx = s[0][0];
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[t][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = __expf(m_run - m_new);   // exp(-inf) = 0 on the first tile
-    float psum = 0.f;
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float pv = __expf(s[t][r] - m_new);
-        s[t][r] = pv;
-        psum += pv;
       }
-    l_run = l_run * alpha + psum;
-    m_run = m_new;
+      float mx = fmaxf(st[0], st[1]);
 #pragma unroll
-    for (int i = 0; i < C::IB; ++i)
+      for (int r = 2; r < 16; ++r) mx = fmaxf(mx, st[r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = exp2_fast(m_run - m_new);   // 2^(-inf) = 0 on the first tile
+      float ps0 = 0.f, ps1 = 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
-    // O^T += V^T . P^T
-#pragma unroll
-    for (int sp = 0; sp < 4; ++sp) {
-      const bf16x8_v pf = frag_from_acc(s, sp);
+      for (int r = 0; r < 16; r += 2) {
+        st[r] = exp2_fast(st[r] - m_new);
+        st[r + 1] = exp2_fast(st[r + 1] - m_new);
+        ps0 += st[r];
+        ps1 += st[r + 1];
+      }
+      l_run = fmaf(l_run, alpha, ps0 + ps1);
+      m_run = m_new;
 #pragma unroll
       for (int i = 0; i < C::IB; ++i)
-        o[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(ldsVt, i * 32, sp, lane), pf, o[i], 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2) {
+        const uint4 pw = make_uint4(pack_bf16x2(st[8 * h2 + 0], st[8 * h2 + 1]), pack_bf16x2(st[8 * h2 + 2], st[8 * h2 + 3]),
+                                    pack_bf16x2(st[8 * h2 + 4], st[8 * h2 + 5]), pack_bf16x2(st[8 * h2 + 6], st[8 * h2 + 7]));
+        const bf16x8_v pf = __builtin_bit_cast(bf16x8_v, pw);
+#pragma unroll
+        for (int i = 0; i < C::IB; ++i)
+          o[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(ldsVt, i * 32, 2 * t + h2, lane), pf, o[i], 0, 0, 0);
+      }
     }
   }
 
@@ -250,7 +251,7 @@ __global__ __launch_bounds__(NT) void attn_fwd_kernel(const bf16_t* __restrict__
         pk.y = pack_bf16x2(o[i][4 * g + 2] * inv, o[i][4 * g + 3] * inv);
         *reinterpret_cast<uint2*>(orow + i * 32 + 8 * g + 4 * (lane >> 5)) = pk;
       }
-    if (lane < 32) lse[((long)b * H + h) * T + q] = m_run + __logf(l_tot);
+    if (lane < 32) lse[((long)b * H + h) * T + q] = m_run * LN2 + __logf(l_tot);
   }
 }
 
@@ -294,7 +295,7 @@ __global__ void attn_bwd_prep_kernel(const bf16_t* __restrict__ o, const bf16_t*
 // backward dQ: lanes own queries (same geometry as forward)
 // =====================================================================================================
 template <int HD>
-__global__ __launch_bounds__(NT) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+__global__ __launch_bounds__(NT, (HD <= 32 ? 4 : (HD <= 64 ? 2 : 1))) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                          const float* __restrict__ kbias, const int* __restrict__ kstart,
                                                          const float* __restrict__ lse, const float* __restrict__ Dv,
                                                          bf16_t* __restrict__ dqkv, int B, int T, int H, float scale) {
@@ -322,7 +323,8 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_kernel(const bf16_t* __restric
   bf16x8_v qf[C::KS], dof[C::KS];
   row_frags<HD>(qbase + (long)q * ld, qvalid, lane, qf);
   row_frags<HD>(dout + ((long)b * T + q) * d + h * HD, qvalid, lane, dof);
-  const float my_lse = qvalid ? lse[((long)b * H + h) * T + q] : 0.f;
+  const float my_lse = (qvalid ? lse[((long)b * H + h) * T + q] : 0.f) * LOG2E;
+  const float scale2 = scale * LOG2E;
   const float my_D = qvalid ? Dv[((long)b * H + h) * T + q] : 0.f;
 
   int masked_q = 0;
@@ -358,36 +360,38 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_kernel(const bf16_t* __restric
     __syncthreads();
     if (kt + 1 < kt_end) prefetch(kt + 1);
 
-    f32x16 s[2], dp[2];
+    // one 32-key sub-tile at a time (16 score + 16 dP registers live)
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
+      f32x16 st, dpt;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { s[t][r] = 0.f; dp[t][r] = 0.f; }
+      for (int r = 0; r < 16; ++r) { st[r] = 0.f; dpt[r] = 0.f; }
 #pragma unroll
       for (int ks = 0; ks < C::KS; ++ks) {
-        s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_nat<HD>(ldsK, t * 32, ks, lane), qf[ks], s[t], 0, 0, 0);
-        dp[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_nat<HD>(ldsV, t * 32, ks, lane), dof[ks], dp[t], 0, 0, 0);
+        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_nat<HD>(ldsK, t * 32, ks, lane), qf[ks], st, 0, 0, 0);
+        dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_nat<HD>(ldsV, t * 32, ks, lane), dof[ks], dpt, 0, 0, 0);
       }
-    }
-    // dS^T = P^T o (dP^T - D); zero where the score was REPLACED by the causal constant
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
+      // dS^T = P^T o (dP^T - D); zero where the score was REPLACED by the causal constant
+      const int lim_causal = q - k0 - t * 32 - 4 * (lane >> 5);
+      const int lim_len = T - 1 - k0 - t * 32 - 4 * (lane >> 5);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int kl = t * 32 + acc_row(r, lane);
-        const int key = k0 + kl;
-        const bool causal_ok = key <= q;
-        float sv = (causal_ok ? s[t][r] * scale : MASK_VAL) + ldsKb[kl];
-        const float pv = (key < T) ? __expf(sv - my_lse) : 0.f;
-        s[t][r] = causal_ok ? pv * (dp[t][r] - my_D) : 0.f;
+        const int c = (r & 3) + 8 * (r >> 2);
+        const bool causal_ok = c <= lim_causal;
+        const float sv = fmaf(ldsKb[t * 32 + c + 4 * (lane >> 5)], LOG2E, causal_ok ? st[r] * scale2 : MASK_VAL * LOG2E);
+        const float pv = (c <= lim_len) ? exp2_fast(sv - my_lse) : 0.f;
+        st[r] = causal_ok ? pv * (dpt[r] - my_D) : 0.f;
       }
-    // dQ^T += K^T . dS^T
+      // dQ^T += K^T . dS^T
 #pragma unroll
-    for (int sp = 0; sp < 4; ++sp) {
-      const bf16x8_v df = frag_from_acc(s, sp);
+      for (int h2 = 0; h2 < 2; ++h2) {
+        const uint4 w = make_uint4(pack_bf16x2(st[8 * h2 + 0], st[8 * h2 + 1]), pack_bf16x2(st[8 * h2 + 2], st[8 * h2 + 3]),
+                                   pack_bf16x2(st[8 * h2 + 4], st[8 * h2 + 5]), pack_bf16x2(st[8 * h2 + 6], st[8 * h2 + 7]));
+        const bf16x8_v df = __builtin_bit_cast(bf16x8_v, w);
 #pragma unroll
-      for (int i = 0; i < C::IB; ++i)
-        dq[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(ldsKt, i * 32, sp, lane), df, dq[i], 0, 0, 0);
+        for (int i = 0; i < C::IB; ++i)
+          dq[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(ldsKt, i * 32, 2 * t + h2, lane), df, dq[i], 0, 0, 0);
+      }
     }
   }
 
@@ -409,7 +413,7 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_kernel(const bf16_t* __restric
 // backward dK/dV: lanes own keys; loop over 64-query tiles
 // =====================================================================================================
 template <int HD>
-__global__ __launch_bounds__(NT) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+__global__ __launch_bounds__(NT, (HD <= 32 ? 3 : (HD <= 64 ? 2 : 1))) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                           const float* __restrict__ kbias, const float* __restrict__ lse,
                                                           const float* __restrict__ Dv, const int* __restrict__ qflags,
                                                           bf16_t* __restrict__ dqkv, int B, int T, int H, float scale) {
@@ -437,7 +441,8 @@ __global__ __launch_bounds__(NT) void attn_bwd_dkv_kernel(const bf16_t* __restri
   const int k0 = kblk * 128, kw0 = k0 + wave * 32;
   const int key = kw0 + (lane & 31);
   const bool kvalid = key < T;
-  const float my_kb = kvalid ? kbias[(long)b * T + key] : 0.f;
+  const float my_kb = (kvalid ? kbias[(long)b * T + key] : 0.f) * LOG2E;
+  const float scale2 = scale * LOG2E;
 
   bf16x8_v kf[C::KS], vf[C::KS];
   row_frags<HD>(kbase + (long)key * ld, kvalid, lane, kf);
@@ -462,7 +467,7 @@ __global__ __launch_bounds__(NT) void attn_bwd_dkv_kernel(const bf16_t* __restri
     const int q0 = t * KT;
     tile_load<HD>(qbase, ld, q0, T, tid, rq);
     tile_load<HD>(dobase, d, q0, T, tid, rdo);
-    if (tid < KT) rl = (q0 + tid < T) ? lse_b[q0 + tid] : 0.f;
+    if (tid < KT) rl = (q0 + tid < T) ? lse_b[q0 + tid] * LOG2E : 0.f;
     else if (tid < 2 * KT) rl = (q0 + tid - KT < T) ? D_b[q0 + tid - KT] : 0.f;
   };
   int qt = next_tile(0);
@@ -480,38 +485,42 @@ __global__ __launch_bounds__(NT) void attn_bwd_dkv_kernel(const bf16_t* __restri
     const int qn = next_tile(qt + 1);
     if (qn < nqt) prefetch(qn);
 
-    // S = Q . K^T and dP = dO . V^T : rows = queries (two 32-query tiles), lane column = own key
-    f32x16 s[2], dp[2];
+    // S = Q . K^T and dP = dO . V^T : rows = queries, lane column = own key; one 32-query sub-tile at a time
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
+      f32x16 st, dpt;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { s[t][r] = 0.f; dp[t][r] = 0.f; }
+      for (int r = 0; r < 16; ++r) { st[r] = 0.f; dpt[r] = 0.f; }
 #pragma unroll
       for (int ks = 0; ks < C::KS; ++ks) {
-        s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_nat<HD>(ldsQ, t * 32, ks, lane), kf[ks], s[t], 0, 0, 0);
-        dp[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_nat<HD>(ldsdO, t * 32, ks, lane), vf[ks], dp[t], 0, 0, 0);
+        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_nat<HD>(ldsQ, t * 32, ks, lane), kf[ks], st, 0, 0, 0);
+        dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_nat<HD>(ldsdO, t * 32, ks, lane), vf[ks], dpt, 0, 0, 0);
       }
-    }
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
+      const int lim_causal = q0 + t * 32 + 4 * (lane >> 5) - key;    // key <= query  <=>  -c(r) <= lim_causal
+      const int lim_len = T - 1 - q0 - t * 32 - 4 * (lane >> 5);     // query < T     <=>   c(r) <= lim_len
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int ql = t * 32 + acc_row(r, lane);
-        const int qq = q0 + ql;
-        const bool causal_ok = key <= qq;
-        const float sv = (causal_ok ? s[t][r] * scale : MASK_VAL) + my_kb;
-        const float pv = (qq < T && kvalid) ? __expf(sv - ldsLse[ql]) : 0.f;
-        s[t][r] = pv;                                              // P   (for dV)
-        dp[t][r] = causal_ok ? pv * (dp[t][r] - ldsD[ql]) : 0.f;  // dS  (for dK)
+        const int c = (r & 3) + 8 * (r >> 2);
+        const int ql = t * 32 + c + 4 * (lane >> 5);
+        const bool causal_ok = (-c) <= lim_causal;
+        const float sv = (causal_ok ? st[r] * scale2 : MASK_VAL * LOG2E) + my_kb;
+        const float pv = (c <= lim_len && kvalid) ? exp2_fast(sv - ldsLse[ql]) : 0.f;
+        st[r] = pv;                                              // P   (for dV)
+        dpt[r] = causal_ok ? pv * (dpt[r] - ldsD[ql]) : 0.f;     // dS  (for dK)
       }
 #pragma unroll
-    for (int sp = 0; sp < 4; ++sp) {
-      const bf16x8_v pf = frag_from_acc(s, sp);
-      const bf16x8_v df = frag_from_acc(dp, sp);
+      for (int h2 = 0; h2 < 2; ++h2) {
+        const uint4 wp = make_uint4(pack_bf16x2(st[8 * h2 + 0], st[8 * h2 + 1]), pack_bf16x2(st[8 * h2 + 2], st[8 * h2 + 3]),
+                                    pack_bf16x2(st[8 * h2 + 4], st[8 * h2 + 5]), pack_bf16x2(st[8 * h2 + 6], st[8 * h2 + 7]));
+        const uint4 wd = make_uint4(pack_bf16x2(dpt[8 * h2 + 0], dpt[8 * h2 + 1]), pack_bf16x2(dpt[8 * h2 + 2], dpt[8 * h2 + 3]),
+                                    pack_bf16x2(dpt[8 * h2 + 4], dpt[8 * h2 + 5]), pack_bf16x2(dpt[8 * h2 + 6], dpt[8 * h2 + 7]));
+        const bf16x8_v pf = __builtin_bit_cast(bf16x8_v, wp);
+        const bf16x8_v df = __builtin_bit_cast(bf16x8_v, wd);
 #pragma unroll
-      for (int i = 0; i < C::IB; ++i) {
-        dv[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(ldsdOt, i * 32, sp, lane), pf, dv[i], 0, 0, 0);
-        dk[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(ldsQt, i * 32, sp, lane), df, dk[i], 0, 0, 0);
+        for (int i = 0; i < C::IB; ++i) {
+          dv[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(ldsdOt, i * 32, 2 * t + h2, lane), pf, dv[i], 0, 0, 0);
+          dk[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(ldsQt, i * 32, 2 * t + h2, lane), df, dk[i], 0, 0, 0);
+        }
       }
     }
     qt = qn;

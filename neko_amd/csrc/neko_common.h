@@ -27,14 +27,18 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 __device__ __forceinline__ float bf16_to_f32(bf16_t h) {
   return __uint_as_float(((uint32_t)h) << 16);
 }
-__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // quiet NaN
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
-}
+// gfx950 has a hardware packed conversion (round-to-nearest-even, NaN-preserving); hipcc lowers a plain
+// float->bf16 cast to a ~6-instruction software sequence with a divergent NaN branch, so it is issued explicitly.
+// A 2-wide vector convert is what selects v_cvt_pk_bf16_f32 (a scalar cast does not); unlike inline asm the
+// compiler then also inserts the VALU->MFMA operand wait states when the result feeds an MFMA directly.
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+  typedef float f32x2_v __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2_v __attribute__((ext_vector_type(2)));
+  const f32x2_v v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_v));
+}
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  return (bf16_t)(pack_bf16x2(f, 0.0f) & 0xffffu);
 }
 
 // ---- wave64 reductions ---------------------------------------------------------------------

@@ -1,0 +1,105 @@
+"""TrainingArgs -- the flag names and defaults of gato/training/arguments.py:20-138 that concern the hot path
+(the flag names are API surface).  Dataset / environment / W&B / LoRA flags of the reference
+are accepted and ignored by the synthetic-data `train.py` (their subsystems are out of scope).
+A small argparse front-end is generated from the dataclass (the reference's 423-line HF-style parser is not
+re-implemented)."""
+from __future__ import annotations
+
+import argparse
+import dataclasses
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+
+@dataclass
+class TrainingArgs:
+    cpu: bool = False
+    device: str = "cuda"
+    mixed_precision: str = "bf16"          # the HIP path is always bf16-operand / fp32-accumulate
+
+    # input & tokenization
+    sequence_length: int = 1024
+    patch_size: int = 16
+    resid_mid_channels: int = 128
+    num_groups: int = 32
+    patch_position_vocab_size: int = 128
+    disable_patch_pos_encoding: bool = False
+    disable_inner_pos_encoding: bool = False
+    mu: int = 100
+    M: int = 256
+    continuous_tokens: int = 1024
+    discrete_tokens: int = 1024
+
+    # architecture
+    tokenizer_model_name: str = "gpt2"
+    pretrained_lm: Optional[str] = None
+    flash: bool = False
+    init_checkpoint: Optional[str] = None
+    embed_dim: int = 768
+    layers: int = 8
+    heads: int = 24
+    activation_fn: str = "gelu"
+
+    # training
+    text_prop: float = 0.0
+    caption_prop: float = 0.0
+    vqa_prop: float = 0.0
+    gradient_accumulation_steps: int = 1
+    batch_size: int = 512
+    dropout: float = 0.1
+    beta_1: float = 0.9
+    beta_2: float = 0.95
+    adam_eps: float = 1e-8
+    weight_decay: float = 0.1
+    grad_norm_clip: float = 1.0
+    disable_grad_clip: bool = False
+    warmup_steps: int = 15000
+    init_lr: float = 1e-7
+    learning_rate: float = 1e-4
+    min_factor: float = 10.0
+    disable_cosine_decay: bool = False
+    training_steps: int = 1_000_000
+    log_eval_freq: int = 100_000
+    pad_seq: bool = False
+
+    # evaluation (kept for CLI compatibility; rollouts are out of scope)
+    eval_episodes: int = 10
+    eval_mode: str = "deterministic"
+    promptless_eval: bool = False
+
+    # datasets (synthetic stand-ins: names select the synthetic generator shapes)
+    control_datasets: List[str] = field(default_factory=list)
+    text_datasets: List[str] = field(default_factory=list)
+    caption_dataset: str = ""
+
+    # logging / saving
+    use_wandb: bool = False
+    wandb_project: str = "gato-control"
+    save_model: bool = False
+    save_mode: str = "last"
+    save_dir: str = "models"
+
+    # neko_amd extras
+    text_vocab_size: int = 50257           # used when the gpt2 tokenizer cannot be downloaded
+    seed: int = 1234
+
+
+def build_parser() -> argparse.ArgumentParser:
+    p = argparse.ArgumentParser(description="neko_amd train.py (flag names of ManifoldRG/NEKO's train.py)")
+    for f in dataclasses.fields(TrainingArgs):
+        name = "--" + f.name
+        default = f.default if f.default is not dataclasses.MISSING else f.default_factory()
+        if f.type in ("bool", bool):
+            p.add_argument(name, action="store_true", default=default)
+        elif str(f.type).startswith("List"):
+            p.add_argument(name, nargs="+", default=default)
+        elif "Optional" in str(f.type):
+            p.add_argument(name, default=default)
+        else:
+            p.add_argument(name, type=type(default), default=default)
+    return p
+
+
+def parse_args(argv=None) -> TrainingArgs:
+    ns = build_parser().parse_args(argv)
+    return TrainingArgs(**vars(ns))

@@ -216,6 +216,38 @@ def main():
                        "warmup": warm, "total_steps": total_steps, "min_lr": lr / 10.0,
                        "trace": trace, "final_small_params": final_sd}
 
+    # ---- G7b: 100 steps in the regime of the metric's recipe (arguments.py defaults: lr 1e-4, warm-up from
+    # 1e-7, betas .9/.95, wd .1, clip 1.0) on the d=128 / 3 layers / hd=32 geometry, text + control batches.
+    # This is the trace the "loss within 1e-3 rel over 100 steps" gate is held on; G7 above (lr 3e-3 on a
+    # 64-d model, loss 7.8 -> 0.2 in 100 steps) is chaotic and only checked for tracking.
+    cfg3 = O.OracleConfig(embed_dim=128, layers=3, heads=4, text_tokens=TEXT_VOCAB, context_len=128)
+    m8, _ = build_reference(GP, cfg3, 999)
+    m8.train()
+    lr8, init8, warm8, total8 = 1e-4, 1e-7, 20, 100
+    opt8 = torch.optim.AdamW(m8.parameters(), lr=lr8, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.1)
+    sch8 = get_linear_warmup_cosine_decay_scheduler(opt8, warm8, total8, base_lr=lr8, init_lr=init8, min_lr=lr8 / 10.0)
+    g = torch.Generator().manual_seed(8)
+    batches8 = []
+    for i in range(5):
+        b = []
+        for j in range(4):
+            if (i + j) % 2 == 0:
+                b.append({"text": torch.randint(0, TEXT_VOCAB, (100 + 3 * j,), generator=g).tolist()})
+            else:
+                b.append({"continuous_obs": torch.randn(5, 11, generator=g), "continuous_actions": torch.rand(5, 3, generator=g) * 2 - 1})
+        batches8.append(b)
+    tr8 = {"loss": [], "grad_norm": [], "lr": []}
+    for step in range(total8):
+        tr8["lr"].append(sch8.get_last_lr()[0])
+        _, loss = m8.forward(inputs=batches8[step % len(batches8)], compute_loss=True)
+        loss.backward()
+        gnorm = torch.nn.utils.clip_grad_norm_(m8.parameters(), 1.0)
+        opt8.step(); sch8.step(); opt8.zero_grad()
+        tr8["loss"].append(loss.item()); tr8["grad_norm"].append(float(gnorm))
+    out["g7b_trace"] = {"cfg": cfg3.__dict__, "seed": 999, "batches": batches8, "lr": lr8, "init_lr": init8,
+                        "warmup": warm8, "total_steps": total8, "min_lr": lr8 / 10.0, "trace": tr8}
+    print("g7b loss head:", tr8["loss"][:3], "tail:", tr8["loss"][-3:])
+
     for name, obj in out.items():
         path = os.path.join(HERE, name + ".pt")
         torch.save(obj, path)

@@ -89,6 +89,20 @@ def test_g6_policy_logits_loss_grads(golden):
     assert grads["transformer.wte.weight"] is None   # never receives a grad
 
 
+def test_g7b_training_trace_reference_recipe(golden):
+    f = golden("g7b_trace")
+    cfg = _cfg(f["cfg"])
+    sd = O.init_state_dict(cfg, f["seed"])
+    st = O.AdamWState(lr=f["lr"])
+    tr = f["trace"]
+    for step in range(f["total_steps"]):
+        lr = f["lr"] * O.lr_ratio(step, f["warmup"], f["total_steps"], f["lr"], f["init_lr"], f["min_lr"])
+        assert abs(lr - tr["lr"][step]) < 1e-12 + 1e-9 * lr
+        loss, gn = O.train_step(sd, cfg, st, f["batches"][step % len(f["batches"])], lr, 1.0)
+        assert abs(loss - tr["loss"][step]) < 1e-4 * abs(tr["loss"][step]), (step, loss, tr["loss"][step])
+        assert abs(gn - tr["grad_norm"][step]) < 1e-3 * tr["grad_norm"][step], (step, gn)
+
+
 def test_g7_training_trace(golden):
     f = golden("g7_trace")
     cfg = _cfg(f["cfg"])

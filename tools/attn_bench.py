@@ -1,0 +1,56 @@
+#!/usr/bin/env python
+"""Isolated timing of the attention kernels at the metric shape (B=32, T=1024, H=24, hd=32) or --hd/--H/--T.
+    python tools/attn_bench.py [--iters 20] [--pad 0]
+Useful FLOPs (causal half): fwd 4*T^2/2*hd per (b,h); bwd 2.5x fwd (flash convention)."""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from neko_amd import ops  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--B", type=int, default=32)
+    ap.add_argument("--T", type=int, default=1024)
+    ap.add_argument("--H", type=int, default=24)
+    ap.add_argument("--hd", type=int, default=32)
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--pad", type=int, default=0, help="left padding of every sequence")
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    B, T, H, hd = a.B, a.T, a.H, a.hd
+    d = H * hd
+    dev = "cuda"
+    qkv = (torch.randn(B * T, 3 * d, device=dev)).to(torch.bfloat16)
+    do = torch.randn(B * T, d, device=dev).to(torch.bfloat16)
+    mask = torch.ones(B, T, device=dev)
+    if a.pad:
+        mask[:, :a.pad] = 0
+    kb, ks = ops.mask_bias(mask)
+    out, lse = ops.attn_fwd(qkv, kb, ks, B, T, H, hd)
+    fl = 4.0 * T * T / 2 * hd * H * B
+
+    def timeit(fn, name, flops):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(a.iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / a.iters
+        print(f"{name:10s} {us:9.1f} us  {flops / us / 1e6:7.1f} TFLOP/s (useful, causal)")
+
+    if "bwd" not in a.only:
+        timeit(lambda: ops.attn_fwd(qkv, kb, ks, B, T, H, hd), "attn fwd", fl)
+    if "fwd" not in a.only:
+        timeit(lambda: ops.attn_bwd(qkv, out, do, kb, ks, lse, B, T, H, hd), "attn bwd", 2.5 * fl)
+
+
+if __name__ == "__main__":
+    main()
