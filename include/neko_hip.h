@@ -33,7 +33,7 @@ extern "C" {
 #define NEKO_ERR_UNSUPPORTED (-2)
 #define NEKO_ERR_LAUNCH (-3)
 
-#define NEKO_ABI_VERSION 2
+#define NEKO_ABI_VERSION 3
 
 int neko_abi_version(void);
 /* human-readable text for a return code (static storage) */
@@ -56,6 +56,8 @@ const char* neko_status_string(int code);
  *   splitk > 1: K is cut in `splitk` slices of k_per_split (multiple of 64).  With splitk_ws (f32
  *   [splitk*M*N], N % 4 == 0) the slices are written to the workspace and summed in a fixed order into Cf
  *   (bit-reproducible); with splitk_ws == NULL they meet in f32 atomics on Cf.  act must be 0, Cb null.
+ *   drop_thr != 0: residual dropout (resid_dropout / MLP dropout, trajectory_gpt2.py:253-254,277-278) applied to
+ *   (alpha*acc + bias [act]) before the residual add; see "Dropout" below for (thr, key, scale).
  *   Contract: contiguous extents and leading dims are multiples of 8 elements.
  *   safe_transpose != 0 selects the transposing-store fallback for k-strided operands (debug).
  * ------------------------------------------------------------------------------------------- */
@@ -64,25 +66,27 @@ int neko_gemm_bf16(const uint16_t* A, long lda, int a_kstrided, const uint16_t* 
                    long ldr, int act,
                    const uint16_t* act_in, long ldact, uint16_t* pre_out, long ldpre, float* Cf, long ldcf,
                    int accumulate, uint16_t* Cb, long ldcb, int splitk, int k_per_split, float* splitk_ws,
-                   int safe_transpose, void* stream);
+                   int drop_thr, unsigned drop_key, float drop_scale, int safe_transpose, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * LayerNorm -- nn.LayerNorm(d, eps) ln_1 / ln_2 / ln_f (trajectory_gpt2.py:301,303,323,353,543,779).
  * fwd: x f32 [M,d] -> y16 (bf16, may be null) and/or y32 (f32, may be null); mean/rstd f32 [M] (may be null).
  * bwd: dy f32 [M,d]; g_in (may be null) is the residual-stream gradient added to the result;
  *      dx f32 and/or dx16 bf16 (either may be null); dgamma/dbeta f32 [d] (+= when accumulate);
- *      workspace: neko_layernorm_bwd_blocks(M) * 2 * d floats.
+ *      workspace: neko_layernorm_bwd_blocks(M) * 2 * d floats.  drop_thr != 0: dx16 (only) additionally carries the
+ *      dropout mask of the residual-dropout site whose Linear consumes it (element index row*d + col).
  * ------------------------------------------------------------------------------------------- */
 int neko_layernorm_fwd(const float* x, const float* gamma, const float* beta, uint16_t* y16, float* y32,
                        float* mean, float* rstd, int M, int d, float eps, void* stream);
 int neko_layernorm_bwd_blocks(int M);
 int neko_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                        const float* g_in, float* dx, uint16_t* dx16, float* dgamma, float* dbeta, int accumulate,
-                       float* workspace, int M, int d, void* stream);
+                       float* workspace, int M, int d, int drop_thr, unsigned drop_key, float drop_scale, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Attention -- Attention._attn + split_heads/merge_heads (trajectory_gpt2.py:163-201,222-226,252)
- * with the mask preparation of GPT2Model.forward (:663-679).  Dropout p = 0 (attn_pdrop path: see DESIGN.md).
+ * with the mask preparation of GPT2Model.forward (:663-679); attn_dropout (:142,179) via (drop_thr, drop_key,
+ * drop_scale) on the probabilities, element index ((b*H+h)*T+q)*T+key (mod 2^32), normaliser undropped.
  *   neko_mask_bias: mask f32 [B,T] (1 real, 0 pad) -> kbias f32 [B,T] = (1-mask)*-1e4 and
  *                   kstart int32 [B] = index of the first real key (may be null).
  *   qkv  bf16 [B*T, 3*H*hd]  (q | k | v, head h at columns h*hd..) as produced by c_attn
@@ -92,10 +96,10 @@ int neko_layernorm_bwd(const float* dy, const float* x, const float* gamma, cons
  * ------------------------------------------------------------------------------------------- */
 int neko_mask_bias(const float* mask, float* kbias, int* kstart, int B, int T, void* stream);
 int neko_attn_fwd(const uint16_t* qkv, const float* kbias, const int* kstart, uint16_t* out, float* lse, int B,
-                  int T, int H, int hd, void* stream);
+                  int T, int H, int hd, int drop_thr, unsigned drop_key, float drop_scale, void* stream);
 int neko_attn_bwd(const uint16_t* qkv, const uint16_t* out, const uint16_t* dout, const float* kbias,
                   const int* kstart, const float* lse, float* D, int* qflags, uint16_t* dqkv, int B, int T, int H,
-                  int hd, void* stream);
+                  int hd, int drop_thr, unsigned drop_key, float drop_scale, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Masked cross-entropy over a chunk of logits -- gato_policy.py:174-186 (shift, mask product,
@@ -139,6 +143,11 @@ int neko_tokenize_continuous(const float* x, int* ids, long n, int use_mu_law, f
  *                        range (bias correction); *active == 0 (may be null) skips the range the way
  *                        torch skips parameters whose grad is None; p16 (may be null) gets bf16(p).
  * ------------------------------------------------------------------------------------------- */
+/* Dropout (nn.Dropout sites of the path: embd :541,707; attention :179; residual :254,278).  Counter-based:
+ * element idx is kept iff top byte of hash(idx ^ key) >= thr with thr = round(p*256) in [0,255] (0 = off), survivors
+ * scaled by scale = 256/(256-thr); forward and backward regenerate the same mask from (idx, key), no mask tensor.
+ * neko_dropout_f32: y = keep ? x*scale : 0 on a flat fp32 array (embedding dropout and its backward). */
+int neko_dropout_f32(const float* x, float* y, long n, int thr, unsigned key, float scale, void* stream);
 int neko_cast_f32_bf16(const float* x, uint16_t* y, long n, void* stream);
 /* loss-position selection (gato_policy.py:183-185): dst[r,:] = r < n ? src[idx[r],:] : 0 (bf16 rows, d % 8 == 0);
  * and its adjoint dst[idx[r],:] = src[r,:] (f32 rows, dst pre-zeroed, idx unique). */

@@ -16,15 +16,16 @@ _vp, _i, _l, _f = C.c_void_p, C.c_int, C.c_long, C.c_float
 #: name -> argtypes, exactly the prototypes of include/neko_hip.h
 SIGNATURES = {
     "neko_gemm_bf16": [_vp, _l, _i, _vp, _l, _i, _i, _i, _i, _f, _vp, _vp, _vp, _l, _i, _vp, _l, _vp, _l,
-                       _vp, _l, _i, _vp, _l, _i, _i, _vp, _i, _vp],
+                       _vp, _l, _i, _vp, _l, _i, _i, _vp, _i, C.c_uint, _f, _i, _vp],
+    "neko_dropout_f32": [_vp, _vp, _l, _i, C.c_uint, _f, _vp],
     "neko_gather_rows_bf16": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "neko_scatter_rows_f32": [_vp, _vp, _vp, _i, _i, _vp],
     "neko_layernorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp],
     "neko_layernorm_bwd_blocks": [_i],
-    "neko_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _vp],
+    "neko_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, C.c_uint, _f, _vp],
     "neko_mask_bias": [_vp, _vp, _vp, _i, _i, _vp],
-    "neko_attn_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
-    "neko_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "neko_attn_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, C.c_uint, _f, _vp],
+    "neko_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, C.c_uint, _f, _vp],
     "neko_ce_fwd_bwd": [_vp, _l, _i, _i, _vp, _vp, _vp, _vp, _l, _i, _vp],
     "neko_pack_embed_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _i, _i, _i, _vp],
     "neko_pack_embed_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],

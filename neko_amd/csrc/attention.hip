@@ -118,7 +118,8 @@ __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (
 template <int HD>
 __global__ __launch_bounds__(NT, (HD <= 32 ? 4 : (HD <= 64 ? 3 : 2))) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ kbias,
                                                       const int* __restrict__ kstart, bf16_t* __restrict__ out,
-                                                      float* __restrict__ lse, int B, int T, int H, float scale) {
+                                                      float* __restrict__ lse, int B, int T, int H, float scale,
+                                                      uint32_t drop_thr, uint32_t drop_key, float drop_scale) {
   using C = Cfg<HD>;
   __shared__ __attribute__((aligned(16))) char smem[C::NAT_BYTES + C::TR_BYTES + KT * 4 + 16];
   char* ldsK = smem;
@@ -222,6 +223,13 @@ __global__ __launch_bounds__(NT, (HD <= 32 ? 4 : (HD <= 64 ? 3 : 2))) void attn_
       }
       l_run = fmaf(l_run, alpha, ps0 + ps1);
       m_run = m_new;
+      if (drop_thr) {   // attn_dropout on the probabilities (trajectory_gpt2.py:179): the normaliser stays undropped
+        const uint32_t base = (((uint32_t)(b * H + h) * (uint32_t)T + (uint32_t)q) * (uint32_t)T) +
+                              (uint32_t)(k0 + t * 32 + 4 * (lane >> 5));
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          st[r] = drop_keep(base + (uint32_t)((r & 3) + 8 * (r >> 2)), drop_key, drop_thr) ? st[r] * drop_scale : 0.f;
+      }
 #pragma unroll
       for (int i = 0; i < C::IB; ++i)
 #pragma unroll
@@ -298,7 +306,8 @@ template <int HD>
 __global__ __launch_bounds__(NT, (HD <= 32 ? 4 : (HD <= 64 ? 2 : 1))) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                          const float* __restrict__ kbias, const int* __restrict__ kstart,
                                                          const float* __restrict__ lse, const float* __restrict__ Dv,
-                                                         bf16_t* __restrict__ dqkv, int B, int T, int H, float scale) {
+                                                         bf16_t* __restrict__ dqkv, int B, int T, int H, float scale,
+                                                         uint32_t drop_thr, uint32_t drop_key, float drop_scale) {
   using C = Cfg<HD>;
   __shared__ __attribute__((aligned(16))) char smem[2 * C::NAT_BYTES + C::TR_BYTES + KT * 4 + 16];
   char* ldsK = smem;
@@ -374,13 +383,17 @@ __global__ __launch_bounds__(NT, (HD <= 32 ? 4 : (HD <= 64 ? 2 : 1))) void attn_
       // dS^T = P^T o (dP^T - D); zero where the score was REPLACED by the causal constant
       const int lim_causal = q - k0 - t * 32 - 4 * (lane >> 5);
       const int lim_len = T - 1 - k0 - t * 32 - 4 * (lane >> 5);
+      const uint32_t dbase = (((uint32_t)(b * H + h) * (uint32_t)T + (uint32_t)q) * (uint32_t)T) +
+                             (uint32_t)(k0 + t * 32 + 4 * (lane >> 5));
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int c = (r & 3) + 8 * (r >> 2);
         const bool causal_ok = c <= lim_causal;
         const float sv = fmaf(ldsKb[t * 32 + c + 4 * (lane >> 5)], LOG2E, causal_ok ? st[r] * scale2 : MASK_VAL * LOG2E);
         const float pv = (c <= lim_len) ? exp2_fast(sv - my_lse) : 0.f;
-        st[r] = causal_ok ? pv * (dpt[r] - my_D) : 0.f;
+        float dpe = dpt[r];
+        if (drop_thr) dpe = drop_keep(dbase + (uint32_t)c, drop_key, drop_thr) ? dpe * drop_scale : 0.f;
+        st[r] = causal_ok ? pv * (dpe - my_D) : 0.f;
       }
       // dQ^T += K^T . dS^T
 #pragma unroll
@@ -416,7 +429,8 @@ template <int HD>
 __global__ __launch_bounds__(NT, (HD <= 32 ? 3 : (HD <= 64 ? 2 : 1))) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                           const float* __restrict__ kbias, const float* __restrict__ lse,
                                                           const float* __restrict__ Dv, const int* __restrict__ qflags,
-                                                          bf16_t* __restrict__ dqkv, int B, int T, int H, float scale) {
+                                                          bf16_t* __restrict__ dqkv, int B, int T, int H, float scale,
+                                                          uint32_t drop_thr, uint32_t drop_key, float drop_scale) {
   using C = Cfg<HD>;
   __shared__ __attribute__((aligned(16))) char smem[2 * C::NAT_BYTES + 2 * C::TR_BYTES + 2 * KT * 4];
   char* ldsQ = smem;
@@ -498,6 +512,8 @@ __global__ __launch_bounds__(NT, (HD <= 32 ? 3 : (HD <= 64 ? 2 : 1))) void attn_
       }
       const int lim_causal = q0 + t * 32 + 4 * (lane >> 5) - key;    // key <= query  <=>  -c(r) <= lim_causal
       const int lim_len = T - 1 - q0 - t * 32 - 4 * (lane >> 5);     // query < T     <=>   c(r) <= lim_len
+      const uint32_t dbase = (((uint32_t)(b * H + h) * (uint32_t)T + (uint32_t)(q0 + t * 32 + 4 * (lane >> 5))) * (uint32_t)T) +
+                             (uint32_t)key;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int c = (r & 3) + 8 * (r >> 2);
@@ -505,8 +521,14 @@ __global__ __launch_bounds__(NT, (HD <= 32 ? 3 : (HD <= 64 ? 2 : 1))) void attn_
         const bool causal_ok = (-c) <= lim_causal;
         const float sv = (causal_ok ? st[r] * scale2 : MASK_VAL * LOG2E) + my_kb;
         const float pv = (c <= lim_len && kvalid) ? exp2_fast(sv - ldsLse[ql]) : 0.f;
-        st[r] = pv;                                              // P   (for dV)
-        dpt[r] = causal_ok ? pv * (dpt[r] - ldsD[ql]) : 0.f;     // dS  (for dK)
+        float pd = pv, dpe = dpt[r];
+        if (drop_thr) {
+          const bool keep = drop_keep(dbase + (uint32_t)c * (uint32_t)T, drop_key, drop_thr);
+          pd = keep ? pv * drop_scale : 0.f;
+          dpe = keep ? dpe * drop_scale : 0.f;
+        }
+        st[r] = pd;                                              // dropped P (for dV)
+        dpt[r] = causal_ok ? pv * (dpe - ldsD[ql]) : 0.f;        // dS        (for dK)
       }
 #pragma unroll
       for (int h2 = 0; h2 < 2; ++h2) {
@@ -546,16 +568,18 @@ __global__ __launch_bounds__(NT, (HD <= 32 ? 3 : (HD <= 64 ? 2 : 1))) void attn_
 
 template <int HD>
 int fwd_launch(const bf16_t* qkv, const float* kbias, const int* kstart, bf16_t* out, float* lse, int B, int T, int H,
-               hipStream_t s) {
+               int thr, unsigned key, float dscale, hipStream_t s) {
   const float scale = 1.0f / sqrtf((float)HD);
   dim3 grid((T + 127) / 128, H, B);
-  hipLaunchKernelGGL((attn_fwd_kernel<HD>), grid, dim3(NT), 0, s, qkv, kbias, kstart, out, lse, B, T, H, scale);
+  hipLaunchKernelGGL((attn_fwd_kernel<HD>), grid, dim3(NT), 0, s, qkv, kbias, kstart, out, lse, B, T, H, scale,
+                     (uint32_t)thr, key, dscale);
   NEKO_CHECK_LAUNCH();
   return NEKO_OK;
 }
 template <int HD>
 int bwd_launch(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const float* kbias, const int* kstart,
-               const float* lse, float* D, int* qflags, bf16_t* dqkv, int B, int T, int H, hipStream_t s) {
+               const float* lse, float* D, int* qflags, bf16_t* dqkv, int B, int T, int H, int thr, unsigned key,
+               float dscale, hipStream_t s) {
   const float scale = 1.0f / sqrtf((float)HD);
   const long total = (long)B * T * H;
   hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, out, dout, kbias, D,
@@ -563,10 +587,10 @@ int bwd_launch(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const f
   NEKO_CHECK_LAUNCH();
   dim3 grid((T + 127) / 128, H, B);
   hipLaunchKernelGGL((attn_bwd_dq_kernel<HD>), grid, dim3(NT), 0, s, qkv, dout, kbias, kstart, lse, D, dqkv, B, T, H,
-                     scale);
+                     scale, (uint32_t)thr, key, dscale);
   NEKO_CHECK_LAUNCH();
   hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD>), grid, dim3(NT), 0, s, qkv, dout, kbias, lse, D, qflags, dqkv, B, T, H,
-                     scale);
+                     scale, (uint32_t)thr, key, dscale);
   NEKO_CHECK_LAUNCH();
   return NEKO_OK;
 }
@@ -574,13 +598,13 @@ int bwd_launch(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const f
 }  // namespace
 
 int neko_attn_fwd_impl(const bf16_t* qkv, const float* kbias, const int* kstart, bf16_t* out, float* lse, int B, int T,
-                       int H, int hd, hipStream_t s) {
+                       int H, int hd, int drop_thr, unsigned drop_key, float drop_scale, hipStream_t s) {
   if (B <= 0 || T <= 0) return NEKO_OK;
-  if (!qkv || !kbias || !out || !lse || H <= 0) return NEKO_ERR_ARG;
+  if (!qkv || !kbias || !out || !lse || H <= 0 || drop_thr < 0 || drop_thr > 255) return NEKO_ERR_ARG;
   switch (hd) {
-    case 32: return fwd_launch<32>(qkv, kbias, kstart, out, lse, B, T, H, s);
-    case 64: return fwd_launch<64>(qkv, kbias, kstart, out, lse, B, T, H, s);
-    case 128: return fwd_launch<128>(qkv, kbias, kstart, out, lse, B, T, H, s);
+    case 32: return fwd_launch<32>(qkv, kbias, kstart, out, lse, B, T, H, drop_thr, drop_key, drop_scale, s);
+    case 64: return fwd_launch<64>(qkv, kbias, kstart, out, lse, B, T, H, drop_thr, drop_key, drop_scale, s);
+    case 128: return fwd_launch<128>(qkv, kbias, kstart, out, lse, B, T, H, drop_thr, drop_key, drop_scale, s);
     default: return NEKO_ERR_UNSUPPORTED;
   }
 }
@@ -588,13 +612,16 @@ int neko_attn_fwd_impl(const bf16_t* qkv, const float* kbias, const int* kstart,
 // workspace: D fp32 [B*H*T] and qflags int32 [B*ceil(T/64)]
 int neko_attn_bwd_impl(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const float* kbias, const int* kstart,
                        const float* lse, float* D, int* qflags, bf16_t* dqkv, int B, int T, int H, int hd,
-                       hipStream_t s) {
+                       int drop_thr, unsigned drop_key, float drop_scale, hipStream_t s) {
   if (B <= 0 || T <= 0) return NEKO_OK;
   if (!qkv || !out || !dout || !kbias || !lse || !D || !qflags || !dqkv || H <= 0) return NEKO_ERR_ARG;
   switch (hd) {
-    case 32: return bwd_launch<32>(qkv, out, dout, kbias, kstart, lse, D, qflags, dqkv, B, T, H, s);
-    case 64: return bwd_launch<64>(qkv, out, dout, kbias, kstart, lse, D, qflags, dqkv, B, T, H, s);
-    case 128: return bwd_launch<128>(qkv, out, dout, kbias, kstart, lse, D, qflags, dqkv, B, T, H, s);
+    case 32: return bwd_launch<32>(qkv, out, dout, kbias, kstart, lse, D, qflags, dqkv, B, T, H, drop_thr, drop_key,
+                                   drop_scale, s);
+    case 64: return bwd_launch<64>(qkv, out, dout, kbias, kstart, lse, D, qflags, dqkv, B, T, H, drop_thr, drop_key,
+                                   drop_scale, s);
+    case 128: return bwd_launch<128>(qkv, out, dout, kbias, kstart, lse, D, qflags, dqkv, B, T, H, drop_thr, drop_key,
+                                   drop_scale, s);
     default: return NEKO_ERR_UNSUPPORTED;
   }
 }

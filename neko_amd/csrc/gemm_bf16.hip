@@ -220,6 +220,7 @@ __global__ __launch_bounds__(NT) void gemm_bf16_kernel(GemmArgs p) {
         } else if (p.act == 2) {
           v *= gelu_grad_f(bf16_to_f32(p.act_in[(long)row * p.ldact + col]));
         }
+        if (p.drop_thr) v = drop_keep((uint32_t)row * (uint32_t)p.N + (uint32_t)col, p.drop_key, p.drop_thr) ? v * p.drop_scale : 0.f;
         if (p.resid && lead) v += p.resid[(long)row * p.ldr + col];
         if (Cf_out) {
           float* dst = Cf_out + (long)row * ldcf_out + col;

@@ -243,6 +243,11 @@ __global__ __launch_bounds__(NT, 2) void gemm_glds_kernel(GemmArgs p) {
         for (int e = 0; e < nv; ++e) v[e] *= gelu_grad_f(bf16_to_f32(src[e]));
       }
     }
+    if (p.drop_thr) {
+      const uint32_t base = (uint32_t)row * (uint32_t)p.N + (uint32_t)col;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = drop_keep(base + e, p.drop_key, p.drop_thr) ? v[e] * p.drop_scale : 0.f;
+    }
     if (p.resid && lead) {
       const float* rs = p.resid + (long)row * p.ldr + col;
       if (r_vec) {

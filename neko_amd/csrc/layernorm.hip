@@ -77,7 +77,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const float* __restrict__ g_in,
                                                      float* __restrict__ dx, bf16_t* __restrict__ dx16,
-                                                     float* __restrict__ part, int M, int d) {
+                                                     float* __restrict__ part, int M, int d, uint32_t drop_thr,
+                                                     uint32_t drop_key, float drop_scale) {
   extern __shared__ __attribute__((aligned(16))) float lds[];  // [4][2][d]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nvec = d >> 2;
@@ -132,6 +133,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
         }
         if (dx) reinterpret_cast<float4*>(dx + (long)row * d)[c] = o;
         if (dx16) {
+          // the bf16 copy feeds the dgrad/wgrad of the Linear that sits behind a residual dropout: it carries that
+          // site's mask (the fp32 residual-stream gradient above does not)
+          if (drop_thr) {
+            const uint32_t base = (uint32_t)row * (uint32_t)d + (uint32_t)c * 4u;
+            o.x = drop_keep(base, drop_key, drop_thr) ? o.x * drop_scale : 0.f;
+            o.y = drop_keep(base + 1, drop_key, drop_thr) ? o.y * drop_scale : 0.f;
+            o.z = drop_keep(base + 2, drop_key, drop_thr) ? o.z * drop_scale : 0.f;
+            o.w = drop_keep(base + 3, drop_key, drop_thr) ? o.w * drop_scale : 0.f;
+          }
           uint2 pk;
           pk.x = pack_bf16x2(o.x, o.y);
           pk.y = pack_bf16x2(o.z, o.w);
@@ -200,9 +210,10 @@ int fwd_launch(const float* x, const float* g, const float* b, bf16_t* y16, floa
 }
 template <int NV>
 int bwd_launch(const float* dy, const float* x, const float* g, const float* mean, const float* rstd,
-               const float* g_in, float* dx, bf16_t* dx16, float* part, int nblk, int M, int d, hipStream_t s) {
+               const float* g_in, float* dx, bf16_t* dx16, float* part, int nblk, int M, int d, int thr, unsigned key,
+               float scale, hipStream_t s) {
   hipLaunchKernelGGL((ln_bwd_kernel<NV>), dim3(nblk), dim3(256), (size_t)8 * d * sizeof(float), s, dy, x, g, mean,
-                     rstd, g_in, dx, dx16, part, M, d);
+                     rstd, g_in, dx, dx16, part, M, d, (uint32_t)thr, key, scale);
   NEKO_CHECK_LAUNCH();
   return NEKO_OK;
 }
@@ -231,19 +242,20 @@ int neko_layernorm_bwd_blocks_impl(int M) {
 
 int neko_layernorm_bwd_impl(const float* dy, const float* x, const float* gamma, const float* mean,
                             const float* rstd, const float* g_in, float* dx, bf16_t* dx16, float* dgamma,
-                            float* dbeta, int accumulate, float* workspace, int M, int d, hipStream_t s) {
+                            float* dbeta, int accumulate, float* workspace, int M, int d, int drop_thr,
+                            unsigned drop_key, float drop_scale, hipStream_t s) {
   if (M <= 0) return NEKO_OK;
   if (!dy || !x || !gamma || !mean || !rstd || !workspace || !dgamma || !dbeta) return NEKO_ERR_ARG;
   if ((d & 3) || d > 256 * LN_MAXV) return NEKO_ERR_UNSUPPORTED;
   const int nblk = neko_layernorm_bwd_blocks_impl(M);
   const int nv = (d / 4 + 63) / 64;
   int rc;
-  if (nv <= 1) rc = bwd_launch<1>(dy, x, gamma, mean, rstd, g_in, dx, dx16, workspace, nblk, M, d, s);
-  else if (nv <= 2) rc = bwd_launch<2>(dy, x, gamma, mean, rstd, g_in, dx, dx16, workspace, nblk, M, d, s);
-  else if (nv <= 3) rc = bwd_launch<3>(dy, x, gamma, mean, rstd, g_in, dx, dx16, workspace, nblk, M, d, s);
-  else if (nv <= 4) rc = bwd_launch<4>(dy, x, gamma, mean, rstd, g_in, dx, dx16, workspace, nblk, M, d, s);
-  else if (nv <= 8) rc = bwd_launch<8>(dy, x, gamma, mean, rstd, g_in, dx, dx16, workspace, nblk, M, d, s);
-  else rc = bwd_launch<16>(dy, x, gamma, mean, rstd, g_in, dx, dx16, workspace, nblk, M, d, s);
+  if (nv <= 1) rc = bwd_launch<1>(dy, x, gamma, mean, rstd, g_in, dx, dx16, workspace, nblk, M, d, drop_thr, drop_key, drop_scale, s);
+  else if (nv <= 2) rc = bwd_launch<2>(dy, x, gamma, mean, rstd, g_in, dx, dx16, workspace, nblk, M, d, drop_thr, drop_key, drop_scale, s);
+  else if (nv <= 3) rc = bwd_launch<3>(dy, x, gamma, mean, rstd, g_in, dx, dx16, workspace, nblk, M, d, drop_thr, drop_key, drop_scale, s);
+  else if (nv <= 4) rc = bwd_launch<4>(dy, x, gamma, mean, rstd, g_in, dx, dx16, workspace, nblk, M, d, drop_thr, drop_key, drop_scale, s);
+  else if (nv <= 8) rc = bwd_launch<8>(dy, x, gamma, mean, rstd, g_in, dx, dx16, workspace, nblk, M, d, drop_thr, drop_key, drop_scale, s);
+  else rc = bwd_launch<16>(dy, x, gamma, mean, rstd, g_in, dx, dx16, workspace, nblk, M, d, drop_thr, drop_key, drop_scale, s);
   if (rc != NEKO_OK) return rc;
   hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * d + 63) / 64), dim3(256), 0, s, workspace, nblk, d, dgamma,
                      dbeta, accumulate);

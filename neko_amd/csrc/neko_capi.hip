@@ -21,9 +21,10 @@ int neko_gemm_bf16(const uint16_t* A, long lda, int a_kstrided, const uint16_t* 
                    int N, int K, float alpha, const float* alpha_dev, const float* bias, const float* resid, long ldr, int act,
                    const uint16_t* act_in, long ldact, uint16_t* pre_out, long ldpre, float* Cf, long ldcf,
                    int accumulate, uint16_t* Cb, long ldcb, int splitk, int k_per_split, float* splitk_ws,
-                   int safe_transpose, void* stream) {
+                   int drop_thr, unsigned drop_key, float drop_scale, int safe_transpose, void* stream) {
   GemmArgs a{A, B, lda, ldb, M, N, K, alpha, alpha_dev, bias, resid, ldr, act_in, ldact, pre_out, ldpre, act,
-             Cf, ldcf, accumulate, Cb, ldcb, splitk, k_per_split, splitk_ws};
+             Cf, ldcf, accumulate, Cb, ldcb, splitk, k_per_split, splitk_ws, drop_thr, drop_key, drop_scale};
+  if (drop_thr < 0 || drop_thr > 255) return NEKO_ERR_ARG;
   return neko_gemm_bf16_full(a, a_kstrided, b_kstrided, safe_transpose, S(stream));
 }
 
@@ -34,22 +35,24 @@ int neko_layernorm_fwd(const float* x, const float* gamma, const float* beta, ui
 int neko_layernorm_bwd_blocks(int M) { return neko_layernorm_bwd_blocks_impl(M); }
 int neko_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                        const float* g_in, float* dx, uint16_t* dx16, float* dgamma, float* dbeta, int accumulate,
-                       float* workspace, int M, int d, void* stream) {
+                       float* workspace, int M, int d, int drop_thr, unsigned drop_key, float drop_scale, void* stream) {
+  if (drop_thr < 0 || drop_thr > 255) return NEKO_ERR_ARG;
   return neko_layernorm_bwd_impl(dy, x, gamma, mean, rstd, g_in, dx, dx16, dgamma, dbeta, accumulate, workspace, M, d,
-                                 S(stream));
+                                 drop_thr, drop_key, drop_scale, S(stream));
 }
 
 int neko_mask_bias(const float* mask, float* kbias, int* kstart, int B, int T, void* stream) {
   return neko_mask_bias_impl(mask, kbias, kstart, B, T, S(stream));
 }
 int neko_attn_fwd(const uint16_t* qkv, const float* kbias, const int* kstart, uint16_t* out, float* lse, int B, int T,
-                  int H, int hd, void* stream) {
-  return neko_attn_fwd_impl(qkv, kbias, kstart, out, lse, B, T, H, hd, S(stream));
+                  int H, int hd, int drop_thr, unsigned drop_key, float drop_scale, void* stream) {
+  return neko_attn_fwd_impl(qkv, kbias, kstart, out, lse, B, T, H, hd, drop_thr, drop_key, drop_scale, S(stream));
 }
 int neko_attn_bwd(const uint16_t* qkv, const uint16_t* out, const uint16_t* dout, const float* kbias,
                   const int* kstart, const float* lse, float* D, int* qflags, uint16_t* dqkv, int B, int T, int H,
-                  int hd, void* stream) {
-  return neko_attn_bwd_impl(qkv, out, dout, kbias, kstart, lse, D, qflags, dqkv, B, T, H, hd, S(stream));
+                  int hd, int drop_thr, unsigned drop_key, float drop_scale, void* stream) {
+  return neko_attn_bwd_impl(qkv, out, dout, kbias, kstart, lse, D, qflags, dqkv, B, T, H, hd, drop_thr, drop_key, drop_scale,
+                            S(stream));
 }
 
 int neko_ce_fwd_bwd(const float* logits, long ldl, int V, int Vpad, const long long* target, const float* weight,
@@ -78,6 +81,9 @@ int neko_gather_rows_bf16(const uint16_t* src, const int* idx, uint16_t* dst, in
 }
 int neko_scatter_rows_f32(const float* src, const int* idx, float* dst, int n, int d, void* stream) {
   return neko_scatter_rows_f32_impl(src, idx, dst, n, d, S(stream));
+}
+int neko_dropout_f32(const float* x, float* y, long n, int thr, unsigned key, float scale, void* stream) {
+  return neko_dropout_f32_impl(x, y, n, thr, key, scale, S(stream));
 }
 int neko_cast_f32_bf16(const float* x, uint16_t* y, long n, void* stream) {
   return neko_cast_f32_bf16_impl(x, y, n, S(stream));

@@ -80,6 +80,17 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
   return fmaf(x * 0.39894228040143267794f, e, 0.5f * (1.0f + er));
 }
 
+// ---- dropout: counter-based keep decision (no mask tensor; forward and backward regenerate it) -----------------
+// keep(idx) <=> top byte of a 2-multiply hash of (idx ^ site key) >= thr, thr = round(p*256): the drop rate is
+// quantised to 1/256 (p = 0.1 -> 26/256) and the survivors are scaled by 256/(256-thr), so E[out] = in exactly.
+// The site key (per layer / site / step) is mixed on the host.  7 VALU ops per element.
+__device__ __forceinline__ bool drop_keep(uint32_t idx, uint32_t key, uint32_t thr) {
+  uint32_t h = (idx ^ key) * 0x9E3779B1u;
+  h ^= h >> 15;
+  h *= 0x85EBCA77u;
+  return (h >> 24) >= thr;
+}
+
 // XCD-aware bijective block remap (8 XCDs, block b runs on XCD b%8): give every XCD a
 // contiguous range of logical tile ids so neighbouring tiles share an L2.
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {

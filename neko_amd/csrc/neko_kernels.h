@@ -25,6 +25,9 @@ struct GemmArgs {
   int splitk;             // >1: each grid.y slice handles k_per_split of K, atomicAdd into Cf
   int k_per_split;        // multiple of 64
   float* splitk_ws;       // optional [splitk, M, N] f32 workspace: slices reduced in fixed order (no atomics)
+  int drop_thr;           // residual dropout on (acc*alpha + bias [act]) before the residual add: 0 = off, else round(p*256)
+  unsigned drop_key;      // site key (element index = row*N + col)
+  float drop_scale;       // 256/(256-thr)
 };
 
 int neko_gemm_bf16_impl(GemmArgs a, int a_kstrided, int b_kstrided, int safe_transpose, hipStream_t s);
@@ -38,12 +41,14 @@ int neko_layernorm_fwd_impl(const float* x, const float* gamma, const float* bet
 int neko_layernorm_bwd_blocks_impl(int M);
 int neko_layernorm_bwd_impl(const float* dy, const float* x, const float* gamma, const float* mean,
                             const float* rstd, const float* g_in, float* dx, bf16_t* dx16, float* dgamma,
-                            float* dbeta, int accumulate, float* workspace, int M, int d, hipStream_t s);
+                            float* dbeta, int accumulate, float* workspace, int M, int d, int drop_thr,
+                            unsigned drop_key, float drop_scale, hipStream_t s);
+int neko_dropout_f32_impl(const float* x, float* y, long n, int thr, unsigned key, float scale, hipStream_t s);
 int neko_attn_fwd_impl(const bf16_t* qkv, const float* kbias, const int* kstart, bf16_t* out, float* lse, int B, int T,
-                       int H, int hd, hipStream_t s);
+                       int H, int hd, int drop_thr, unsigned drop_key, float drop_scale, hipStream_t s);
 int neko_attn_bwd_impl(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const float* kbias, const int* kstart,
                        const float* lse, float* D, int* qflags, bf16_t* dqkv, int B, int T, int H, int hd,
-                       hipStream_t s);
+                       int drop_thr, unsigned drop_key, float drop_scale, hipStream_t s);
 int neko_ce_fwd_bwd_impl(const float* logits, long ldl, int V, int Vpad, const long long* target, const float* weight,
                          float* loss_row, bf16_t* dlogits, long ldd, int R, hipStream_t s);
 int neko_pack_embed_fwd_impl(const int* desc, const float* cont_vals, const int* disc_vals, const float* img_emb,

@@ -51,6 +51,16 @@ class HeadParams:
 
 
 @dataclass
+class DropSites:
+    """Dropout sites of one forward pass (None entries = off): embedding dropout, and per layer the attention-
+    probability dropout and the two residual dropouts (trajectory_gpt2.py:541,707 / :142,179 / :143,254 / :271,278)."""
+    embd: Optional[ops.Drop]
+    attn: List[Optional[ops.Drop]]
+    resid_attn: List[Optional[ops.Drop]]
+    resid_mlp: List[Optional[ops.Drop]]
+
+
+@dataclass
 class LayerCtx:
     x: torch.Tensor = None; a1: torch.Tensor = None; mean1: torch.Tensor = None; rstd1: torch.Tensor = None
     qkv: torch.Tensor = None; o: torch.Tensor = None; lse: torch.Tensor = None
@@ -65,6 +75,7 @@ class StackCtx:
     kbias: torch.Tensor = None
     kstart: torch.Tensor = None
     layers: List[LayerCtx] = field(default_factory=list)
+    drops: Optional[DropSites] = None
     xf: torch.Tensor = None          # residual stream entering ln_f
     meanf: torch.Tensor = None
     rstdf: torch.Tensor = None
@@ -80,7 +91,7 @@ def _wgrad(A: torch.Tensor, Bm: torch.Tensor, Mout: int, N: int, K: int, out: to
 
 
 def stack_forward(P: StackParams, x: torch.Tensor, mask: torch.Tensor, save: bool,
-                  want_f32: bool = False, want_bf16: bool = True):
+                  want_f32: bool = False, want_bf16: bool = True, drops: Optional[DropSites] = None):
     """x (B,T,d) fp32 residual stream, mask (B,T) fp32 0/1.  Returns (hf16 [M,d] bf16 | None,
     hf32 [M,d] fp32 | None, ctx | None) where hf = ln_f(h_L)."""
     B, T, d = x.shape
@@ -90,17 +101,21 @@ def stack_forward(P: StackParams, x: torch.Tensor, mask: torch.Tensor, save: boo
     dev = x.device
     x = x.reshape(M, d).contiguous()
     kbias, kstart = ops.mask_bias(mask.to(F32))
-    ctx = StackCtx(B=B, T=T, kbias=kbias, kstart=kstart) if save else None
-    for lp in P.layers:
+    ctx = StackCtx(B=B, T=T, kbias=kbias, kstart=kstart, drops=drops) if save else None
+    dr = drops
+    if dr is not None and dr.embd is not None:
+        x = ops.dropout_f32(x, dr.embd)                       # embedding dropout (:707)
+    for li, lp in enumerate(P.layers):
         a1 = torch.empty(M, d, dtype=BF16, device=dev)
         mean1 = torch.empty(M, dtype=F32, device=dev)
         rstd1 = torch.empty(M, dtype=F32, device=dev)
         ops.layernorm_fwd(x, lp.ln1_w, lp.ln1_b, y16=a1, mean=mean1, rstd=rstd1, eps=P.eps)
         qkv = torch.empty(M, 3 * d, dtype=BF16, device=dev)
         ops.gemm(a1, lp.w_qkv, M, 3 * d, d, b_kstrided=True, bias=lp.b_qkv, out_bf16=qkv)
-        o, lse = ops.attn_fwd(qkv, kbias, kstart, B, T, H, hd)
+        o, lse = ops.attn_fwd(qkv, kbias, kstart, B, T, H, hd, drop=dr.attn[li] if dr else None)
         x1 = torch.empty(M, d, dtype=F32, device=dev)
-        ops.gemm(o, lp.w_o, M, d, d, b_kstrided=True, bias=lp.b_o, resid=x, out_f32=x1)
+        ops.gemm(o, lp.w_o, M, d, d, b_kstrided=True, bias=lp.b_o, resid=x, out_f32=x1,
+                 drop=dr.resid_attn[li] if dr else None)
         a2 = torch.empty(M, d, dtype=BF16, device=dev)
         mean2 = torch.empty(M, dtype=F32, device=dev)
         rstd2 = torch.empty(M, dtype=F32, device=dev)
@@ -109,7 +124,8 @@ def stack_forward(P: StackParams, x: torch.Tensor, mask: torch.Tensor, save: boo
         h = torch.empty(M, 4 * d, dtype=BF16, device=dev)
         ops.gemm(a2, lp.w_fc, M, 4 * d, d, b_kstrided=True, bias=lp.b_fc, act=1, pre_out=pre, out_bf16=h)
         x2 = torch.empty(M, d, dtype=F32, device=dev)
-        ops.gemm(h, lp.w_pr, M, d, 4 * d, b_kstrided=True, bias=lp.b_pr, resid=x1, out_f32=x2)
+        ops.gemm(h, lp.w_pr, M, d, 4 * d, b_kstrided=True, bias=lp.b_pr, resid=x1, out_f32=x2,
+                 drop=dr.resid_mlp[li] if dr else None)
         if save:
             ctx.layers.append(LayerCtx(x=x, a1=a1, mean1=mean1, rstd1=rstd1, qkv=qkv, o=o, lse=lse, x1=x1, a2=a2,
                                        mean2=mean2, rstd2=rstd2, pre=pre, h=h))
@@ -137,7 +153,12 @@ def stack_backward(P: StackParams, ctx: StackCtx, dhf: torch.Tensor,
     dev = dhf.device
     g = torch.empty(M, d, dtype=F32, device=dev)
     g16 = torch.empty(M, d, dtype=BF16, device=dev)
-    ops.layernorm_bwd(dhf, ctx.xf, P.lnf_w, ctx.meanf, ctx.rstdf, P.g_lnf_w, P.g_lnf_b, g_in=None, dx=g, dx16=g16)
+    dr = ctx.drops
+    L = len(P.layers)
+    # the bf16 gradient copy that enters layer i from above is consumed by its MLP c_proj: it carries that
+    # site's residual-dropout mask; the fp32 residual-stream gradient never does
+    ops.layernorm_bwd(dhf, ctx.xf, P.lnf_w, ctx.meanf, ctx.rstdf, P.g_lnf_w, P.g_lnf_b, g_in=None, dx=g, dx16=g16,
+                      drop=dr.resid_mlp[L - 1] if dr else None)
     if on_layer_done:
         on_layer_done(len(P.layers))
     for i in range(len(P.layers) - 1, -1, -1):
@@ -153,23 +174,27 @@ def stack_backward(P: StackParams, ctx: StackCtx, dhf: torch.Tensor,
         ops.colsum_bf16(d_pre, M, 4 * d, lp.g_b_fc)
         g1 = torch.empty(M, d, dtype=F32, device=dev)
         g1_16 = torch.empty(M, d, dtype=BF16, device=dev)
-        ops.layernorm_bwd(d_a2, c.x1, lp.ln2_w, c.mean2, c.rstd2, lp.g_ln2_w, lp.g_ln2_b, g_in=g, dx=g1, dx16=g1_16)
+        ops.layernorm_bwd(d_a2, c.x1, lp.ln2_w, c.mean2, c.rstd2, lp.g_ln2_w, lp.g_ln2_b, g_in=g, dx=g1, dx16=g1_16,
+                          drop=dr.resid_attn[i] if dr else None)
         # ---- attention: x1 = x + attn(a1 Wqkv + bqkv) Wo + bo -----------------------------------------
         d_o = torch.empty(M, d, dtype=BF16, device=dev)
         ops.gemm(g1_16, lp.w_o, M, d, d, ldb=d, out_bf16=d_o)
         _wgrad(c.o, g1_16, d, d, M, lp.g_w_o)
         ops.colsum_bf16(g1_16, M, d, lp.g_b_o)
-        dqkv = ops.attn_bwd(c.qkv, c.o, d_o, ctx.kbias, ctx.kstart, c.lse, B, T, H, hd)
+        dqkv = ops.attn_bwd(c.qkv, c.o, d_o, ctx.kbias, ctx.kstart, c.lse, B, T, H, hd, drop=dr.attn[i] if dr else None)
         d_a1 = torch.empty(M, d, dtype=F32, device=dev)
         ops.gemm(dqkv, lp.w_qkv, M, d, 3 * d, ldb=3 * d, out_f32=d_a1)
         _wgrad(c.a1, dqkv, d, 3 * d, M, lp.g_w_qkv)
         ops.colsum_bf16(dqkv, M, 3 * d, lp.g_b_qkv)
         g0 = torch.empty(M, d, dtype=F32, device=dev)
         g0_16 = torch.empty(M, d, dtype=BF16, device=dev) if i > 0 else None
-        ops.layernorm_bwd(d_a1, c.x, lp.ln1_w, c.mean1, c.rstd1, lp.g_ln1_w, lp.g_ln1_b, g_in=g1, dx=g0, dx16=g0_16)
+        ops.layernorm_bwd(d_a1, c.x, lp.ln1_w, c.mean1, c.rstd1, lp.g_ln1_w, lp.g_ln1_b, g_in=g1, dx=g0, dx16=g0_16,
+                          drop=dr.resid_mlp[i - 1] if (dr and i > 0) else None)
         g, g16 = g0, g0_16
         if on_layer_done:
             on_layer_done(i)
+    if dr is not None and dr.embd is not None:
+        g = ops.dropout_f32(g, dr.embd)                       # backward of the embedding dropout: same mask
     return g
 
 

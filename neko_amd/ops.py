@@ -31,6 +31,37 @@ def _chk(t: torch.Tensor, dtype, name: str):
     assert t.dtype == dtype, f"{name} must be {dtype}, got {t.dtype}"
 
 
+class Drop:
+    """One dropout site: thr = round(p*256) (0 = off), key = 32-bit site key, scale = 256/(256-thr)."""
+    __slots__ = ("thr", "key", "scale")
+
+    def __init__(self, p: float, key: int):
+        self.thr = max(0, min(255, int(round(p * 256))))
+        self.key = key & 0xFFFFFFFF
+        self.scale = 256.0 / (256 - self.thr)
+
+
+def _drop(d):
+    return (0, 0, 1.0) if (d is None or d.thr == 0) else (d.thr, d.key, d.scale)
+
+
+def mix32(x: int) -> int:
+    """Host-side 32-bit mixer (lowbias32) used to derive per-site dropout keys from (seed, step, site)."""
+    x &= 0xFFFFFFFF
+    x ^= x >> 16; x = (x * 0x7FEB352D) & 0xFFFFFFFF
+    x ^= x >> 15; x = (x * 0x846CA68B) & 0xFFFFFFFF
+    x ^= x >> 16
+    return x
+
+
+def dropout_f32(x, drop, out=None):
+    _chk(x, torch.float32, "x")
+    x = x.contiguous()
+    y = torch.empty_like(x) if out is None else out
+    _lib.call("neko_dropout_f32", _p(x), _p(y), x.numel(), *_drop(drop), _stream())
+    return y
+
+
 def pick_splitk(M: int, N: int, K: int, target_blocks: int = 512) -> tuple:
     """Split-K factor for skinny-output / long-K GEMMs (wgrad): enough blocks to fill 256 CUs."""
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
@@ -51,7 +82,7 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, a_kstrided
          pre_out: Optional[torch.Tensor] = None, out_f32: Optional[torch.Tensor] = None, ldcf: Optional[int] = None,
          accumulate: bool = False, out_bf16: Optional[torch.Tensor] = None, ldcb: Optional[int] = None,
          splitk: int = 1, k_per_split: int = 0, safe_transpose: Optional[int] = None,
-         deterministic_splitk: bool = True) -> None:
+         deterministic_splitk: bool = True, drop=None) -> None:
     """C[M,N] = alpha * opA(A) @ opB(B) (+bias)(act)(+resid)(+C).  See neko_gemm_bf16 in include/neko_hip.h."""
     _chk(A, BF16, "A"); _chk(B, BF16, "B")
     if lda is None:
@@ -84,7 +115,7 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, a_kstrided
         ws = torch.empty(splitk * M * N, dtype=torch.float32, device=A.device)
     _lib.call("neko_gemm_bf16", _p(A), lda, int(a_kstrided), _p(B), ldb, int(b_kstrided), M, N, K, float(alpha),
               _p(alpha_dev), _p(bias), _p(resid), ldr, act, _p(act_in), ldact, _p(pre_out), ldpre, _p(out_f32),
-              ldcf or 0, int(accumulate), _p(out_bf16), ldcb or 0, splitk, k_per_split, _p(ws), st, _stream())
+              ldcf or 0, int(accumulate), _p(out_bf16), ldcb or 0, splitk, k_per_split, _p(ws), *_drop(drop), st, _stream())
 
 
 def layernorm_fwd(x, gamma, beta, y16=None, y32=None, mean=None, rstd=None, eps: float = 1e-5):
@@ -95,13 +126,13 @@ def layernorm_fwd(x, gamma, beta, y16=None, y32=None, mean=None, rstd=None, eps:
               float(eps), _stream())
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, g_in=None, dx=None, dx16=None, accumulate=True):
+def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, g_in=None, dx=None, dx16=None, accumulate=True, drop=None):
     _chk(dy, torch.float32, "dy")
     M, d = x.shape[0], x.shape[1]
     nblk = _lib.load().neko_layernorm_bwd_blocks(M)
     ws = torch.empty(nblk * 2 * d, dtype=torch.float32, device=x.device)
     _lib.call("neko_layernorm_bwd", _p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(g_in), _p(dx), _p(dx16),
-              _p(dgamma), _p(dbeta), int(accumulate), _p(ws), M, d, _stream())
+              _p(dgamma), _p(dbeta), int(accumulate), _p(ws), M, d, *_drop(drop), _stream())
 
 
 def mask_bias(mask: torch.Tensor):
@@ -115,22 +146,22 @@ def mask_bias(mask: torch.Tensor):
     return kb, ks
 
 
-def attn_fwd(qkv, kbias, kstart, B, T, H, hd):
+def attn_fwd(qkv, kbias, kstart, B, T, H, hd, drop=None):
     _chk(qkv, BF16, "qkv")
     out = torch.empty(B * T, H * hd, dtype=BF16, device=qkv.device)
     lse = torch.empty(B, H, T, dtype=torch.float32, device=qkv.device)
-    _lib.call("neko_attn_fwd", _p(qkv), _p(kbias), _p(kstart), _p(out), _p(lse), B, T, H, hd, _stream())
+    _lib.call("neko_attn_fwd", _p(qkv), _p(kbias), _p(kstart), _p(out), _p(lse), B, T, H, hd, *_drop(drop), _stream())
     return out, lse
 
 
-def attn_bwd(qkv, out, dout, kbias, kstart, lse, B, T, H, hd):
+def attn_bwd(qkv, out, dout, kbias, kstart, lse, B, T, H, hd, drop=None):
     _chk(dout, BF16, "dout")
     dev = qkv.device
     D = torch.empty(B * H * T, dtype=torch.float32, device=dev)
     qflags = torch.empty(B * ((T + 63) // 64), dtype=torch.int32, device=dev)
     dqkv = torch.empty(B * T, 3 * H * hd, dtype=BF16, device=dev)
     _lib.call("neko_attn_bwd", _p(qkv), _p(out), _p(dout), _p(kbias), _p(kstart), _p(lse), _p(D), _p(qflags),
-              _p(dqkv), B, T, H, hd, _stream())
+              _p(dqkv), B, T, H, hd, *_drop(drop), _stream())
     return dqkv
 
 

@@ -172,7 +172,8 @@ class _PolicyCoreFn(torch.autograd.Function):
         f.ensure_shadow()
         B, T, d = x.shape
         sp = policy.transformer._stack_params()
-        hf16, _, sctx = engine.stack_forward(sp, x.detach().to(torch.float32), pmask, save=need)
+        hf16, _, sctx = engine.stack_forward(sp, x.detach().to(torch.float32), pmask, save=need,
+                                             drops=policy.transformer.make_drops())
         hp = policy._head_params()
         logits = engine.lm_head_logits(hp, hf16).view(B, T, hp.V) if return_logits else x.new_zeros(0)
         loss = x.new_zeros(())
@@ -430,7 +431,6 @@ class GatoPolicy(nn.Module):
             token_masks = kwargs["token_masks"]
         if not token_embeddings.is_cuda:
             raise RuntimeError("neko_amd.GatoPolicy computes on the GPU only (no CPU fallback)")
-        self.transformer.check_dropout()
         if compute_loss:
             assert tokens is not None and token_target_masks is not None, "compute_loss needs tokens and target masks"
         names = self.transformer._param_names() + ["predict_token.weight"]

@@ -111,7 +111,7 @@ class _TransformerFn(torch.autograd.Function):
         need = any(ctx.needs_input_grad)   # grad mode is off inside Function.forward
         model._flat.ensure_shadow()
         _, hf32, sctx = engine.stack_forward(model._stack_params(), x.detach().to(torch.float32), mask, save=need,
-                                             want_f32=True, want_bf16=False)
+                                             want_f32=True, want_bf16=False, drops=model.make_drops())
         ctx.model, ctx.sctx = model, sctx
         return hf32.view(x.shape)
 
@@ -207,14 +207,27 @@ class GPT2Model(nn.Module):
             g_lnf_w=f.gview(pre + "ln_f.weight"), g_lnf_b=f.gview(pre + "ln_f.bias"))
         return self._sp
 
-    def check_dropout(self) -> None:
-        if self.training:
-            ps = [self.drop.p] + [b.attn.attn_dropout.p for b in self.h] + [b.attn.resid_dropout.p for b in self.h]
-            if any(p > 0 for p in ps):
-                raise NotImplementedError(
-                    "dropout > 0 in training mode is not implemented on the HIP path yet: construct the policy "
-                    "with dropout=0 and set model.transformer.drop.p = 0 (the reference keeps embd_pdrop=0.1 "
-                    "regardless of --dropout, SURVEY.md 2.2 row 0)")
+    def make_drops(self):
+        """Dropout sites for one training-mode forward (None in eval mode or when every p is 0).  Keys are derived
+        from (torch.initial_seed(), rank, a per-model forward counter, site id): masks differ per step / site / rank
+        and are regenerated, not stored.  The rates are the nn.Dropout modules' p, like the reference reads them
+        (embd_pdrop stays 0.1 unless transformer.drop.p is changed)."""
+        if not self.training:
+            return None
+        ps = [self.drop.p] + [b.attn.attn_dropout.p for b in self.h] + [b.attn.resid_dropout.p for b in self.h] + \
+             [b.mlp.dropout.p for b in self.h]
+        if not any(p > 0 for p in ps):
+            return None
+        from .. import ops
+        rank = torch.distributed.get_rank() if torch.distributed.is_initialized() else 0
+        self._drop_step = getattr(self, "_drop_step", 0) + 1
+        base = ops.mix32((torch.initial_seed() & 0xFFFFFFFF) ^ ops.mix32(self._drop_step) ^ ops.mix32(0x51ED270B + rank))
+        mk = lambda p, site: (ops.Drop(p, ops.mix32(base + site * 0x9E3779B9)) if p > 0 else None)
+        return engine.DropSites(
+            embd=mk(self.drop.p, 0),
+            attn=[mk(b.attn.attn_dropout.p, 1 + 3 * i) for i, b in enumerate(self.h)],
+            resid_attn=[mk(b.attn.resid_dropout.p, 2 + 3 * i) for i, b in enumerate(self.h)],
+            resid_mlp=[mk(b.mlp.dropout.p, 3 + 3 * i) for i, b in enumerate(self.h)])
 
     # ---- reference call signature (trajectory_gpt2.py:611-795) ------------------------------------
     def forward(self, input_ids=None, past_key_values=None, attention_mask=None, token_type_ids=None,
@@ -234,7 +247,6 @@ class GPT2Model(nn.Module):
             raise NotImplementedError("output_attentions / output_hidden_states are not materialised by the fused kernels")
         if not inputs_embeds.is_cuda:
             raise RuntimeError("neko_amd.GPT2Model runs on the GPU only (no CPU fallback)")
-        self.check_dropout()
         B, T, _ = inputs_embeds.shape
         if attention_mask is None:
             attention_mask = torch.ones(B, T, dtype=torch.float32, device=inputs_embeds.device)

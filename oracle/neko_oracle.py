@@ -288,7 +288,8 @@ def conv1d(x: Tensor, w: Tensor, b: Tensor, bf16: bool = False) -> Tensor:
     return y.view(shp)
 
 
-def attention_core(q: Tensor, k: Tensor, v: Tensor, pad_mask: Tensor, bf16: bool = False) -> Tensor:
+def attention_core(q: Tensor, k: Tensor, v: Tensor, pad_mask: Tensor, bf16: bool = False,
+                   drop_mask: Optional[Tensor] = None) -> Tensor:
     """trajectory_gpt2.py:163-188 (_attn) + :663-679 (mask prep), dropout 0.
     q,k,v: (B,H,T,hd); pad_mask (B,T) 1=real 0=pad.
     w = q k^T / sqrt(hd); causal: where(tril, w, -1e4) (REPLACE); padding: w += (1-mask)*-1e4 (ADD);
@@ -299,6 +300,8 @@ def attention_core(q: Tensor, k: Tensor, v: Tensor, pad_mask: Tensor, bf16: bool
     w = torch.where(tril, w, torch.tensor(-1e4, dtype=w.dtype))
     w = w + ((1.0 - pad_mask.to(w.dtype)) * -10000.0)[:, None, None, :]
     w = torch.softmax(w, dim=-1)
+    if drop_mask is not None:          # attn_dropout (:179): explicit multiplicative mask (0 or 1/(1-p))
+        w = w * drop_mask
     return torch.matmul(_rb(w, bf16), v)
 
 
@@ -308,9 +311,12 @@ def gelu(x: Tensor) -> Tensor:
 
 
 def block_forward(sd: Dict[str, Tensor], cfg: OracleConfig, i: int, x: Tensor, pad_mask: Tensor,
-                  bf16: bool = False) -> Tensor:
+                  bf16: bool = False, drop_masks: Optional[dict] = None) -> Tensor:
     """trajectory_gpt2.py:311-359 (Block.forward) with Attention.forward :203-257 and
-    MLP.forward :273-278, dropout 0, no cross-attention, no cache."""
+    MLP.forward :273-278, no cross-attention, no cache.  Dropout is either off or given as explicit multiplicative
+    masks drop_masks[('attn', i)] (B,H,T,T), [('resid_attn', i)] / [('resid_mlp', i)] (B,T,d) -- the nn.Dropout sites
+    :179, :254, :278 -- so a counter-based kernel mask can be reproduced exactly."""
+    dm = drop_masks or {}
     p = f"transformer.h.{i}."
     d, H = cfg.embed_dim, cfg.heads
     B, T, _ = x.shape
@@ -318,25 +324,33 @@ def block_forward(sd: Dict[str, Tensor], cfg: OracleConfig, i: int, x: Tensor, p
     qkv = _rb(conv1d(a, sd[p + "attn.c_attn.weight"], sd[p + "attn.c_attn.bias"], bf16), bf16)
     q, k, v = qkv.split(d, dim=2)                                          # :222
     sh = lambda t: t.view(B, T, H, d // H).permute(0, 2, 1, 3)             # :195-201
-    o = attention_core(sh(q), sh(k), sh(v), pad_mask, bf16)
+    o = attention_core(sh(q), sh(k), sh(v), pad_mask, bf16, dm.get(("attn", i)))
     o = _rb(o.permute(0, 2, 1, 3).reshape(B, T, d), bf16)                  # :190-193
-    x = x + conv1d(o, sd[p + "attn.c_proj.weight"], sd[p + "attn.c_proj.bias"], bf16)   # :253,333
+    ao = conv1d(o, sd[p + "attn.c_proj.weight"], sd[p + "attn.c_proj.bias"], bf16)       # :253
+    if ("resid_attn", i) in dm:
+        ao = ao * dm[("resid_attn", i)]                                                   # :254
+    x = x + ao                                                                             # :333
     a2 = F.layer_norm(x, (d,), sd[p + "ln_2.weight"], sd[p + "ln_2.bias"], cfg.layer_norm_eps)
     pre = _rb(conv1d(a2, sd[p + "mlp.c_fc.weight"], sd[p + "mlp.c_fc.bias"], bf16), bf16)
     h = _rb(gelu(pre), bf16)                                               # :274
     if cfg.activation_fn == "geglu":                                       # :275-276
         h = h * F.linear(a2, sd[p + "mlp.gated_layer.weight"], sd[p + "mlp.gated_layer.bias"])
-    x = x + conv1d(h, sd[p + "mlp.c_proj.weight"], sd[p + "mlp.c_proj.bias"], bf16)     # :277,355
+    mo = conv1d(h, sd[p + "mlp.c_proj.weight"], sd[p + "mlp.c_proj.bias"], bf16)         # :277
+    if ("resid_mlp", i) in dm:
+        mo = mo * dm[("resid_mlp", i)]                                                    # :278
+    x = x + mo                                                                             # :355
     return x
 
 
 def transformer_forward(sd: Dict[str, Tensor], cfg: OracleConfig, x: Tensor, pad_mask: Tensor,
-                        bf16: bool = False, return_all: bool = False):
+                        bf16: bool = False, return_all: bool = False, drop_masks: Optional[dict] = None):
     """GPT2Model.forward (trajectory_gpt2.py:611-795) for inputs_embeds + attention_mask:
     no position embedding (:700-701), embedding dropout 0, L blocks, ln_f (:779)."""
+    if drop_masks and "embd" in drop_masks:            # embedding dropout (:707)
+        x = x * drop_masks["embd"]
     hs = [x]
     for i in range(cfg.layers):
-        x = block_forward(sd, cfg, i, x, pad_mask, bf16)
+        x = block_forward(sd, cfg, i, x, pad_mask, bf16, drop_masks)
         hs.append(x)
     out = F.layer_norm(x, (cfg.embed_dim,), sd["transformer.ln_f.weight"],
                        sd["transformer.ln_f.bias"], cfg.layer_norm_eps)
@@ -367,9 +381,9 @@ def masked_cross_entropy(logits: Tensor, tokens: Tensor, target_masks: Tensor, p
 
 def policy_forward(sd: Dict[str, Tensor], cfg: OracleConfig, emb: Tensor, tokens: Tensor,
                    target_masks: Tensor, pad_masks: Tensor, compute_loss: bool = True,
-                   bf16: bool = False):
+                   bf16: bool = False, drop_masks: Optional[dict] = None):
     """GatoPolicy.forward from the packed batch on (gato_policy.py:167-192)."""
-    hidden = transformer_forward(sd, cfg, emb, pad_masks, bf16)
+    hidden = transformer_forward(sd, cfg, emb, pad_masks, bf16, drop_masks=drop_masks)
     logits = lm_head(sd, hidden, bf16)
     loss = masked_cross_entropy(logits, tokens, target_masks, pad_masks) if compute_loss else None
     return logits, loss
@@ -451,7 +465,7 @@ def adamw_step(sd: Dict[str, Tensor], grads: Dict[str, Optional[Tensor]], st: Ad
 
 
 def loss_and_grads(sd: Dict[str, Tensor], cfg: OracleConfig, inputs=None, packed=None,
-                   patch_positions=None, bf16: bool = False):
+                   patch_positions=None, bf16: bool = False, drop_masks: Optional[dict] = None):
     """loss + dict of grads (None where the parameter did not take part, e.g. transformer.wte
     and, on image-free batches, image_embedding.*) -- autograd over the oracle functions."""
     keys = trainable_keys(sd)
@@ -462,7 +476,7 @@ def loss_and_grads(sd: Dict[str, Tensor], cfg: OracleConfig, inputs=None, packed
         emb, tok, tgt, msk = tokenize_input_dicts(full, cfg, inputs, patch_positions, bf16)
     else:
         emb, tok, tgt, msk = packed
-    logits, loss = policy_forward(full, cfg, emb, tok, tgt, msk, True, bf16)
+    logits, loss = policy_forward(full, cfg, emb, tok, tgt, msk, True, bf16, drop_masks)
     gl = torch.autograd.grad(loss, [leaf[k] for k in keys], allow_unused=True)
     return loss.detach(), logits.detach(), {k: g for k, g in zip(keys, gl)}
 

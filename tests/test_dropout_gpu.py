@@ -1,0 +1,147 @@
+"""Dropout on the HIP path (embedding / attention-probability / residual sites).  Bit-wise parity with torch's
+RNG is impossible, so the counter-based mask is re-derived on the host (numpy restatement of
+drop_keep in neko_common.h) and handed to the oracle as explicit multiplicative masks: kernels and wiring are then
+checked exactly like the dropout-free path, forward AND backward."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import neko_oracle as O  # noqa: E402
+
+DEV = "cuda"
+
+
+def keep_np(idx, key, thr):
+    """numpy restatement of drop_keep(idx, key, thr) (neko_amd/csrc/neko_common.h)."""
+    h = (np.asarray(idx, dtype=np.uint64) ^ np.uint64(key)) & np.uint64(0xFFFFFFFF)
+    h = (h * np.uint64(0x9E3779B1)) & np.uint64(0xFFFFFFFF)
+    h ^= h >> np.uint64(15)
+    h = (h * np.uint64(0x85EBCA77)) & np.uint64(0xFFFFFFFF)
+    return (h >> np.uint64(24)) >= np.uint64(thr)
+
+
+def mask_flat(n, drop):
+    return torch.from_numpy(keep_np(np.arange(n, dtype=np.uint64), drop.key, drop.thr).astype(np.float32)) * drop.scale
+
+
+def mask_attn(B, H, T, drop):
+    idx = np.arange(B * H * T * T, dtype=np.uint64) & np.uint64(0xFFFFFFFF)
+    m = keep_np(idx, drop.key, drop.thr).astype(np.float32).reshape(B, H, T, T)
+    return torch.from_numpy(m) * drop.scale
+
+
+def rb(x):
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+def test_dropout_kernel_exact_and_rate():
+    from neko_amd import ops
+    d = ops.Drop(0.1, 0xDEADBEEF)
+    assert d.thr == 26 and abs(d.scale - 256 / 230) < 1e-12
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(1_000_003, generator=g)
+    y = ops.dropout_f32(x.to(DEV), d).cpu()
+    ref = x * mask_flat(x.numel(), d)
+    assert torch.equal(y, ref)
+    rate = float((y == 0).float().mean())
+    assert abs(rate - 26 / 256) < 2e-3, rate                      # quantised rate 26/256 = 0.1016
+    assert abs(float(y.sum()) - float(x.sum())) < 5e-3 * x.numel() ** 0.5 * 3   # unbiased
+    assert torch.equal(ops.dropout_f32(x.to(DEV), None).cpu(), x)  # off = identity
+
+
+def test_gemm_epilogue_and_ln_bwd_masks():
+    from neko_amd import ops
+    g = torch.Generator().manual_seed(1)
+    M, N, K = 200, 128, 192
+    A, W = rb(torch.randn(M, K, generator=g)), rb(torch.randn(K, N, generator=g) * 0.1)
+    bias, resid = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    d = ops.Drop(0.25, 12345)
+    for safe in (0, 2):
+        out = torch.empty(M, N, device=DEV)
+        ops.gemm(A.to(torch.bfloat16).to(DEV), W.to(torch.bfloat16).to(DEV), M, N, K, b_kstrided=True,
+                 bias=bias.to(DEV), resid=resid.to(DEV), out_f32=out, drop=d, safe_transpose=safe)
+        ref = (A @ W + bias) * mask_flat(M * N, d).view(M, N) + resid
+        assert torch.allclose(out.cpu(), ref, rtol=1e-4, atol=1e-3), safe
+    # LayerNorm backward: dx fp32 unmasked, bf16 copy masked
+    dd = 64
+    x = torch.randn(M, dd, generator=g); w = torch.randn(dd, generator=g); b = torch.randn(dd, generator=g)
+    dy = torch.randn(M, dd, generator=g)
+    xd = x.to(DEV); mean = torch.empty(M, device=DEV); rstd = torch.empty(M, device=DEV)
+    y32 = torch.empty(M, dd, device=DEV)
+    ops.layernorm_fwd(xd, w.to(DEV), b.to(DEV), y32=y32, mean=mean, rstd=rstd)
+    dg = torch.zeros(dd, device=DEV); db = torch.zeros(dd, device=DEV)
+    dx = torch.empty(M, dd, device=DEV); dx16 = torch.empty(M, dd, dtype=torch.bfloat16, device=DEV)
+    ops.layernorm_bwd(dy.to(DEV), xd, w.to(DEV), mean, rstd, dg, db, dx=dx, dx16=dx16, drop=d)
+    ref16 = (dx.cpu() * mask_flat(M * dd, d).view(M, dd)).to(torch.bfloat16)
+    assert torch.equal(dx16.cpu(), ref16)
+
+
+@pytest.mark.parametrize("B,T,H,hd", [(2, 96, 2, 32), (1, 200, 2, 64)])
+def test_attention_dropout_fwd_bwd(B, T, H, hd):
+    from neko_amd import ops
+    g = torch.Generator().manual_seed(T)
+    d = H * hd
+    qkv = rb(torch.randn(B, T, 3 * d, generator=g))
+    mask = torch.ones(B, T); mask[0, :9] = 0
+    do = rb(torch.randn(B, T, d, generator=g))
+    drop = ops.Drop(0.1, 0xABCDEF01)
+    dm = mask_attn(B, H, T, drop)
+    leaf = qkv.clone().requires_grad_(True)
+    q, k, v = leaf.split(d, dim=2)
+    sh = lambda t: t.view(B, T, H, hd).permute(0, 2, 1, 3)
+    o_ref = O.attention_core(sh(q), sh(k), sh(v), mask, drop_mask=dm).permute(0, 2, 1, 3).reshape(B, T, d)
+    o_ref.backward(do)
+    kb, ks = ops.mask_bias(mask.to(DEV))
+    qd = qkv.view(B * T, 3 * d).to(torch.bfloat16).to(DEV).contiguous()
+    out, lse = ops.attn_fwd(qd, kb, ks, B, T, H, hd, drop=drop)
+    sc = float(o_ref.detach().abs().max())
+    assert float((out.view(B, T, d).float().cpu() - o_ref.detach()).abs().max()) < 1e-2 * sc
+    dqkv = ops.attn_bwd(qd, out, do.view(B * T, d).to(torch.bfloat16).to(DEV).contiguous(), kb, ks, lse, B, T, H, hd, drop=drop)
+    gs = float(leaf.grad.abs().max())
+    assert float((dqkv.view(B, T, 3 * d).float().cpu() - leaf.grad).abs().max()) < 2e-2 * gs
+
+
+def test_policy_with_dropout_matches_oracle_with_same_masks():
+    """Whole policy, training mode, every dropout site on: loss and gradients against the oracle fed with the
+    masks the kernels generate (proves the forward/backward wiring of all four site kinds)."""
+    from neko_amd.policy.gato_policy import GatoPolicy
+    cfg = O.OracleConfig(embed_dim=64, layers=2, heads=2, text_tokens=128, context_len=64)
+    sd = O.init_state_dict(cfg, 11)
+    m = GatoPolicy(DEV, 64, 2, 2, 0.15, resid_mid_channels=128, context_len=64, text_tokenizer=128)
+    m.load_state_dict(sd)
+    m.train()
+    assert m.transformer.drop.p == 0.1                      # embd_pdrop stays at the HF default like the reference
+    drops = m.transformer.make_drops()
+    m.transformer.make_drops = lambda: drops               # pin the sites so the host can rebuild the masks
+    g = torch.Generator().manual_seed(3)
+    batch = [{"text": torch.randint(0, 128, (40,), generator=g).tolist()},
+             {"continuous_obs": torch.randn(5, 6, generator=g), "continuous_actions": torch.rand(5, 2, generator=g) * 2 - 1}]
+    dev_batch = [{k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in ex.items()} for ex in batch]
+    _, loss = m(dev_batch, compute_loss=True, return_logits=False)
+    loss.backward()
+    emb, tok, tgt, msk = O.tokenize_input_dicts(sd, cfg, batch)
+    B, T, d = emb.shape
+    masks = {"embd": mask_flat(B * T * d, drops.embd).view(B, T, d)}
+    for i in range(cfg.layers):
+        masks[("attn", i)] = mask_attn(B, cfg.heads, T, drops.attn[i])
+        masks[("resid_attn", i)] = mask_flat(B * T * d, drops.resid_attn[i]).view(B, T, d)
+        masks[("resid_mlp", i)] = mask_flat(B * T * d, drops.resid_mlp[i]).view(B, T, d)
+    loss_ref, _, grads = O.loss_and_grads(sd, cfg, batch, drop_masks=masks)
+    assert abs(float(loss) - float(loss_ref)) < 3e-3 * abs(float(loss_ref)), (float(loss), float(loss_ref))
+    named = dict(m.named_parameters())
+    for k in ("transformer.h.0.mlp.c_fc.weight", "transformer.h.1.attn.c_proj.weight", "transformer.h.0.attn.c_attn.weight",
+              "embed_token.weight", "predict_token.weight", "transformer.h.1.mlp.c_proj.bias", "pos_embed_observation.weight"):
+        gr, gg = grads[k], named[k].grad.cpu()
+        rel = float((gg - gr).abs().max() / gr.abs().max())
+        assert rel < 8e-2, (k, rel)
+    # a different step draws a different mask; eval mode has no dropout
+    m.transformer.make_drops = type(m.transformer).make_drops.__get__(m.transformer)
+    with torch.no_grad():
+        l1 = float(m(dev_batch, compute_loss=True, return_logits=False)[1])
+        l2 = float(m(dev_batch, compute_loss=True, return_logits=False)[1])
+        m.eval()
+        e1 = float(m(dev_batch, compute_loss=True, return_logits=False)[1])
+        e2 = float(m(dev_batch, compute_loss=True, return_logits=False)[1])
+    assert l1 != l2 and e1 == e2
