@@ -1,0 +1,111 @@
+"""Data-parallel step on the GPU with two ranks (both on cuda:0, backend gloo -- the pool has one GPU per box, so
+RCCL itself cannot be exercised here): the full neko_amd.dp path -- parameter broadcast, per-range all-reduce
+launched from inside backward, deferred ranges, MAX-reduced activity flags read by the optimiser kernel, 1/world
+gradient scale, clip on the averaged gradient -- must give every rank exactly the parameters a single process gets
+from the two batches with gradient averaging.  Rank 1's batch has no image, rank 0's has one (different parameter
+ranges touched per rank: the collective order must still match)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _batches():
+    g = torch.Generator().manual_seed(5)
+    b0 = [{"images": torch.floor(torch.rand(2, 3, 32, 32, generator=g) * 256), "discrete_actions": torch.randint(0, 4, (2, 1), generator=g).to(torch.int32)},
+          {"text": torch.randint(0, 128, (30,), generator=g).tolist()}]
+    b1 = [{"continuous_obs": torch.randn(4, 5, generator=g), "continuous_actions": torch.rand(4, 2, generator=g) * 2 - 1},
+          {"text": torch.randint(0, 128, (41,), generator=g).tolist()}]
+    return b0, b1
+
+
+def _to_dev(b):
+    return [{k: (v.cuda() if torch.is_tensor(v) else v) for k, v in ex.items()} for ex in b]
+
+
+def _make():
+    from neko_amd.policy.gato_policy import GatoPolicy
+    from oracle import neko_oracle as O
+    cfg = O.OracleConfig(embed_dim=64, layers=2, heads=2, text_tokens=128, context_len=96)
+    m = GatoPolicy("cuda:0", 64, 2, 2, 0.0, resid_mid_channels=128, context_len=96, text_tokenizer=128)
+    m.transformer.drop.p = 0.0
+    m.load_state_dict(O.init_state_dict(cfg, 21))
+    m.eval()            # deterministic patch positions; gradients flow regardless of mode
+    return m
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from neko_amd.dp import GradReducer
+        from neko_amd.training.optim import NekoAdamW
+        m = _make()
+        if rank == 1:                       # prove the broadcast: rank 1 starts from different weights
+            with torch.no_grad():
+                for p in m.parameters():
+                    p.add_(0.01)
+        opt = NekoAdamW(m, lr=1e-2, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.1)
+        dp = GradReducer(m._flat, bucket_bytes=32 * 1024)
+        dp.broadcast_parameters()
+        dp.attach(m, opt)
+        batch = _to_dev(_batches()[rank])
+        for _ in range(2):
+            _, loss = m.forward(inputs=batch, compute_loss=True, return_logits=False)
+            loss.backward()
+            dp.flush()
+            dp.finish()
+            gn = opt.clip_grad_norm_(0.5)
+            opt.step()
+            opt.zero_grad()
+        torch.cuda.synchronize()
+        out[rank] = {k: v.detach().cpu() for k, v in m.state_dict().items() if v.dtype == torch.float32 and v.numel() < 70000}
+        out[f"gn{rank}"] = float(gn)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dp_two_ranks_match_single_process_average():
+    from neko_amd.training.optim import NekoAdamW
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as mgr:
+        out = mgr.dict()
+        procs = [ctx.Process(target=_worker, args=(r, world, port, out)) for r in range(world)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(timeout=600)
+            assert p.exitcode == 0, f"worker exit code {p.exitcode}"
+        r0, r1, gn0, gn1 = out[0], out[1], out["gn0"], out["gn1"]
+    for k in r0:
+        assert torch.equal(r0[k], r1[k]), f"ranks diverged on {k}"
+    assert gn0 == gn1
+    # single-process reference: the two batches one after the other, gradients averaged with equal weight per rank
+    m = _make()
+    opt = NekoAdamW(m, lr=1e-2, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.1)
+    opt.grad_scale = torch.full((1,), 0.5, device="cuda")
+    b0, b1 = (_to_dev(b) for b in _batches())
+    for _ in range(2):
+        for b in (b0, b1):
+            _, loss = m.forward(inputs=b, compute_loss=True, return_logits=False)
+            loss.backward()                  # accumulates into the flat gradient
+        gn = opt.clip_grad_norm_(0.5)
+        opt.step()
+        opt.zero_grad()
+    ref = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    assert abs(float(gn) - gn0) < 1e-4 * gn0
+    for k, v in r0.items():
+        assert torch.allclose(v, ref[k], rtol=2e-4, atol=2e-6), (k, float((v - ref[k]).abs().max()))
