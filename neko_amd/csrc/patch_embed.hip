@@ -26,36 +26,60 @@ constexpr int HALO = PS + 2;  // 18
 constexpr int CHUNK = 32;     // channels per LDS chunk
 constexpr float GN_EPS = 1e-5f;
 
-struct Smem {
+// BWD = false drops the two backward-only [32][256] tiles: 83 KB -> two forward blocks per CU
+template <bool BWD>
+struct SmemT {
   float gx[3][HALO][HALO];        // GELU(x) with zero halo
-  float dh3[3][HALO][HALO];       // d(conv2 out) with zero halo (bwd)
+  float dh3[BWD ? 3 : 1][BWD ? HALO : 1][BWD ? HALO : 1];   // d(conv2 out) with zero halo (bwd)
   float tile[CHUNK][HALO][HALO];  // haloed channel chunk: raw h1, then h2 = GELU(GN(h1))
-  float xh[CHUNK][PS * PS];       // bwd: xhat of the chunk
-  float du[CHUNK][PS * PS];       // bwd: d(GN out), then d(h1)
+  float xh[BWD ? CHUNK : 1][PS * PS];       // bwd: xhat of the chunk
+  float du[BWD ? CHUNK : 1][PS * PS];       // bwd: d(GN out), then d(h1)
   float red[4][2 * CHUNK];        // cross-wave partials
   float mean[CHUNK / CPG], rstd[CHUNK / CPG];
-  float chan[2 * CHUNK];          // bwd per-patch per-channel sums: [cc] sum(du*xhat), [CHUNK+cc] sum(du)
-  float acc_gn[2 * C];            // bwd block accumulators for dgamma / dbeta
+  float chan[BWD ? 2 * CHUNK : 1];   // bwd per-patch per-channel sums: [cc] sum(du*xhat), [CHUNK+cc] sum(du)
+  float acc_gn[BWD ? 2 * C : 1];     // bwd block accumulators for dgamma / dbeta
   float acc_b2[4];
   // conv / GroupNorm parameters staged once per block (wave-uniform LDS broadcast reads)
-  float w1[C * 27];
-  float w2[3 * C * 9];
+  // rows padded to 28 floats (112 B): a channel's 27 weights are 7 aligned ds_read_b128 broadcasts
+  __attribute__((aligned(16))) float w1[C * 28];   // [c][i*9 + tap]
+  __attribute__((aligned(16))) float w2[C * 28];   // [c][o*9 + tap]  (regrouped per mid channel)
   float b1[C];
   float gw[C];
   float gb[C];
 };
-// forward does not need xh/du: it is launched with a smaller dynamic LDS window (offsetof(Smem, xh) + tail)
 
+template <class Smem>
 __device__ __forceinline__ void stage_params(Smem& s, const float* __restrict__ w1, const float* __restrict__ b1,
                                              const float* __restrict__ gw, const float* __restrict__ gb,
                                              const float* __restrict__ w2, int tid) {
-  for (int i = tid; i < C * 27; i += 256) { s.w1[i] = w1[i]; s.w2[i] = w2[i]; }
+  for (int i = tid; i < C * 27; i += 256) {
+    const int c = i / 27, t = i % 27;
+    s.w1[c * 28 + t] = w1[i];                                  // conv1.weight [c][3][3][3]
+    s.w2[c * 28 + t] = w2[((t / 9) * C + c) * 9 + (t % 9)];     // conv2.weight [o][c][3][3] -> [c][o][3][3]
+  }
+  if (tid < C) { s.w1[tid * 28 + 27] = 0.f; s.w2[tid * 28 + 27] = 0.f; }
   if (tid < C) { s.b1[tid] = b1[tid]; s.gw[tid] = gw[tid]; s.gb[tid] = gb[tid]; }
 }
 
+// dot of a channel's 27 (padded to 28) LDS-resident weights with 27 per-thread values
+__device__ __forceinline__ float dot27(const float* __restrict__ w, const float (&v)[27], float acc) {
+  const float4* w4 = reinterpret_cast<const float4*>(w);
+#pragma unroll
+  for (int q = 0; q < 7; ++q) {
+    const float4 a = w4[q];
+    acc = fmaf(a.x, v[4 * q + 0], acc);
+    acc = fmaf(a.y, v[4 * q + 1], acc);
+    acc = fmaf(a.z, v[4 * q + 2], acc);
+    if (q < 6) acc = fmaf(a.w, v[4 * q + 3], acc);
+  }
+  return acc;
+}
+
+template <class Smem>
 __device__ __forceinline__ void zero_halos(Smem& s, int tid) {
   float* z = &s.gx[0][0][0];
-  for (int i = tid; i < 3 * HALO * HALO; i += 256) { z[i] = 0.f; (&s.dh3[0][0][0])[i] = 0.f; }
+  for (int i = tid; i < 3 * HALO * HALO; i += 256) z[i] = 0.f;
+  for (int i = tid; i < (int)(sizeof(s.dh3) / sizeof(float)); i += 256) (&s.dh3[0][0][0])[i] = 0.f;
   float* t = &s.tile[0][0][0];
   for (int i = tid; i < CHUNK * HALO * HALO; i += 256) t[i] = 0.f;
 }
@@ -63,6 +87,7 @@ __device__ __forceinline__ void zero_halos(Smem& s, int tid) {
 // conv1 of channel chunk k for this thread's pixel -> raw h1 into the haloed tile, then the GroupNorm
 // statistics of the chunk's 8 groups (two-pass: mean, centred variance) into s.mean / s.rstd.
 // nb = the 27 GELU(x) neighbours of the pixel.  All loops are dynamic on purpose (small live ranges).
+template <class Smem>
 __device__ __forceinline__ void conv1_stats_chunk(Smem& s, int k, const float (&nb)[27], int py, int px, int tid) {
   const int lane = tid & 63, wave = tid >> 6;
   constexpr int NG = CHUNK / CPG;
@@ -72,10 +97,7 @@ __device__ __forceinline__ void conv1_stats_chunk(Smem& s, int k, const float (&
 #pragma unroll
     for (int j = 0; j < CPG; ++j) {
       const int cc = g * CPG + j, c = k * CHUNK + cc;
-      const float* w = &s.w1[c * 27];
-      float a = s.b1[c];
-#pragma unroll
-      for (int t = 0; t < 27; ++t) a = fmaf(w[t], nb[t], a);
+      const float a = dot27(&s.w1[c * 28], nb, s.b1[c]);
       s.tile[cc][py + 1][px + 1] = a;
       gs += a;
     }
@@ -105,12 +127,12 @@ __device__ __forceinline__ void conv1_stats_chunk(Smem& s, int k, const float (&
 }
 
 template <bool U8>
-__global__ __launch_bounds__(256) void resblock_fwd_kernel(const void* __restrict__ images, int n, int H, int W,
+__global__ __launch_bounds__(256, 2) void resblock_fwd_kernel(const void* __restrict__ images, int n, int H, int W,
                                                            const float* __restrict__ w1, const float* __restrict__ b1,
                                                            const float* __restrict__ gw, const float* __restrict__ gb,
                                                            const float* __restrict__ w2, const float* __restrict__ b2,
                                                            bf16_t* __restrict__ y16, float* __restrict__ xp) {
-  __shared__ Smem s;
+  __shared__ SmemT<false> s;
   const int tid = threadIdx.x, py = tid >> 4, px = tid & 15;
   const int nh = H / PS, nw = W / PS, P = n * nh * nw;
   zero_halos(s, tid);
@@ -158,15 +180,22 @@ __global__ __launch_bounds__(256) void resblock_fwd_kernel(const void* __restric
 #pragma unroll 2
       for (int cc = 0; cc < CHUNK; ++cc) {
         const int c = k * CHUNK + cc;
+        float wv[28];
+        const float4* w4 = reinterpret_cast<const float4*>(&s.w2[c * 28]);
+#pragma unroll
+        for (int q = 0; q < 7; ++q) {
+          const float4 a = w4[q];
+          wv[4 * q] = a.x; wv[4 * q + 1] = a.y; wv[4 * q + 2] = a.z; wv[4 * q + 3] = a.w;
+        }
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
           for (int dx = 0; dx < 3; ++dx) {
             const float v = s.tile[cc][py + dy][px + dx];
             const int t = dy * 3 + dx;
-            o0 = fmaf(s.w2[(0 * C + c) * 9 + t], v, o0);
-            o1 = fmaf(s.w2[(1 * C + c) * 9 + t], v, o1);
-            o2 = fmaf(s.w2[(2 * C + c) * 9 + t], v, o2);
+            o0 = fmaf(wv[t], v, o0);
+            o1 = fmaf(wv[9 + t], v, o1);
+            o2 = fmaf(wv[18 + t], v, o2);
           }
       }
       __syncthreads();   // tile is rewritten by the next chunk
@@ -177,8 +206,12 @@ __global__ __launch_bounds__(256) void resblock_fwd_kernel(const void* __restric
   }
 }
 
-// Backward over patches (grid-stride).  dy f32 [P,768] is the gradient of the block output
-// (= gradient wrt conv2 output; the identity branch reaches only the input image).
+// Backward.  dy f32 [P,768] is the gradient of the block output (= gradient wrt conv2 output; the identity
+// branch reaches only the input image).  Loop order: channel chunk k OUTER, patches (grid-stride) INNER, so only the
+// chunk's weight-gradient accumulators are live in registers; everything per patch is recomputed per chunk (cheap
+// next to the sweeps).  Weight-gradient sweeps are register-blocked: thread (cp, sl) owns channels {2cp, 2cp+1} of
+// the chunk and pixel row sl, and accumulates all (output, tap) / (input, tap) combinations -> 54 FMAs per 21 / 29
+// LDS reads; the 16 row-slices meet in xor-shuffles once per chunk, then one fp32 atomic per weight per block.
 __global__ __launch_bounds__(256) void resblock_bwd_kernel(const float* __restrict__ xp, const float* __restrict__ dy,
                                                            int P, const float* __restrict__ w1,
                                                            const float* __restrict__ b1, const float* __restrict__ gw,
@@ -186,58 +219,59 @@ __global__ __launch_bounds__(256) void resblock_bwd_kernel(const float* __restri
                                                            float* __restrict__ dw1, float* __restrict__ db1,
                                                            float* __restrict__ dgw, float* __restrict__ dgb,
                                                            float* __restrict__ dw2, float* __restrict__ db2) {
-  __shared__ Smem s;
+  __shared__ SmemT<true> s;
   const int tid = threadIdx.x, py = tid >> 4, px = tid & 15, lane = tid & 63, wave = tid >> 6;
+  const int cp = tid >> 4, sl = tid & 15;          // sweep role: channel pair / pixel row
   zero_halos(s, tid);
   stage_params(s, w1, b1, gw, gb, w2, tid);
   for (int i = tid; i < 2 * C; i += 256) s.acc_gn[i] = 0.f;
   if (tid < 4) s.acc_b2[tid] = 0.f;
-  // register accumulators over the patches this block walks: output slot j of chunk k is (tid + 256*j)
-  float aw2[C / CHUNK][4], aw1[C / CHUNK][4];
-#pragma unroll
-  for (int k = 0; k < C / CHUNK; ++k)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { aw2[k][j] = 0.f; aw1[k][j] = 0.f; }
   const float inv_n = 1.0f / (float)(CPG * PS * PS);
 
-  for (int p = blockIdx.x; p < P; p += gridDim.x) {
-    float g3[3];
-    {
-      float xv[3];
+#pragma unroll 1
+  for (int k = 0; k < C / CHUNK; ++k) {
+    float a2[27][2], a1[27][2], ab[2];
 #pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        xv[i] = xp[(long)p * 768 + i * 256 + tid];
-        g3[i] = dy[(long)p * 768 + i * 256 + tid];
+    for (int i = 0; i < 27; ++i) { a2[i][0] = a2[i][1] = 0.f; a1[i][0] = a1[i][1] = 0.f; }
+    ab[0] = ab[1] = 0.f;
+
+#pragma unroll 1
+    for (int p = blockIdx.x; p < P; p += gridDim.x) {
+      float g3[3];
+      {
+        float xv[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          xv[i] = xp[(long)p * 768 + i * 256 + tid];
+          g3[i] = dy[(long)p * 768 + i * 256 + tid];
+        }
+        __syncthreads();      // previous (chunk, patch) is done with every LDS tile
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          s.gx[i][py + 1][px + 1] = gelu_f(xv[i]);
+          s.dh3[i][py + 1][px + 1] = g3[i];
+        }
+      }
+      if (k == 0) {           // db2 once per patch
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          const float r = wave_sum(g3[i]);
+          if (lane == 0) s.red[wave][i] = r;
+        }
       }
       __syncthreads();
+      if (k == 0 && tid < 3) s.acc_b2[tid] += (s.red[0][tid] + s.red[1][tid]) + (s.red[2][tid] + s.red[3][tid]);
+      float nb[27], nb3[27];
 #pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        s.gx[i][py + 1][px + 1] = gelu_f(xv[i]);
-        s.dh3[i][py + 1][px + 1] = g3[i];
-      }
-    }
-    // db2
+      for (int i = 0; i < 3; ++i)
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const float r = wave_sum(g3[i]);
-      if (lane == 0) s.red[wave][i] = r;
-    }
-    __syncthreads();
-    if (tid < 3) s.acc_b2[tid] += (s.red[0][tid] + s.red[1][tid]) + (s.red[2][tid] + s.red[3][tid]);
-    float nb[27], nb3[27];
+        for (int dy_ = 0; dy_ < 3; ++dy_)
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-      for (int dy_ = 0; dy_ < 3; ++dy_)
-#pragma unroll
-        for (int dx_ = 0; dx_ < 3; ++dx_) {
-          nb[i * 9 + dy_ * 3 + dx_] = s.gx[i][py + dy_][px + dx_];
-          nb3[i * 9 + dy_ * 3 + dx_] = s.dh3[i][py - dy_ + 2][px - dx_ + 2];
-        }
-    __syncthreads();
-
-#pragma unroll
-    for (int k = 0; k < C / CHUNK; ++k) {      // unrolled: aw1/aw2 stay in registers; inner loops are dynamic
+          for (int dx_ = 0; dx_ < 3; ++dx_) {
+            nb[i * 9 + dy_ * 3 + dx_] = s.gx[i][py + dy_][px + dx_];
+            nb3[i * 9 + dy_ * 3 + dx_] = s.dh3[i][py - dy_ + 2][px - dx_ + 2];
+          }
+      __syncthreads();
       conv1_stats_chunk(s, k, nb, py, px, tid);
       // xhat -> s.xh ; h2 -> haloed tile ; du = d(h2)*GELU'(u) -> s.du ; per-channel sums
 #pragma unroll 1
@@ -251,13 +285,7 @@ __global__ __launch_bounds__(256) void resblock_bwd_kernel(const float* __restri
           s.xh[cc][tid] = xh;
           s.tile[cc][py + 1][px + 1] = gelu_f(u);
           // d_h2[c] = sum_o sum_taps w2[o][c][tap] * dh3[o][pixel - tap + 1]
-          float a = 0.f;
-#pragma unroll
-          for (int o = 0; o < 3; ++o) {
-            const float* w = &s.w2[(o * C + c) * 9];
-#pragma unroll
-            for (int t = 0; t < 9; ++t) a = fmaf(w[t], nb3[o * 9 + t], a);
-          }
+          const float a = dot27(&s.w2[c * 28], nb3, 0.f);
           const float du = a * gelu_grad_f(u);
           s.du[cc][tid] = du;
           const float r1 = wave_sum(du * xh), r2 = wave_sum(du);
@@ -271,23 +299,26 @@ __global__ __launch_bounds__(256) void resblock_bwd_kernel(const float* __restri
         const int c = k * CHUNK + (tid & (CHUNK - 1));
         s.acc_gn[(tid < CHUNK ? 0 : C) + c] += v;      // [0,C) dgamma, [C,2C) dbeta
       }
-      // dW2 sweep: outputs idx = (o*CHUNK + cc)*9 + t over the chunk (864)
+      // ---- dW2 sweep: a2[o*9+tap][e] += dh3[o][px] * h2[2cp+e][px + tap - 1] over pixel row sl ------------------
+      {
+        const int c0 = 2 * cp;
+#pragma unroll 2
+        for (int xx = 0; xx < PS; ++xx) {
+          const float d0 = s.dh3[0][sl + 1][xx + 1], d1 = s.dh3[1][sl + 1][xx + 1], d2 = s.dh3[2][sl + 1][xx + 1];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int idx = tid + 256 * j;
-        if (idx < 3 * CHUNK * 9) {
-          const int t = idx % 9, cc = (idx / 9) % CHUNK, o = idx / (9 * CHUNK);
-          const int dy_ = t / 3, dx_ = t % 3;
-          float a = 0.f;
-#pragma unroll 1
-          for (int yy = 0; yy < PS; ++yy)
+          for (int dy_ = 0; dy_ < 3; ++dy_)
 #pragma unroll
-            for (int xx = 0; xx < PS; ++xx) a = fmaf(s.dh3[o][yy + 1][xx + 1], s.tile[cc][yy + dy_][xx + dx_], a);
-          aw2[k][j] += a;
+            for (int dx_ = 0; dx_ < 3; ++dx_) {
+              const int t = dy_ * 3 + dx_;
+              const float h0 = s.tile[c0][sl + dy_][xx + dx_], h1 = s.tile[c0 + 1][sl + dy_][xx + dx_];
+              a2[t][0] = fmaf(d0, h0, a2[t][0]);      a2[t][1] = fmaf(d0, h1, a2[t][1]);
+              a2[9 + t][0] = fmaf(d1, h0, a2[9 + t][0]);  a2[9 + t][1] = fmaf(d1, h1, a2[9 + t][1]);
+              a2[18 + t][0] = fmaf(d2, h0, a2[18 + t][0]); a2[18 + t][1] = fmaf(d2, h1, a2[18 + t][1]);
+            }
         }
       }
       __syncthreads();
-      // d_h1 = rstd_g * (du*gamma - A_g/N - xhat*B_g/N) in place of du (own pixel)
+      // ---- d_h1 = rstd_g * (du*gamma - A_g/N - xhat*B_g/N) in place of du (own pixel) -------------------------
 #pragma unroll 1
       for (int g = 0; g < CHUNK / CPG; ++g) {
         float A = 0.f, Bv = 0.f;
@@ -305,49 +336,59 @@ __global__ __launch_bounds__(256) void resblock_bwd_kernel(const float* __restri
         }
       }
       __syncthreads();
-      // dW1 / db1 sweep: idx < 864: (cc, i, tap); 864 <= idx < 896: bias of channel idx-864
+      // ---- dW1 / db1 sweep: a1[i*9+tap][e] += d_h1[2cp+e][px] * gx[i][px + tap - 1] over pixel row sl -----------
+      {
+        const int c0 = 2 * cp;
+#pragma unroll 2
+        for (int xx = 0; xx < PS; ++xx) {
+          const float u0 = s.du[c0][sl * 16 + xx], u1 = s.du[c0 + 1][sl * 16 + xx];
+          ab[0] += u0;
+          ab[1] += u1;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int idx = tid + 256 * j;
-        if (idx < CHUNK * 27) {
-          const int t9 = idx % 9, i = (idx / 9) % 3, cc = idx / 27;
-          const int dy_ = t9 / 3, dx_ = t9 % 3;
-          float a = 0.f;
-#pragma unroll 1
-          for (int yy = 0; yy < PS; ++yy)
+          for (int i = 0; i < 3; ++i)
 #pragma unroll
-            for (int xx = 0; xx < PS; ++xx) a = fmaf(s.du[cc][yy * 16 + xx], s.gx[i][yy + dy_][xx + dx_], a);
-          aw1[k][j] += a;
-        } else if (idx < CHUNK * 28) {
-          const int cc = idx - CHUNK * 27;
-          float a = 0.f;
-#pragma unroll 8
-          for (int q = 0; q < 256; ++q) a += s.du[cc][q];
-          aw1[k][j] += a;
+            for (int dy_ = 0; dy_ < 3; ++dy_)
+#pragma unroll
+              for (int dx_ = 0; dx_ < 3; ++dx_) {
+                const int t = i * 9 + dy_ * 3 + dx_;
+                const float gv = s.gx[i][sl + dy_][xx + dx_];
+                a1[t][0] = fmaf(u0, gv, a1[t][0]);
+                a1[t][1] = fmaf(u1, gv, a1[t][1]);
+              }
         }
       }
-      __syncthreads();
-    }
-  }
+    }   // patches
 
-  // ---- flush block accumulators ------------------------------------------------------------------------
-  __syncthreads();
+    // ---- combine the 16 pixel-row slices of every channel pair (lanes tid%16) and flush the chunk ------------------
 #pragma unroll
-  for (int k = 0; k < C / CHUNK; ++k)
+    for (int i = 0; i < 27; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int idx = tid + 256 * j;
-      if (idx < 3 * CHUNK * 9) {
-        const int t = idx % 9, cc = (idx / 9) % CHUNK, o = idx / (9 * CHUNK);
-        atomicAdd(dw2 + (o * C + k * CHUNK + cc) * 9 + t, aw2[k][j]);
+      for (int e = 0; e < 2; ++e) {
+        float v2 = a2[i][e], v1 = a1[i][e];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) { v2 += __shfl_xor(v2, o, 64); v1 += __shfl_xor(v1, o, 64); }
+        a2[i][e] = v2;
+        a1[i][e] = v1;
       }
-      if (idx < CHUNK * 27) {
-        const int t9 = idx % 9, i = (idx / 9) % 3, cc = idx / 27;
-        atomicAdd(dw1 + ((k * CHUNK + cc) * 3 + i) * 9 + t9, aw1[k][j]);
-      } else if (idx < CHUNK * 28) {
-        atomicAdd(db1 + k * CHUNK + (idx - CHUNK * 27), aw1[k][j]);
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) ab[e] += __shfl_xor(ab[e], o, 64);
+    if (sl == 0) {
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int c = k * CHUNK + 2 * cp + e;
+#pragma unroll
+        for (int i = 0; i < 27; ++i) {
+          atomicAdd(dw2 + ((i / 9) * C + c) * 9 + (i % 9), a2[i][e]);      // i = o*9 + tap
+          atomicAdd(dw1 + (c * 3 + (i / 9)) * 9 + (i % 9), a1[i][e]);      // i = in*9 + tap
+        }
+        atomicAdd(db1 + c, ab[e]);
       }
     }
+  }   // chunks
+
+  __syncthreads();
   if (tid < C) {
     atomicAdd(dgw + tid, s.acc_gn[tid]);
     atomicAdd(dgb + tid, s.acc_gn[C + tid]);
