@@ -19,9 +19,11 @@
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 32, NT = 256;
-constexpr int NSTAGE = 4;                       // LDS ring depth: 3 tiles in flight while one is consumed
+// LDS ring depth NSTAGE (template): NSTAGE-1 tiles in flight while one is consumed.
+//   3 stages = 48 KB -> 3 blocks per CU: best for short K (768..3072), where prologue/epilogue overlap matters;
+//   4 stages = 64 KB -> 2 blocks per CU: best for long K (LM-head dH, wgrad), where the deeper ring matters.
 constexpr int OP_BYTES = 128 * BK * 2;          // 8 KiB per operand per stage
-constexpr int STAGE_BYTES = 2 * OP_BYTES;       // 16 KiB per stage -> 64 KiB per block, 2 blocks per CU
+constexpr int STAGE_BYTES = 2 * OP_BYTES;       // 16 KiB per stage
 constexpr int GLDS_PER_STAGE = 4;               // wave-instructions each wave issues per stage (2 A + 2 B)
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -101,8 +103,8 @@ __device__ __forceinline__ void wait_dma_and_barrier() {
   asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
-template <bool A_KC, bool B_KC>
-__global__ __launch_bounds__(NT, 2) void gemm_glds_kernel(GemmArgs p) {
+template <bool A_KC, bool B_KC, int NSTAGE>
+__global__ __launch_bounds__(NT, (160 * 1024) / (NSTAGE * STAGE_BYTES)) void gemm_glds_kernel(GemmArgs p) {
   __shared__ __attribute__((aligned(1024))) char smem[NSTAGE * STAGE_BYTES];   // ring of [A|B] stages
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -145,8 +147,8 @@ __global__ __launch_bounds__(NT, 2) void gemm_glds_kernel(GemmArgs p) {
   for (int kt = 0; kt < nkt; ++kt) {
     // tile kt must have landed: the tiles issued after it (at most NSTAGE-2) may stay in flight
     const int later = min(NSTAGE - 2, nkt - 1 - kt);
-    if (later >= 2) wait_dma_and_barrier<2 * GLDS_PER_STAGE>();
-    else if (later == 1) wait_dma_and_barrier<1 * GLDS_PER_STAGE>();
+    if (NSTAGE >= 4 && later >= 2) wait_dma_and_barrier<2 * GLDS_PER_STAGE>();
+    else if (later >= 1) wait_dma_and_barrier<1 * GLDS_PER_STAGE>();
     else wait_dma_and_barrier<0>();
     // every wave is past tile kt-1: its ring slot is free for tile kt+NSTAGE-1
     if (kt + NSTAGE - 1 < nkt) stage(kt + NSTAGE - 1);
@@ -170,18 +172,8 @@ __global__ __launch_bounds__(NT, 2) void gemm_glds_kernel(GemmArgs p) {
   }
   __syncthreads();   // all waves done with the ring before the slabs overwrite it
 
-  // ---- epilogue through this wave's private 16 KiB slab -------------------------------------------------
-  float* slab = reinterpret_cast<float*>(smem + wave * 16384);   // [64 rows][64 f32], float4 chunk ^= row&15
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const int col = j * 32 + (lane & 31);
-        slab[row * 64 + ((((col >> 2) ^ (row & 15)) << 2) | (col & 3))] = acc[i][j][r];
-      }
+  // ---- epilogue through this wave's private 8 KiB slab, two passes of 32 rows ---------------------------------
+  float* slab = reinterpret_cast<float*>(smem + wave * 8192);   // [32 rows][64 f32], float4 chunk ^= row&15
   // same-wave LDS write -> read: the compiler's lgkmcnt wait orders it (no cross-wave sharing of a slab)
   const float alpha = p.alpha_dev ? p.alpha * (*p.alpha_dev) : p.alpha;
   const bool to_ws = p.splitk > 1 && p.splitk_ws;   // split-K slices go to a workspace, reduced in fixed order afterwards
@@ -205,10 +197,20 @@ __global__ __launch_bounds__(NT, 2) void gemm_glds_kernel(GemmArgs p) {
   }
   const bool cf_vec = vec && ((ldcf_out & 3) == 0);
   const bool r_vec = vec && ((p.ldr & 3) == 0);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int lr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int lc = j * 32 + (lane & 31);
+        slab[lr * 64 + ((((lc >> 2) ^ (lr & 15)) << 2) | (lc & 3))] = acc[i][j][r];
+      }
 #pragma unroll 4
-  for (int s = 0; s < 16; ++s) {
+  for (int s = 0; s < 8; ++s) {
     const int lrow = s * 4 + (lane >> 4);
-    const int row = m0 + wm * 64 + lrow;
+    const int row = m0 + wm * 64 + i * 32 + lrow;
     const float4 a4 = *reinterpret_cast<const float4*>(slab + lrow * 64 + ((cchunk ^ (lrow & 15)) << 2));
     if (row >= p.M || !col_ok) continue;
     float v[4] = {a4.x * alpha + bv.x, a4.y * alpha + bv.y, a4.z * alpha + bv.z, a4.w * alpha + bv.w};
@@ -281,13 +283,16 @@ __global__ __launch_bounds__(NT, 2) void gemm_glds_kernel(GemmArgs p) {
       }
     }
   }
+  }   // 32-row passes
 }
 
 template <bool A_KC, bool B_KC>
 int launch(const GemmArgs& a, hipStream_t s) {
   const int nbm = (a.M + BM - 1) / BM, nbn = (a.N + BN - 1) / BN;
   dim3 grid(nbm * nbn, a.splitk > 1 ? a.splitk : 1);
-  hipLaunchKernelGGL((gemm_glds_kernel<A_KC, B_KC>), grid, dim3(NT), 0, s, a);
+  const int klen = a.splitk > 1 ? a.k_per_split : a.K;
+  if (klen >= 16384) hipLaunchKernelGGL((gemm_glds_kernel<A_KC, B_KC, 4>), grid, dim3(NT), 0, s, a);
+  else hipLaunchKernelGGL((gemm_glds_kernel<A_KC, B_KC, 3>), grid, dim3(NT), 0, s, a);
   NEKO_CHECK_LAUNCH();
   return NEKO_OK;
 }
