@@ -33,7 +33,7 @@ extern "C" {
 #define NEKO_ERR_UNSUPPORTED (-2)
 #define NEKO_ERR_LAUNCH (-3)
 
-#define NEKO_ABI_VERSION 3
+#define NEKO_ABI_VERSION 4
 
 int neko_abi_version(void);
 /* human-readable text for a return code (static storage) */
@@ -176,7 +176,9 @@ int neko_patch_resblock_fwd(const void* images, int images_are_u8, int n, int H,
 int neko_patch_resblock_bwd(const float* x_patches, const float* dy, int P, const float* w1, const float* b1,
                             const float* gn_w, const float* gn_b, const float* w2, const float* b2,
                             int mid_channels, int num_groups, float* dw1, float* db1, float* dgn_w, float* dgn_b,
-                            float* dw2, float* db2, void* stream);
+                            float* dw2, float* db2, float* workspace, void* stream);
+/* workspace floats the backward needs for P patches (per-block partial gradient rows, reduced in fixed order) */
+int neko_patch_resblock_bwd_ws_floats(int P);
 int neko_patch_pos_add(float* out, const int* hpos, const int* wpos, const float* row_emb, const float* col_emb,
                        int P, int d, void* stream);
 int neko_patch_pos_add_bwd(const float* dout, const int* hpos, const int* wpos, float* d_row_emb,

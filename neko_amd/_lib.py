@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libneko_hip.so")
+LIB_PATH = os.environ.get("NEKO_HIP_LIB") or os.path.join(_HERE, "csrc", "libneko_hip.so")   # override: kernel A/B builds
 
 _vp, _i, _l, _f = C.c_void_p, C.c_int, C.c_long, C.c_float
 
@@ -36,7 +36,8 @@ SIGNATURES = {
     "neko_adamw_step": [_vp, _vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _vp, _f, _vp, _vp, _vp, _vp],
     "neko_patch_resblock_fwd": [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp],
     "neko_patch_resblock_bwd": [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
-                                _vp],
+                                _vp, _vp],
+    "neko_patch_resblock_bwd_ws_floats": [_i],
     "neko_patch_pos_add": [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "neko_patch_pos_add_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "neko_abi_version": [],

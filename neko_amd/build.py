@@ -51,6 +51,11 @@ def _compile(src: str, force: bool) -> str:
 
 
 def build(force: bool = False, jobs: int = 4, verbose: bool = True) -> str:
+    global BUILD, LIB
+    tag = os.environ.get("NEKO_BUILD_TAG")          # A/B builds: separate object dir and library name
+    if tag:
+        BUILD = os.path.join(CSRC, "build_" + tag)
+        LIB = os.path.join(CSRC, f"libneko_hip_{tag}.so")
     os.makedirs(BUILD, exist_ok=True)
     with cf.ThreadPoolExecutor(max_workers=jobs) as ex:
         objs = list(ex.map(lambda s: _compile(s, force), SOURCES))

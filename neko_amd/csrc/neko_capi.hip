@@ -110,9 +110,12 @@ int neko_patch_resblock_fwd(const void* images, int images_are_u8, int n, int H,
 int neko_patch_resblock_bwd(const float* x_patches, const float* dy, int P, const float* w1, const float* b1,
                             const float* gn_w, const float* gn_b, const float* w2, const float* b2, int mid_channels,
                             int num_groups, float* dw1, float* db1, float* dgn_w, float* dgn_b, float* dw2, float* db2,
-                            void* stream) {
+                            float* workspace, void* stream) {
   return neko_patch_resblock_bwd_impl(x_patches, dy, P, w1, b1, gn_w, gn_b, w2, b2, mid_channels, num_groups, dw1, db1,
-                                      dgn_w, dgn_b, dw2, db2, S(stream));
+                                      dgn_w, dgn_b, dw2, db2, workspace, S(stream));
+}
+int neko_patch_resblock_bwd_ws_floats(int P) {
+  return neko_patch_resblock_bwd_blocks_impl(P) * neko_patch_resblock_ws_stride_impl();
 }
 int neko_patch_pos_add(float* out, const int* hpos, const int* wpos, const float* row_emb, const float* col_emb,
                        int P, int d, void* stream) {

@@ -73,7 +73,9 @@ int neko_patch_resblock_fwd_impl(const void* images, int images_are_u8, int n, i
 int neko_patch_resblock_bwd_impl(const float* x_patches, const float* dy, int P, const float* w1, const float* b1,
                                  const float* gn_w, const float* gn_b, const float* w2, const float* b2,
                                  int mid_channels, int num_groups, float* dw1, float* db1, float* dgn_w, float* dgn_b,
-                                 float* dw2, float* db2, hipStream_t s);
+                                 float* dw2, float* db2, float* workspace, hipStream_t s);
+int neko_patch_resblock_bwd_blocks_impl(int P);
+int neko_patch_resblock_ws_stride_impl();
 int neko_patch_pos_add_impl(float* out, const int* hpos, const int* wpos, const float* row_emb, const float* col_emb,
                             int P, int d, hipStream_t s);
 int neko_patch_pos_add_bwd_impl(const float* dout, const int* hpos, const int* wpos, float* d_row_emb,

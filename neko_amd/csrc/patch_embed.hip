@@ -25,6 +25,9 @@ constexpr int PS = 16;        // patch size
 constexpr int HALO = PS + 2;  // 18
 constexpr int CHUNK = 32;     // channels per LDS chunk
 constexpr float GN_EPS = 1e-5f;
+// layout of one per-block partial-gradient row of the backward kernel
+constexpr int OFF_W1 = 0, OFF_B1 = 128 * 27, OFF_GW = OFF_B1 + 128, OFF_GB = OFF_GW + 128, OFF_W2 = OFF_GB + 128,
+              OFF_B2 = OFF_W2 + 3 * 128 * 9, PART_USED = OFF_B2 + 3, PART_STRIDE = (PART_USED + 63) / 64 * 64;
 
 // BWD = false drops the two backward-only [32][256] tiles: 83 KB -> two forward blocks per CU
 template <bool BWD>
@@ -84,45 +87,51 @@ __device__ __forceinline__ void zero_halos(Smem& s, int tid) {
   for (int i = tid; i < CHUNK * HALO * HALO; i += 256) t[i] = 0.f;
 }
 
+// out[cc] = sum over the 256 pixels of f(cc, px) for the chunk's 32 channels: 8 threads per channel sum 32 pixels
+// each (rotated start so the lanes of a half-wave hit distinct banks), then 3 in-row xor steps.  Replaces per-channel
+// wave_sum chains (6 dependent cross-lane steps each), which dominated the kernels at one wave per SIMD.
+template <class F>
+__device__ __forceinline__ void chan_reduce32(F f, float* out, int tid) {
+  const int cc = tid >> 3, sub = tid & 7;
+  float a0 = 0.f, a1 = 0.f;
+#pragma unroll 8
+  for (int i = 0; i < 32; i += 2) {
+    a0 += f(cc, sub * 32 + ((i + tid) & 31));
+    a1 += f(cc, sub * 32 + ((i + 1 + tid) & 31));
+  }
+  float a = a0 + a1;
+  a += __shfl_xor(a, 1, 64);
+  a += __shfl_xor(a, 2, 64);
+  a += __shfl_xor(a, 4, 64);
+  if (sub == 0) out[cc] = a;
+}
+
 // conv1 of channel chunk k for this thread's pixel -> raw h1 into the haloed tile, then the GroupNorm
 // statistics of the chunk's 8 groups (two-pass: mean, centred variance) into s.mean / s.rstd.
 // nb = the 27 GELU(x) neighbours of the pixel.  All loops are dynamic on purpose (small live ranges).
 template <class Smem>
 __device__ __forceinline__ void conv1_stats_chunk(Smem& s, int k, const float (&nb)[27], int py, int px, int tid) {
-  const int lane = tid & 63, wave = tid >> 6;
   constexpr int NG = CHUNK / CPG;
 #pragma unroll 1
   for (int g = 0; g < NG; ++g) {
-    float gs = 0.f;
 #pragma unroll
     for (int j = 0; j < CPG; ++j) {
       const int cc = g * CPG + j, c = k * CHUNK + cc;
-      const float a = dot27(&s.w1[c * 28], nb, s.b1[c]);
-      s.tile[cc][py + 1][px + 1] = a;
-      gs += a;
+      s.tile[cc][py + 1][px + 1] = dot27(&s.w1[c * 28], nb, s.b1[c]);
     }
-    gs = wave_sum(gs);
-    if (lane == 0) s.red[wave][g] = gs;
   }
+  __syncthreads();
+  float* csum = &s.red[0][0];      // 32 per-channel sums
+  chan_reduce32([&](int cc, int p) { return s.tile[cc][(p >> 4) + 1][(p & 15) + 1]; }, csum, tid);
   __syncthreads();
   const float inv_n = 1.0f / (float)(CPG * PS * PS);
-  if (tid < NG) s.mean[tid] = ((s.red[0][tid] + s.red[1][tid]) + (s.red[2][tid] + s.red[3][tid])) * inv_n;
+  if (tid < NG) s.mean[tid] = ((csum[4 * tid] + csum[4 * tid + 1]) + (csum[4 * tid + 2] + csum[4 * tid + 3])) * inv_n;
   __syncthreads();
-#pragma unroll 1
-  for (int g = 0; g < NG; ++g) {
-    const float m = s.mean[g];
-    float q = 0.f;
-#pragma unroll
-    for (int j = 0; j < CPG; ++j) {
-      const float d = s.tile[g * CPG + j][py + 1][px + 1] - m;
-      q = fmaf(d, d, q);
-    }
-    q = wave_sum(q);
-    if (lane == 0) s.red[wave][CHUNK + g] = q;
-  }
+  chan_reduce32([&](int cc, int p) { const float d = s.tile[cc][(p >> 4) + 1][(p & 15) + 1] - s.mean[cc / CPG]; return d * d; },
+                csum, tid);
   __syncthreads();
   if (tid < NG)
-    s.rstd[tid] = rsqrtf(((s.red[0][CHUNK + tid] + s.red[1][CHUNK + tid]) + (s.red[2][CHUNK + tid] + s.red[3][CHUNK + tid])) * inv_n + GN_EPS);
+    s.rstd[tid] = rsqrtf(((csum[4 * tid] + csum[4 * tid + 1]) + (csum[4 * tid + 2] + csum[4 * tid + 3])) * inv_n + GN_EPS);
   __syncthreads();
 }
 
@@ -216,9 +225,16 @@ __global__ __launch_bounds__(256) void resblock_bwd_kernel(const float* __restri
                                                            int P, const float* __restrict__ w1,
                                                            const float* __restrict__ b1, const float* __restrict__ gw,
                                                            const float* __restrict__ gb, const float* __restrict__ w2,
-                                                           float* __restrict__ dw1, float* __restrict__ db1,
-                                                           float* __restrict__ dgw, float* __restrict__ dgb,
-                                                           float* __restrict__ dw2, float* __restrict__ db2) {
+                                                           float* __restrict__ part) {
+  // every block writes one partial row [PART_STRIDE] = dw1 | db1 | dgamma | dbeta | dw2 | db2 (plain stores);
+  // resblock_param_reduce_kernel sums the rows in a fixed order.  (fp32 atomics from 512 blocks onto the same 54
+  // cache lines serialised in L2 and cost 8x the kernel's compute.)
+  float* const dw1 = part + (long)blockIdx.x * PART_STRIDE + OFF_W1;
+  float* const db1 = part + (long)blockIdx.x * PART_STRIDE + OFF_B1;
+  float* const dgw = part + (long)blockIdx.x * PART_STRIDE + OFF_GW;
+  float* const dgb = part + (long)blockIdx.x * PART_STRIDE + OFF_GB;
+  float* const dw2 = part + (long)blockIdx.x * PART_STRIDE + OFF_W2;
+  float* const db2 = part + (long)blockIdx.x * PART_STRIDE + OFF_B2;
   __shared__ SmemT<true> s;
   const int tid = threadIdx.x, py = tid >> 4, px = tid & 15, lane = tid & 63, wave = tid >> 6;
   const int cp = tid >> 4, sl = tid & 15;          // sweep role: channel pair / pixel row
@@ -285,21 +301,26 @@ __global__ __launch_bounds__(256) void resblock_bwd_kernel(const float* __restri
           s.xh[cc][tid] = xh;
           s.tile[cc][py + 1][px + 1] = gelu_f(u);
           // d_h2[c] = sum_o sum_taps w2[o][c][tap] * dh3[o][pixel - tap + 1]
+#ifndef NEKO_PATCH_DIAG_NODH2
           const float a = dot27(&s.w2[c * 28], nb3, 0.f);
+#else
+          const float a = nb3[cc % 27];
+#endif
           const float du = a * gelu_grad_f(u);
           s.du[cc][tid] = du;
-          const float r1 = wave_sum(du * xh), r2 = wave_sum(du);
-          if (lane == 0) { s.red[wave][cc] = r1; s.red[wave][CHUNK + cc] = r2; }
         }
       }
       __syncthreads();
+      // per-channel sums over the patch: chan[cc] = sum du*xhat, chan[32+cc] = sum du
+      chan_reduce32([&](int cc, int p) { return s.du[cc][p] * s.xh[cc][p]; }, &s.chan[0], tid);
+      chan_reduce32([&](int cc, int p) { return s.du[cc][p]; }, &s.chan[CHUNK], tid);
+      __syncthreads();
       if (tid < 2 * CHUNK) {
-        const float v = (s.red[0][tid] + s.red[1][tid]) + (s.red[2][tid] + s.red[3][tid]);
-        s.chan[tid] = v;
         const int c = k * CHUNK + (tid & (CHUNK - 1));
-        s.acc_gn[(tid < CHUNK ? 0 : C) + c] += v;      // [0,C) dgamma, [C,2C) dbeta
+        s.acc_gn[(tid < CHUNK ? 0 : C) + c] += s.chan[tid];      // [0,C) dgamma, [C,2C) dbeta
       }
       // ---- dW2 sweep: a2[o*9+tap][e] += dh3[o][px] * h2[2cp+e][px + tap - 1] over pixel row sl ------------------
+#ifndef NEKO_PATCH_DIAG_NOSWEEP
       {
         const int c0 = 2 * cp;
 #pragma unroll 2
@@ -317,6 +338,7 @@ __global__ __launch_bounds__(256) void resblock_bwd_kernel(const float* __restri
             }
         }
       }
+#endif
       __syncthreads();
       // ---- d_h1 = rstd_g * (du*gamma - A_g/N - xhat*B_g/N) in place of du (own pixel) -------------------------
 #pragma unroll 1
@@ -337,6 +359,7 @@ __global__ __launch_bounds__(256) void resblock_bwd_kernel(const float* __restri
       }
       __syncthreads();
       // ---- dW1 / db1 sweep: a1[i*9+tap][e] += d_h1[2cp+e][px] * gx[i][px + tap - 1] over pixel row sl -----------
+#ifndef NEKO_PATCH_DIAG_NOSWEEP
       {
         const int c0 = 2 * cp;
 #pragma unroll 2
@@ -357,6 +380,7 @@ __global__ __launch_bounds__(256) void resblock_bwd_kernel(const float* __restri
               }
         }
       }
+#endif
     }   // patches
 
     // ---- combine the 16 pixel-row slices of every channel pair (lanes tid%16) and flush the chunk ------------------
@@ -380,20 +404,47 @@ __global__ __launch_bounds__(256) void resblock_bwd_kernel(const float* __restri
         const int c = k * CHUNK + 2 * cp + e;
 #pragma unroll
         for (int i = 0; i < 27; ++i) {
-          atomicAdd(dw2 + ((i / 9) * C + c) * 9 + (i % 9), a2[i][e]);      // i = o*9 + tap
-          atomicAdd(dw1 + (c * 3 + (i / 9)) * 9 + (i % 9), a1[i][e]);      // i = in*9 + tap
+          dw2[((i / 9) * C + c) * 9 + (i % 9)] = a2[i][e];      // i = o*9 + tap
+          dw1[(c * 3 + (i / 9)) * 9 + (i % 9)] = a1[i][e];      // i = in*9 + tap
         }
-        atomicAdd(db1 + c, ab[e]);
+        db1[c] = ab[e];
       }
     }
   }   // chunks
 
   __syncthreads();
   if (tid < C) {
-    atomicAdd(dgw + tid, s.acc_gn[tid]);
-    atomicAdd(dgb + tid, s.acc_gn[C + tid]);
+    dgw[tid] = s.acc_gn[tid];
+    dgb[tid] = s.acc_gn[C + tid];
   }
-  if (tid < 3) atomicAdd(db2 + tid, s.acc_b2[tid]);
+  if (tid < 3) db2[tid] = s.acc_b2[tid];
+}
+
+// grads (+)= sum over the per-block partial rows; thread per element, coalesced across elements
+__global__ __launch_bounds__(256) void resblock_param_reduce_kernel(const float* __restrict__ part, int nblk,
+                                                                    float* __restrict__ dw1, float* __restrict__ db1,
+                                                                    float* __restrict__ dgw, float* __restrict__ dgb,
+                                                                    float* __restrict__ dw2, float* __restrict__ db2) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= PART_USED) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int b = 0;
+  for (; b + 3 < nblk; b += 4) {
+    s0 += part[(long)b * PART_STRIDE + j];
+    s1 += part[(long)(b + 1) * PART_STRIDE + j];
+    s2 += part[(long)(b + 2) * PART_STRIDE + j];
+    s3 += part[(long)(b + 3) * PART_STRIDE + j];
+  }
+  for (; b < nblk; ++b) s0 += part[(long)b * PART_STRIDE + j];
+  const float v = (s0 + s1) + (s2 + s3);
+  float* dst;
+  if (j < OFF_B1) dst = dw1 + j;
+  else if (j < OFF_GW) dst = db1 + (j - OFF_B1);
+  else if (j < OFF_GB) dst = dgw + (j - OFF_GW);
+  else if (j < OFF_W2) dst = dgb + (j - OFF_GB);
+  else if (j < OFF_B2) dst = dw2 + (j - OFF_W2);
+  else dst = db2 + (j - OFF_B2);
+  *dst += v;
 }
 
 __global__ void patch_pos_add_kernel(float* __restrict__ out, const int* __restrict__ hpos, const int* __restrict__ wpos,
@@ -450,17 +501,25 @@ int neko_patch_resblock_fwd_impl(const void* images, int images_are_u8, int n, i
   return NEKO_OK;
 }
 
+// blocks (= partial rows) the backward uses for P patches; workspace = blocks * neko_patch_resblock_ws_stride floats
+int neko_patch_resblock_bwd_blocks_impl(int P) { return P < 512 ? (P < 1 ? 1 : P) : 512; }
+int neko_patch_resblock_ws_stride_impl() { return PART_STRIDE; }
+
 int neko_patch_resblock_bwd_impl(const float* x_patches, const float* dy, int P, const float* w1, const float* b1,
                                  const float* gn_w, const float* gn_b, const float* w2, const float* b2,
                                  int mid_channels, int num_groups, float* dw1, float* db1, float* dgn_w, float* dgn_b,
-                                 float* dw2, float* db2, hipStream_t s) {
+                                 float* dw2, float* db2, float* workspace, hipStream_t s) {
   (void)b2;
   if (P <= 0) return NEKO_OK;
-  if (!x_patches || !dy || !w1 || !b1 || !gn_w || !gn_b || !w2 || !dw1 || !db1 || !dgn_w || !dgn_b || !dw2 || !db2)
+  if (!x_patches || !dy || !w1 || !b1 || !gn_w || !gn_b || !w2 || !dw1 || !db1 || !dgn_w || !dgn_b || !dw2 || !db2 ||
+      !workspace)
     return NEKO_ERR_ARG;
   if (mid_channels != C || num_groups != G) return NEKO_ERR_UNSUPPORTED;
-  const int grid = P < 512 ? P : 512;
-  hipLaunchKernelGGL(resblock_bwd_kernel, dim3(grid), dim3(256), 0, s, x_patches, dy, P, w1, b1, gn_w, gn_b, w2, dw1,
+  const int grid = neko_patch_resblock_bwd_blocks_impl(P);
+  hipLaunchKernelGGL(resblock_bwd_kernel, dim3(grid), dim3(256), 0, s, x_patches, dy, P, w1, b1, gn_w, gn_b, w2,
+                     workspace);
+  NEKO_CHECK_LAUNCH();
+  hipLaunchKernelGGL(resblock_param_reduce_kernel, dim3((PART_USED + 255) / 256), dim3(256), 0, s, workspace, grid, dw1,
                      db1, dgn_w, dgn_b, dw2, db2);
   NEKO_CHECK_LAUNCH();
   return NEKO_OK;

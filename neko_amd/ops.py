@@ -254,8 +254,9 @@ def patch_resblock_fwd(images, w1, b1, gw, gb, w2, b2, mid, groups, want_x=True)
 
 def patch_resblock_bwd(xp, dy, w1, b1, gw, gb, w2, b2, mid, groups, dw1, db1, dgw, dgb, dw2, db2):
     _chk(dy, torch.float32, "dy")
+    ws = torch.empty(_lib.load().neko_patch_resblock_bwd_ws_floats(xp.shape[0]), dtype=torch.float32, device=xp.device)
     _lib.call("neko_patch_resblock_bwd", _p(xp), _p(dy), xp.shape[0], _p(w1), _p(b1), _p(gw), _p(gb), _p(w2), _p(b2),
-              mid, groups, _p(dw1), _p(db1), _p(dgw), _p(dgb), _p(dw2), _p(db2), _stream())
+              mid, groups, _p(dw1), _p(db1), _p(dgw), _p(dgb), _p(dw2), _p(db2), _p(ws), _stream())
 
 
 def patch_pos_add(out, hpos, wpos, row_emb, col_emb):
