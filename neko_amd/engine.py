@@ -276,6 +276,7 @@ def lm_head_backward(Hp: HeadParams, hf16: torch.Tensor, dlogits: torch.Tensor, 
     M, d = hf16.shape
     go = grad_out.reshape(1).to(F32)
     dhf = torch.empty(M, d, dtype=F32, device=hf16.device)
-    ops.gemm(dlogits, Hp.w, M, d, Hp.Vpad, b_kstrided=True, ldb=d, out_f32=dhf, alpha_dev=go)
+    sk, kps = ops.pick_splitk(M, d, Hp.Vpad)          # few output tiles, K = vocabulary: fill the CUs
+    ops.gemm(dlogits, Hp.w, M, d, Hp.Vpad, b_kstrided=True, ldb=d, out_f32=dhf, alpha_dev=go, splitk=sk, k_per_split=kps)
     _wgrad(dlogits, hf16, Hp.Vpad, d, M, Hp.g_w, alpha_dev=go)
     return dhf

@@ -62,17 +62,30 @@ def dropout_f32(x, drop, out=None):
     return y
 
 
-def pick_splitk(M: int, N: int, K: int, target_blocks: int = 512) -> tuple:
-    """Split-K factor for skinny-output / long-K GEMMs (wgrad): enough blocks to fill 256 CUs."""
-    tiles = ((M + 127) // 128) * ((N + 127) // 128)
-    if tiles >= target_blocks // 2 or K <= 512:
+def pick_splitk(M: int, N: int, K: int, target_blocks: int = 256) -> tuple:
+    """Split-K factor for skinny-output / long-K GEMMs (weight gradients, LM-head dH).  Split-K launches run the
+    256x256 tile, one block per CU (gemm_glds.hip: launch()), so the model is: rounds of `target_blocks` tiles,
+    each k-step of 32 costing ~1.05 us per round, plus the fixed-order workspace reduce (write + read at ~4 TB/s).
+    Returns (splitk, k_per_split) with k_per_split a multiple of 64, or (1, 0)."""
+    if K < 4096:
         return 1, 0
-    sk = min((target_blocks + tiles - 1) // tiles, (K + 255) // 256)
-    if sk <= 1:
+    tiles = ((M + 255) // 256) * ((N + 255) // 256)
+    if tiles >= 2 * target_blocks:
         return 1, 0
-    kps = ((K + sk - 1) // sk + 63) // 64 * 64
-    sk = (K + kps - 1) // kps
-    return (sk, kps) if sk > 1 else (1, 0)
+    best_t, best = None, (1, 0)
+    for sk in range(1, 33):
+        kps = ((K + sk - 1) // sk + 63) // 64 * 64
+        if (K + kps - 1) // kps != sk:
+            continue
+        if sk > 1 and kps < 1024:
+            break
+        rounds = (tiles * sk + target_blocks - 1) // target_blocks
+        t = rounds * kps * (1.05e-6 / 32)
+        if sk > 1:
+            t += 2.0 * sk * M * N * 4 / 4e12 + 4e-6
+        if best_t is None or t < best_t * 0.97:          # prefer the smaller split on near-ties
+            best_t, best = t, ((sk, kps) if sk > 1 else (1, 0))
+    return best
 
 
 def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, a_kstrided=False, b_kstrided=False,

@@ -31,6 +31,15 @@ SHAPES = [
     ("lm logits NT", 4096, V, D, False, False, "f32,ldc=%d" % VP),
     ("lm dH     NN", M, D, VP, False, True, "f32"),
     ("lm dW     TN", VP, D, M, True, True, "acc"),
+    ("rl k768   NN", M, 1024, 768, False, True, "bf16"),
+    ("rl k768   NT", M, 1024, 768, False, False, "bf16"),
+    ("rl k4096  NN", M, 1024, 4096, False, True, "bf16"),
+    ("rl k4096  NT", M, 1024, 4096, False, False, "bf16"),
+    ("rl k4096  TN", M, 1024, 4096, True, True, "bf16"),
+    ("sq4k      NT", 4096, 4096, 4096, False, False, "bf16"),
+    ("sq8k      NT", 8192, 8192, 8192, False, False, "bf16"),
+    ("sq8k      NN", 8192, 8192, 8192, False, True, "bf16"),
+    ("sq8k      TN", 8192, 8192, 8192, True, True, "bf16"),
 ]
 
 
@@ -39,6 +48,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--only", default="")
     ap.add_argument("--safe", type=int, default=0)
+    ap.add_argument("--sk", type=int, default=0, help="force this split-K factor on the split-K shapes")
     args = ap.parse_args()
     dev = "cuda"
     g = torch.Generator(device=dev).manual_seed(0)
@@ -67,6 +77,10 @@ def main():
             kw["ldcf"] = ldc
         if "splitk" in ex:
             sk, kps = ops.pick_splitk(m, n, k)
+            if args.sk:
+                sk = args.sk
+                kps = ((k + sk - 1) // sk + 63) // 64 * 64
+                sk = (k + kps - 1) // kps
             kw.update(splitk=sk, k_per_split=kps, accumulate=(sk == 1))
         if "acc" in ex:
             kw["accumulate"] = True
