@@ -40,6 +40,12 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
   return (bf16_t)(pack_bf16x2(f, 0.0f) & 0xffffu);
 }
+// 8 floats -> one MFMA A/B fragment (element j = v[j])
+__device__ __forceinline__ bf16x8_v pack8_bf16(const float (&v)[8]) {
+  typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_v;
+  const u32x4_v u = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+  return __builtin_bit_cast(bf16x8_v, u);
+}
 
 // ---- wave64 reductions ---------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {

@@ -135,17 +135,86 @@ __device__ __forceinline__ void conv1_stats_chunk(Smem& s, int k, const float (&
   __syncthreads();
 }
 
+// ---- MFMA forward -------------------------------------------------------------------------------------------------
+// Both 3x3 convolutions are dense contractions over (input channel, tap) and run on v_mfma_f32_32x32x16_bf16 with bf16
+// operands and fp32 accumulation (the reference runs them in bf16 under autocast):
+//   conv1  H1^T[c][px] = W1[c][k] * im2col[k][px],  k = (in, dy, dx) padded 27 -> 32; columns 27/28 of the im2col are
+//          1.0 and carry the bias as a bf16 hi + lo pair.  With the CHANNEL as the accumulator row, lane (px, h) holds
+//          rows (r&3) + 8(r>>2) + 4h: every 4 consecutive registers are one GroupNorm group of its pixel.
+//   GN     two-pass statistics from the fp32 accumulators: in-lane over the 4 channels, xor-shuffles over the 32 pixel
+//          lanes, one LDS exchange across the 4 waves (each wave owns 64 of the 256 pixels).
+//   conv2  Z^T[q][px] = W2[q][c] * H2[c][px], q = (out, dy, dx) padded 27 -> 32: the contraction index (channel) may be
+//          permuted freely, so the B fragment of k-step (t, s) is simply bf16(acc[t][.][8s .. 8s+7]) -- no LDS round
+//          trip, no shuffles -- and W2 is staged with the matching channel order.  out[o][p] = b2[o] +
+//          sum_taps Z[(o,tap)][p + tap - 1] is a 27-term shift-sum through a zero-haloed LDS buffer.
+struct FwdSmem {
+  float gx[3][HALO][HALO];                         // GELU(x), zero halo
+  float z[27][HALO][HALO];                         // conv2 partial products per (out, tap), zero halo
+  __attribute__((aligned(16))) float red[2][G][4]; // GroupNorm partials [pass][group][wave]
+  __attribute__((aligned(16))) bf16_t w1[C * 32];  // [c][k] k-contiguous, 16-B piece ^= (c>>2)&3
+  __attribute__((aligned(16))) bf16_t w2[32 * C];  // [q][permuted c], 16-B piece ^= q&15
+  float gw[C], gb[C];
+  __attribute__((aligned(16))) bf16_t im[PS * PS * 32];   // im2col [pixel][k], 16-B piece ^= (pixel>>2)&3
+};
+
+// one pixel's im2col row: k = in*9 + dy*3 + dx from the haloed tile t3[3][18][18] at (py+dy, px+dx), then ones
+__device__ __forceinline__ void write_im2col_row(bf16_t* im, const float* t3, int pix, float one_cols) {
+  const float* base = t3 + (pix >> 4) * HALO + (pix & 15);
+  float v[32];
+#pragma unroll
+  for (int k = 0; k < 32; ++k)
+    v[k] = k < 27 ? base[(k / 9) * HALO * HALO + ((k % 9) / 3) * HALO + (k % 3)] : (k < 29 ? one_cols : 0.f);
+  uint4* row = reinterpret_cast<uint4*>(im + pix * 32);
+#pragma unroll
+  for (int pc = 0; pc < 4; ++pc)
+    row[pc ^ ((pix >> 2) & 3)] = make_uint4(pack_bf16x2(v[8 * pc], v[8 * pc + 1]), pack_bf16x2(v[8 * pc + 2], v[8 * pc + 3]),
+                                            pack_bf16x2(v[8 * pc + 4], v[8 * pc + 5]), pack_bf16x2(v[8 * pc + 6], v[8 * pc + 7]));
+}
+// B fragment (pixel = column) of k-step sidx from an im2col tile: 8 consecutive k of pixel `pix`
+__device__ __forceinline__ bf16x8_v im2col_frag(const bf16_t* im, int pix, int sidx, int h) {
+  return *reinterpret_cast<const bf16x8_v*>(im + pix * 32 + (((2 * sidx + h) ^ ((pix >> 2) & 3)) << 3));
+}
+
+// channel held by lane-half h in register 8s+j of channel tile t (== MFMA accumulator row of H1^T)
+__device__ __forceinline__ int acc_channel(int t, int s, int h, int j) { return 32 * t + (j & 3) + 8 * (2 * s + (j >> 2)) + 4 * h; }
+
+__device__ __forceinline__ void stage_params_mfma(FwdSmem& s, const float* __restrict__ w1, const float* __restrict__ b1,
+                                                  const float* __restrict__ gw, const float* __restrict__ gb,
+                                                  const float* __restrict__ w2, int tid) {
+  for (int i = tid; i < C * 32; i += 256) {
+    const int c = i >> 5, k = i & 31;
+    float v = 0.f;
+    if (k < 27) v = w1[c * 27 + k];
+    else if (k == 27) v = bf16_to_f32(f32_to_bf16(b1[c]));
+    else if (k == 28) v = b1[c] - bf16_to_f32(f32_to_bf16(b1[c]));
+    s.w1[c * 32 + ((((k >> 3) ^ ((c >> 2) & 3)) << 3) | (k & 7))] = f32_to_bf16(v);
+  }
+  for (int i = tid; i < 32 * C; i += 256) {
+    const int q = i >> 7, slot = i & 127;          // slot = ((t*2+s)*2+h)*8 + j
+    const int j = slot & 7, h = (slot >> 3) & 1, sidx = (slot >> 4) & 1, t = slot >> 5;
+    const int c = acc_channel(t, sidx, h, j);
+    const float v = q < 27 ? w2[((q / 9) * C + c) * 9 + (q % 9)] : 0.f;     // conv2.weight [o][c][3][3]
+    s.w2[q * C + ((((slot >> 3) ^ (q & 15)) << 3) | j)] = f32_to_bf16(v);
+  }
+  if (tid < C) { s.gw[tid] = gw[tid]; s.gb[tid] = gb[tid]; }
+}
+
 template <bool U8>
 __global__ __launch_bounds__(256, 2) void resblock_fwd_kernel(const void* __restrict__ images, int n, int H, int W,
                                                            const float* __restrict__ w1, const float* __restrict__ b1,
                                                            const float* __restrict__ gw, const float* __restrict__ gb,
                                                            const float* __restrict__ w2, const float* __restrict__ b2,
                                                            bf16_t* __restrict__ y16, float* __restrict__ xp) {
-  __shared__ SmemT<false> s;
-  const int tid = threadIdx.x, py = tid >> 4, px = tid & 15;
+  __shared__ FwdSmem s;
+  const int tid = threadIdx.x, py = tid >> 4, px = tid & 15, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, l32 = lane & 31;
   const int nh = H / PS, nw = W / PS, P = n * nh * nw;
-  zero_halos(s, tid);
-  stage_params(s, w1, b1, gw, gb, w2, tid);
+  for (int i = tid; i < 3 * HALO * HALO; i += 256) (&s.gx[0][0][0])[i] = 0.f;
+  for (int i = tid; i < 27 * HALO * HALO; i += 256) (&s.z[0][0][0])[i] = 0.f;
+  stage_params_mfma(s, w1, b1, gw, gb, w2, tid);
+  const float bias2[3] = {b2[0], b2[1], b2[2]};
+  const float inv_n = 1.0f / (float)(CPG * PS * PS);
+
   for (int p = blockIdx.x; p < P; p += gridDim.x) {
     const int b = p / (nh * nw), ph = (p / nw) % nh, pw = p % nw;
     float xv[3];
@@ -158,60 +227,128 @@ __global__ __launch_bounds__(256, 2) void resblock_fwd_kernel(const void* __rest
       xv[i] = __fsub_rn(__fmul_rn(__fdiv_rn(raw, 255.0f), 2.0f), 1.0f) * 0.25f;
       if (xp) xp[(long)p * 768 + i * 256 + tid] = xv[i];
     }
-    __syncthreads();   // previous patch finished with the LDS tiles
+    __syncthreads();   // previous patch finished reading gx / z
 #pragma unroll
     for (int i = 0; i < 3; ++i) s.gx[i][py + 1][px + 1] = gelu_f(xv[i]);
     __syncthreads();
-    float nb[27];
+    write_im2col_row(s.im, &s.gx[0][0][0], tid, 1.0f);      // rows 64w .. 64w+63 are written and read by wave w only
+
+    // ---- conv1: this wave's 2 pixel tiles x 4 channel tiles -----------------------------------------------------
+    f32x16 acc[4][2];
+    {
+      bf16x8_v bfr[2][2];
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
+      for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+        for (int sidx = 0; sidx < 2; ++sidx) bfr[pt][sidx] = im2col_frag(s.im, 64 * wave + 32 * pt + l32, sidx, h);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        bf16x8_v afr[2];
+#pragma unroll
+        for (int sidx = 0; sidx < 2; ++sidx) {
+          const int c = 32 * t + l32;
+          afr[sidx] = *reinterpret_cast<const bf16x8_v*>(&s.w1[c * 32 + (((2 * sidx + h) ^ ((c >> 2) & 3)) << 3)]);
+        }
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[t][pt][r] = 0.f;
+#pragma unroll
+          for (int sidx = 0; sidx < 2; ++sidx)
+            acc[t][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[sidx], bfr[pt][sidx], acc[t][pt], 0, 0, 0);
+        }
+      }
+    }
+    // ---- GroupNorm statistics: group (t, qq, h) = channels 32t + 8qq + 4h + {0..3}, all 256 pixels ------------------
+    // pass 0: subtract the group mean in place; pass 1: scale by rstd in place (acc becomes xhat)
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+          float v = 0.f;
+#pragma unroll
+          for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float x = acc[t][pt][4 * qq + e];
+              v = pass == 0 ? v + x : fmaf(x, x, v);
+            }
+#pragma unroll
+          for (int m = 1; m < 32; m <<= 1) v += __shfl_xor(v, m, 64);
+          if (l32 == 0) s.red[pass][8 * t + 2 * qq + h][wave] = v;
+          if (qq == 3) __builtin_amdgcn_sched_barrier(0);     // bound the live shuffle chains (register pressure)
+        }
+      __syncthreads();
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+          const float4 r4 = *reinterpret_cast<const float4*>(&s.red[pass][8 * t + 2 * qq + h][0]);
+          const float tot = ((r4.x + r4.y) + (r4.z + r4.w)) * inv_n;
+          const float k = pass == 0 ? tot : rsqrtf(tot + GN_EPS);
+#pragma unroll
+          for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              acc[t][pt][4 * qq + e] = pass == 0 ? acc[t][pt][4 * qq + e] - k : acc[t][pt][4 * qq + e] * k;
+          if (qq == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // ---- h2 = GELU(GN(h1)) in registers -> conv2 partial products Z^T[q][px] -----------------------------------------
+    f32x16 zacc[2];
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) zacc[pt][r] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+      for (int sidx = 0; sidx < 2; ++sidx) {
+        float gwv[8], gbv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int c = acc_channel(t, sidx, h, j);
+          gwv[j] = s.gw[c];
+          gbv[j] = s.gb[c];
+        }
+        const int q = l32;
+        const bf16x8_v afr = *reinterpret_cast<const bf16x8_v*>(&s.w2[q * C + (((((t * 2 + sidx) * 2 + h)) ^ (q & 15)) << 3)]);
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) {
+          float v[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            v[j] = gelu_f(fmaf(acc[t][pt][8 * sidx + j], gwv[j], gbv[j]));
+            if (j == 3) __builtin_amdgcn_sched_barrier(0);     // 4 GELUs in flight at a time (register pressure)
+          }
+          zacc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, pack8_bf16(v), zacc[pt], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+    // ---- shift-sum: Z^T rows q = (r&3) + 8(r>>2) + 4h of this lane's pixel -> haloed LDS, then 27 taps per output -----
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt) {
+      const int pix = 64 * wave + 32 * pt + l32;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int q = (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (q < 27) s.z[q][(pix >> 4) + 1][(pix & 15) + 1] = zacc[pt][r];
+      }
+    }
+    __syncthreads();
+    float o[3] = {bias2[0], bias2[1], bias2[2]};
+#pragma unroll
+    for (int oc = 0; oc < 3; ++oc)
 #pragma unroll
       for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-        for (int dx = 0; dx < 3; ++dx) nb[i * 9 + dy * 3 + dx] = s.gx[i][py + dy][px + dx];
-    float o0 = b2[0], o1 = b2[1], o2 = b2[2];
-#pragma unroll 1
-    for (int k = 0; k < C / CHUNK; ++k) {
-      conv1_stats_chunk(s, k, nb, py, px, tid);
-      // h2 = GELU(GN(h1)) in place (own pixel)
-#pragma unroll 1
-      for (int g = 0; g < CHUNK / CPG; ++g) {
-        const float m = s.mean[g], rs = s.rstd[g];
-#pragma unroll
-        for (int j = 0; j < CPG; ++j) {
-          const int cc = g * CPG + j, c = k * CHUNK + cc;
-          const float v = (s.tile[cc][py + 1][px + 1] - m) * rs;
-          s.tile[cc][py + 1][px + 1] = gelu_f(fmaf(v, s.gw[c], s.gb[c]));
-        }
-      }
-      __syncthreads();
-      // conv2 partial over the chunk's channels
-#pragma unroll 2
-      for (int cc = 0; cc < CHUNK; ++cc) {
-        const int c = k * CHUNK + cc;
-        float wv[28];
-        const float4* w4 = reinterpret_cast<const float4*>(&s.w2[c * 28]);
-#pragma unroll
-        for (int q = 0; q < 7; ++q) {
-          const float4 a = w4[q];
-          wv[4 * q] = a.x; wv[4 * q + 1] = a.y; wv[4 * q + 2] = a.z; wv[4 * q + 3] = a.w;
-        }
-#pragma unroll
-        for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-          for (int dx = 0; dx < 3; ++dx) {
-            const float v = s.tile[cc][py + dy][px + dx];
-            const int t = dy * 3 + dx;
-            o0 = fmaf(wv[t], v, o0);
-            o1 = fmaf(wv[9 + t], v, o1);
-            o2 = fmaf(wv[18 + t], v, o2);
-          }
-      }
-      __syncthreads();   // tile is rewritten by the next chunk
-    }
-    y16[(long)p * 768 + 0 * 256 + tid] = f32_to_bf16(xv[0] + o0);
-    y16[(long)p * 768 + 1 * 256 + tid] = f32_to_bf16(xv[1] + o1);
-    y16[(long)p * 768 + 2 * 256 + tid] = f32_to_bf16(xv[2] + o2);
+        for (int dx = 0; dx < 3; ++dx) o[oc] += s.z[oc * 9 + dy * 3 + dx][py + dy][px + dx];
+    y16[(long)p * 768 + 0 * 256 + tid] = f32_to_bf16(xv[0] + o[0]);
+    y16[(long)p * 768 + 1 * 256 + tid] = f32_to_bf16(xv[1] + o[1]);
+    y16[(long)p * 768 + 2 * 256 + tid] = f32_to_bf16(xv[2] + o[2]);
   }
 }
 

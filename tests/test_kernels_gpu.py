@@ -298,7 +298,8 @@ def test_patch_resblock_fwd_bwd(ops, u8):
     img_in = imgs.to(torch.uint8).to(DEV) if u8 else imgs.to(DEV)
     y16, xpd = ops.patch_resblock_fwd(img_in, *[dev[n] for n in names], 128, 32)
     close(xpd, xp.reshape(-1, 768), 1e-6, 1e-6, "normalised patches")
-    close(y16, y_ref, 2 ** -8, 2e-4, "resblock fwd")
+    # convolutions run on bf16 MFMA (fp32 accumulate), the block output is bf16: bf16-level tolerance
+    close(y16, y_ref.detach(), 2 ** -7, 3e-3 * float(y_ref.detach().abs().max()), "resblock fwd")
     grads = {n: torch.zeros_like(dev[n]) for n in names}
     ops.patch_resblock_bwd(xpd, dy.to(DEV), *[dev[n] for n in names], 128, 32, *[grads[n] for n in names])
     for nme in names:
