@@ -66,7 +66,7 @@ __device__ __forceinline__ float wave_max(float v) {
 // gelu and gelu' share one exponential: exp(-(x/sqrt2)^2) == exp(-x^2/2).
 __device__ __forceinline__ void erf_exp_parts(float x, float& erf_z, float& e) {
   const float z = fabsf(x) * 0.70710678118654752440f;
-  const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));   // v_rcp_f32 (1 ulp); __frcp_rn is a 10-instruction IEEE divide
   e = __expf(-z * z);
   float poly = fmaf(t, 1.061405429f, -1.453152027f);
   poly = fmaf(poly, t, 1.421413741f);

@@ -4,16 +4,15 @@
 // x + conv3x3(3<-C)(GELU(GroupNorm(conv3x3(C<-3)(GELU(x)))))), PatchPosEncoding's lookup/add (:101-110)
 // and their autograd.  The 768->d projection (:53) runs on the bf16 GEMM.
 //
-// One 256-thread block = one 16x16 patch, one thread = one pixel.  The C=128 mid channels are processed in
-// 4 chunks of 32 (GroupNorm groups of 4 channels are chunk-local): conv1 writes the chunk's raw activations
-// into a haloed LDS tile, the group statistics are two-pass block reductions, GELU(GN(.)) is applied in
-// place and the second conv accumulates its 3 outputs over the chunk.  Conv/GN parameters are staged in LDS
-// once per block and read as wave-uniform broadcasts; every inner loop is dynamic with a small body (an
-// earlier fully-unrolled register-resident version spilled thousands of SGPRs/VGPRs).  Nothing but the
-// normalised patch (768 floats) is kept for backward: the backward kernel recomputes the block chunk by
-// chunk and produces all six parameter gradients in one pass (weight gradients by "one output per thread"
-// sweeps over LDS tiles, accumulated in registers over the patches a block walks, then f32 atomics).
-// <2 % of the model FLOPs: fp32 VALU, no MFMA reshaping.
+// One 256-thread block (4 waves) walks 16x16 patches; wave w owns pixels 64w .. 64w+63.  Both 3x3 convolutions and
+// both weight gradients are dense contractions over (channel, tap) or over pixels and run on
+// v_mfma_f32_32x32x16_bf16 (bf16 operands, fp32 accumulation -- the reference runs these convolutions in bf16 under
+// autocast); GroupNorm statistics, GELU and the GroupNorm backward stay fp32 on the accumulator
+// registers.  On the m-mix batch the image path is ~12k patches per step: the earlier fp32 VALU version of these two
+// kernels was 18 % of the step, this one is ~3 %.  Nothing but the normalised patch (768 floats) is kept for
+// backward: the backward kernel recomputes conv1/GroupNorm tile by tile and produces all six parameter gradients in
+// one pass (per-block partial rows, summed in a fixed order by resblock_param_reduce_kernel).
+#include <type_traits>
 #include "neko_kernels.h"
 
 namespace {
@@ -23,117 +22,10 @@ constexpr int G = 32;         // GroupNorm groups  -> 4 channels per group
 constexpr int CPG = C / G;
 constexpr int PS = 16;        // patch size
 constexpr int HALO = PS + 2;  // 18
-constexpr int CHUNK = 32;     // channels per LDS chunk
 constexpr float GN_EPS = 1e-5f;
 // layout of one per-block partial-gradient row of the backward kernel
 constexpr int OFF_W1 = 0, OFF_B1 = 128 * 27, OFF_GW = OFF_B1 + 128, OFF_GB = OFF_GW + 128, OFF_W2 = OFF_GB + 128,
               OFF_B2 = OFF_W2 + 3 * 128 * 9, PART_USED = OFF_B2 + 3, PART_STRIDE = (PART_USED + 63) / 64 * 64;
-
-// BWD = false drops the two backward-only [32][256] tiles: 83 KB -> two forward blocks per CU
-template <bool BWD>
-struct SmemT {
-  float gx[3][HALO][HALO];        // GELU(x) with zero halo
-  float dh3[BWD ? 3 : 1][BWD ? HALO : 1][BWD ? HALO : 1];   // d(conv2 out) with zero halo (bwd)
-  float tile[CHUNK][HALO][HALO];  // haloed channel chunk: raw h1, then h2 = GELU(GN(h1))
-  float xh[BWD ? CHUNK : 1][PS * PS];       // bwd: xhat of the chunk
-  float du[BWD ? CHUNK : 1][PS * PS];       // bwd: d(GN out), then d(h1)
-  float red[4][2 * CHUNK];        // cross-wave partials
-  float mean[CHUNK / CPG], rstd[CHUNK / CPG];
-  float chan[BWD ? 2 * CHUNK : 1];   // bwd per-patch per-channel sums: [cc] sum(du*xhat), [CHUNK+cc] sum(du)
-  float acc_gn[BWD ? 2 * C : 1];     // bwd block accumulators for dgamma / dbeta
-  float acc_b2[4];
-  // conv / GroupNorm parameters staged once per block (wave-uniform LDS broadcast reads)
-  // rows padded to 28 floats (112 B): a channel's 27 weights are 7 aligned ds_read_b128 broadcasts
-  __attribute__((aligned(16))) float w1[C * 28];   // [c][i*9 + tap]
-  __attribute__((aligned(16))) float w2[C * 28];   // [c][o*9 + tap]  (regrouped per mid channel)
-  float b1[C];
-  float gw[C];
-  float gb[C];
-};
-
-template <class Smem>
-__device__ __forceinline__ void stage_params(Smem& s, const float* __restrict__ w1, const float* __restrict__ b1,
-                                             const float* __restrict__ gw, const float* __restrict__ gb,
-                                             const float* __restrict__ w2, int tid) {
-  for (int i = tid; i < C * 27; i += 256) {
-    const int c = i / 27, t = i % 27;
-    s.w1[c * 28 + t] = w1[i];                                  // conv1.weight [c][3][3][3]
-    s.w2[c * 28 + t] = w2[((t / 9) * C + c) * 9 + (t % 9)];     // conv2.weight [o][c][3][3] -> [c][o][3][3]
-  }
-  if (tid < C) { s.w1[tid * 28 + 27] = 0.f; s.w2[tid * 28 + 27] = 0.f; }
-  if (tid < C) { s.b1[tid] = b1[tid]; s.gw[tid] = gw[tid]; s.gb[tid] = gb[tid]; }
-}
-
-// dot of a channel's 27 (padded to 28) LDS-resident weights with 27 per-thread values
-__device__ __forceinline__ float dot27(const float* __restrict__ w, const float (&v)[27], float acc) {
-  const float4* w4 = reinterpret_cast<const float4*>(w);
-#pragma unroll
-  for (int q = 0; q < 7; ++q) {
-    const float4 a = w4[q];
-    acc = fmaf(a.x, v[4 * q + 0], acc);
-    acc = fmaf(a.y, v[4 * q + 1], acc);
-    acc = fmaf(a.z, v[4 * q + 2], acc);
-    if (q < 6) acc = fmaf(a.w, v[4 * q + 3], acc);
-  }
-  return acc;
-}
-
-template <class Smem>
-__device__ __forceinline__ void zero_halos(Smem& s, int tid) {
-  float* z = &s.gx[0][0][0];
-  for (int i = tid; i < 3 * HALO * HALO; i += 256) z[i] = 0.f;
-  for (int i = tid; i < (int)(sizeof(s.dh3) / sizeof(float)); i += 256) (&s.dh3[0][0][0])[i] = 0.f;
-  float* t = &s.tile[0][0][0];
-  for (int i = tid; i < CHUNK * HALO * HALO; i += 256) t[i] = 0.f;
-}
-
-// out[cc] = sum over the 256 pixels of f(cc, px) for the chunk's 32 channels: 8 threads per channel sum 32 pixels
-// each (rotated start so the lanes of a half-wave hit distinct banks), then 3 in-row xor steps.  Replaces per-channel
-// wave_sum chains (6 dependent cross-lane steps each), which dominated the kernels at one wave per SIMD.
-template <class F>
-__device__ __forceinline__ void chan_reduce32(F f, float* out, int tid) {
-  const int cc = tid >> 3, sub = tid & 7;
-  float a0 = 0.f, a1 = 0.f;
-#pragma unroll 8
-  for (int i = 0; i < 32; i += 2) {
-    a0 += f(cc, sub * 32 + ((i + tid) & 31));
-    a1 += f(cc, sub * 32 + ((i + 1 + tid) & 31));
-  }
-  float a = a0 + a1;
-  a += __shfl_xor(a, 1, 64);
-  a += __shfl_xor(a, 2, 64);
-  a += __shfl_xor(a, 4, 64);
-  if (sub == 0) out[cc] = a;
-}
-
-// conv1 of channel chunk k for this thread's pixel -> raw h1 into the haloed tile, then the GroupNorm
-// statistics of the chunk's 8 groups (two-pass: mean, centred variance) into s.mean / s.rstd.
-// nb = the 27 GELU(x) neighbours of the pixel.  All loops are dynamic on purpose (small live ranges).
-template <class Smem>
-__device__ __forceinline__ void conv1_stats_chunk(Smem& s, int k, const float (&nb)[27], int py, int px, int tid) {
-  constexpr int NG = CHUNK / CPG;
-#pragma unroll 1
-  for (int g = 0; g < NG; ++g) {
-#pragma unroll
-    for (int j = 0; j < CPG; ++j) {
-      const int cc = g * CPG + j, c = k * CHUNK + cc;
-      s.tile[cc][py + 1][px + 1] = dot27(&s.w1[c * 28], nb, s.b1[c]);
-    }
-  }
-  __syncthreads();
-  float* csum = &s.red[0][0];      // 32 per-channel sums
-  chan_reduce32([&](int cc, int p) { return s.tile[cc][(p >> 4) + 1][(p & 15) + 1]; }, csum, tid);
-  __syncthreads();
-  const float inv_n = 1.0f / (float)(CPG * PS * PS);
-  if (tid < NG) s.mean[tid] = ((csum[4 * tid] + csum[4 * tid + 1]) + (csum[4 * tid + 2] + csum[4 * tid + 3])) * inv_n;
-  __syncthreads();
-  chan_reduce32([&](int cc, int p) { const float d = s.tile[cc][(p >> 4) + 1][(p & 15) + 1] - s.mean[cc / CPG]; return d * d; },
-                csum, tid);
-  __syncthreads();
-  if (tid < NG)
-    s.rstd[tid] = rsqrtf(((csum[4 * tid] + csum[4 * tid + 1]) + (csum[4 * tid + 2] + csum[4 * tid + 3])) * inv_n + GN_EPS);
-  __syncthreads();
-}
 
 // ---- MFMA forward -------------------------------------------------------------------------------------------------
 // Both 3x3 convolutions are dense contractions over (input channel, tap) and run on v_mfma_f32_32x32x16_bf16 with bf16
@@ -157,13 +49,18 @@ struct FwdSmem {
   __attribute__((aligned(16))) bf16_t im[PS * PS * 32];   // im2col [pixel][k], 16-B piece ^= (pixel>>2)&3
 };
 
-// one pixel's im2col row: k = in*9 + dy*3 + dx from the haloed tile t3[3][18][18] at (py+dy, px+dx), then ones
+// one pixel's im2col row [32] (bf16): k = ch*9 + dy*3 + dx < 27 from the haloed tile t3[3][18][18], columns 27/28 =
+// one_cols, rest 0.  FLIP = false: t3[ch][py+dy][px+dx] (forward neighbourhood); FLIP = true: t3[ch][py-dy+2][px-dx+2]
+// (the transposed-convolution neighbourhood of the output gradient).
+template <bool FLIP>
 __device__ __forceinline__ void write_im2col_row(bf16_t* im, const float* t3, int pix, float one_cols) {
-  const float* base = t3 + (pix >> 4) * HALO + (pix & 15);
+  const float* base = t3 + ((pix >> 4) + (FLIP ? 2 : 0)) * HALO + (pix & 15) + (FLIP ? 2 : 0);
   float v[32];
 #pragma unroll
-  for (int k = 0; k < 32; ++k)
-    v[k] = k < 27 ? base[(k / 9) * HALO * HALO + ((k % 9) / 3) * HALO + (k % 3)] : (k < 29 ? one_cols : 0.f);
+  for (int k = 0; k < 32; ++k) {
+    const int off = (k / 9) * HALO * HALO + (FLIP ? -1 : 1) * (((k % 9) / 3) * HALO + (k % 3));
+    v[k] = k < 27 ? base[off] : (k < 29 ? one_cols : 0.f);
+  }
   uint4* row = reinterpret_cast<uint4*>(im + pix * 32);
 #pragma unroll
   for (int pc = 0; pc < 4; ++pc)
@@ -231,7 +128,7 @@ __global__ __launch_bounds__(256, 2) void resblock_fwd_kernel(const void* __rest
 #pragma unroll
     for (int i = 0; i < 3; ++i) s.gx[i][py + 1][px + 1] = gelu_f(xv[i]);
     __syncthreads();
-    write_im2col_row(s.im, &s.gx[0][0][0], tid, 1.0f);      // rows 64w .. 64w+63 are written and read by wave w only
+    write_im2col_row<false>(s.im, &s.gx[0][0][0], tid, 1.0f);      // rows 64w .. 64w+63 are written and read by wave w only
 
     // ---- conv1: this wave's 2 pixel tiles x 4 channel tiles -----------------------------------------------------
     f32x16 acc[4][2];
@@ -352,228 +249,341 @@ __global__ __launch_bounds__(256, 2) void resblock_fwd_kernel(const void* __rest
   }
 }
 
-// Backward.  dy f32 [P,768] is the gradient of the block output (= gradient wrt conv2 output; the identity
-// branch reaches only the input image).  Loop order: channel chunk k OUTER, patches (grid-stride) INNER, so only the
-// chunk's weight-gradient accumulators are live in registers; everything per patch is recomputed per chunk (cheap
-// next to the sweeps).  Weight-gradient sweeps are register-blocked: thread (cp, sl) owns channels {2cp, 2cp+1} of
-// the chunk and pixel row sl, and accumulates all (output, tap) / (input, tap) combinations -> 54 FMAs per 21 / 29
-// LDS reads; the 16 row-slices meet in xor-shuffles once per chunk, then one fp32 atomic per weight per block.
-__global__ __launch_bounds__(256) void resblock_bwd_kernel(const float* __restrict__ xp, const float* __restrict__ dy,
-                                                           int P, const float* __restrict__ w1,
-                                                           const float* __restrict__ b1, const float* __restrict__ gw,
-                                                           const float* __restrict__ gb, const float* __restrict__ w2,
-                                                           float* __restrict__ part) {
+// ---- MFMA backward ------------------------------------------------------------------------------------------------
+// dy f32 [P,768] is the gradient of the block output (= gradient wrt conv2's output; the identity branch reaches only
+// the input image).  Nothing but the normalised patch was kept by the forward: per patch and per 32-channel tile t the
+// kernel recomputes conv1 + GroupNorm in registers (same layout as the forward: channel = accumulator row, lane =
+// pixel) and then runs four more small contractions on v_mfma_f32_32x32x16_bf16:
+//   d_h2^T[c][px] = W2[c][q] * dZ[q][px]      q = (out, dy, dx); dZ = flipped im2col of dy (im3)
+//   dW2[q][c]    += dZ[q][px] * h2[px][c]     contraction over this wave's 64 pixels, accumulators live across patches
+//   dW1[c][k]    += d_h1[px][c] * im2col(gelu x)[px][k]   (column 27 of the im2col is 1.0 -> db1 for free)
+// h2 / d_h1 go through wave-private [pixel][channel] bf16 tiles and come back as ds_read_b64_tr_b16 fragments.  The
+// per-channel sums of the GroupNorm backward (sum du, sum du*xhat over 256 pixels) use a 32-value reduce-scatter
+// butterfly over the 32 pixel lanes (31 exchanges instead of 160) and one LDS exchange across the 4 waves.
+struct BwdSmem {
+  float gx[3][HALO][HALO];                            // GELU(x), zero halo
+  float dh3[3][HALO][HALO];                           // dy, zero halo
+  __attribute__((aligned(16))) bf16_t im1[PS * PS * 32];   // im2col of gx       [pixel][k]
+  __attribute__((aligned(16))) bf16_t im3[PS * PS * 32];   // flipped im2col of dy [pixel][q]
+  __attribute__((aligned(16))) bf16_t t2[PS * PS * 32];    // h2 tile   [pixel][32 channels of tile t]
+  __attribute__((aligned(16))) bf16_t t1[PS * PS * 32];    // d_h1 tile [pixel][32 channels of tile t]
+  __attribute__((aligned(16))) bf16_t w1[C * 32];     // [c][k], piece ^= (c>>2)&3 (bias hi/lo in columns 27/28)
+  __attribute__((aligned(16))) bf16_t w2c[C * 32];    // [c][q], piece ^= (c>>2)&3
+  __attribute__((aligned(16))) float red[2][8][4];    // GroupNorm statistics partials [pass][group of tile][wave]
+  float cs[4][2][32];                                 // per-wave channel sums [wave][kind][channel of tile]
+  float cst[2][32];                                   // their totals
+  float gw[C], gb[C];
+  float acc_gn[2][C];                                 // dgamma / dbeta accumulated over the block's patches
+  float fin[3][4];
+};
+
+// tile [row = k][col] with 64-B rows (32 bf16), 16-B piece ^= (row>>2)&3: 32x32x16 MFMA fragment whose 32 rows/cols
+// are the tile COLUMNS and whose k = tile rows 16*ks .. 16*ks+15 (+ rowbase)
+__device__ __forceinline__ bf16x8_v tr_frag32(const bf16_t* tile, int rowbase, int ks, int lane) {
+  const int g = lane >> 4, c16 = lane & 15;
+  const int col = 16 * (g & 1) + 4 * (c16 & 3);
+  const int krow = rowbase + ks * 16 + 8 * (g >> 1) + (c16 >> 2);
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  const char* b = reinterpret_cast<const char*>(tile);
+  const int off_lo = krow * 64 + ((((col >> 3) ^ ((krow >> 2) & 3)) << 4) | ((col & 7) << 1));
+  const int off_hi = (krow + 4) * 64 + ((((col >> 3) ^ (((krow + 4) >> 2) & 3)) << 4) | ((col & 7) << 1));
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(b + off_lo));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(b + off_hi));
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  s16x8 r;
+  r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+  r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+  return __builtin_bit_cast(bf16x8_v, r);
+}
+
+// v[0..31] summed over the 32 lanes that share lane>>5: afterwards lane l32 holds the total of index l32.
+// Recursive template so that every v[] index is a literal (a `half >>= 1` loop is not unrolled by hipcc and turned the
+// register array into 32-way select chains: 7,700 v_cmp/v_cndmask pairs).
+template <int HALF>
+__device__ __forceinline__ void reduce_scatter_step(float (&v)[32], int l32) {
+  const bool up = (l32 & HALF) != 0;
+#pragma unroll
+  for (int i = 0; i < HALF; ++i) {
+    const float keep = up ? v[HALF + i] : v[i];
+    const float send = up ? v[i] : v[HALF + i];
+    v[i] = keep + __shfl_xor(send, HALF, 64);
+  }
+  if constexpr (HALF > 1) reduce_scatter_step<HALF / 2>(v, l32);
+}
+__device__ __forceinline__ float reduce_scatter32(float (&v)[32], int l32) {
+  reduce_scatter_step<16>(v, l32);
+  return v[0];
+}
+
+__global__ __launch_bounds__(256, 1) void resblock_bwd_kernel(const float* __restrict__ xp, const float* __restrict__ dy,
+                                                              int P, const float* __restrict__ w1,
+                                                              const float* __restrict__ b1, const float* __restrict__ gw,
+                                                              const float* __restrict__ gb, const float* __restrict__ w2,
+                                                              float* __restrict__ part) {
   // every block writes one partial row [PART_STRIDE] = dw1 | db1 | dgamma | dbeta | dw2 | db2 (plain stores);
-  // resblock_param_reduce_kernel sums the rows in a fixed order.  (fp32 atomics from 512 blocks onto the same 54
-  // cache lines serialised in L2 and cost 8x the kernel's compute.)
+  // resblock_param_reduce_kernel sums the rows in a fixed order (atomics onto 54 shared lines serialised in L2).
   float* const dw1 = part + (long)blockIdx.x * PART_STRIDE + OFF_W1;
   float* const db1 = part + (long)blockIdx.x * PART_STRIDE + OFF_B1;
   float* const dgw = part + (long)blockIdx.x * PART_STRIDE + OFF_GW;
   float* const dgb = part + (long)blockIdx.x * PART_STRIDE + OFF_GB;
   float* const dw2 = part + (long)blockIdx.x * PART_STRIDE + OFF_W2;
   float* const db2 = part + (long)blockIdx.x * PART_STRIDE + OFF_B2;
-  __shared__ SmemT<true> s;
+  __shared__ BwdSmem s;
   const int tid = threadIdx.x, py = tid >> 4, px = tid & 15, lane = tid & 63, wave = tid >> 6;
-  const int cp = tid >> 4, sl = tid & 15;          // sweep role: channel pair / pixel row
-  zero_halos(s, tid);
-  stage_params(s, w1, b1, gw, gb, w2, tid);
-  for (int i = tid; i < 2 * C; i += 256) s.acc_gn[i] = 0.f;
-  if (tid < 4) s.acc_b2[tid] = 0.f;
+  const int h = lane >> 5, l32 = lane & 31;
+  for (int i = tid; i < 3 * HALO * HALO; i += 256) { (&s.gx[0][0][0])[i] = 0.f; (&s.dh3[0][0][0])[i] = 0.f; }
+  for (int i = tid; i < 2 * C; i += 256) (&s.acc_gn[0][0])[i] = 0.f;
+  for (int i = tid; i < C * 32; i += 256) {
+    const int c = i >> 5, k = i & 31;
+    float v = 0.f;
+    if (k < 27) v = w1[c * 27 + k];
+    else if (k == 27) v = bf16_to_f32(f32_to_bf16(b1[c]));
+    else if (k == 28) v = b1[c] - bf16_to_f32(f32_to_bf16(b1[c]));
+    const int dst = c * 32 + ((((k >> 3) ^ ((c >> 2) & 3)) << 3) | (k & 7));
+    s.w1[dst] = f32_to_bf16(v);
+    s.w2c[dst] = f32_to_bf16(k < 27 ? w2[((k / 9) * C + c) * 9 + (k % 9)] : 0.f);      // conv2.weight [o][c][3][3]
+  }
+  if (tid < C) { s.gw[tid] = gw[tid]; s.gb[tid] = gb[tid]; }
   const float inv_n = 1.0f / (float)(CPG * PS * PS);
 
-#pragma unroll 1
-  for (int k = 0; k < C / CHUNK; ++k) {
-    float a2[27][2], a1[27][2], ab[2];
+  f32x16 dw2acc[4], dw1acc[4];     // [t]: dW2[q][32t + n], dW1[32t + m][k]
 #pragma unroll
-    for (int i = 0; i < 27; ++i) { a2[i][0] = a2[i][1] = 0.f; a1[i][0] = a1[i][1] = 0.f; }
-    ab[0] = ab[1] = 0.f;
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dw2acc[t][r] = 0.f; dw1acc[t][r] = 0.f; }
+  float b2acc[3] = {0.f, 0.f, 0.f};
 
 #pragma unroll 1
-    for (int p = blockIdx.x; p < P; p += gridDim.x) {
-      float g3[3];
-      {
-        float xv[3];
+  for (int p = blockIdx.x; p < P; p += gridDim.x) {
+    {
+      float xv[3], g3[3];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-          xv[i] = xp[(long)p * 768 + i * 256 + tid];
-          g3[i] = dy[(long)p * 768 + i * 256 + tid];
-        }
-        __syncthreads();      // previous (chunk, patch) is done with every LDS tile
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-          s.gx[i][py + 1][px + 1] = gelu_f(xv[i]);
-          s.dh3[i][py + 1][px + 1] = g3[i];
-        }
+      for (int i = 0; i < 3; ++i) {
+        xv[i] = xp[(long)p * 768 + i * 256 + tid];
+        g3[i] = dy[(long)p * 768 + i * 256 + tid];
+        b2acc[i] += g3[i];
       }
-      if (k == 0) {           // db2 once per patch
+      __syncthreads();      // previous patch is done with the halo tiles, cs/cst and red
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-          const float r = wave_sum(g3[i]);
-          if (lane == 0) s.red[wave][i] = r;
-        }
-      }
-      __syncthreads();
-      if (k == 0 && tid < 3) s.acc_b2[tid] += (s.red[0][tid] + s.red[1][tid]) + (s.red[2][tid] + s.red[3][tid]);
-      float nb[27], nb3[27];
-#pragma unroll
-      for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int dy_ = 0; dy_ < 3; ++dy_)
-#pragma unroll
-          for (int dx_ = 0; dx_ < 3; ++dx_) {
-            nb[i * 9 + dy_ * 3 + dx_] = s.gx[i][py + dy_][px + dx_];
-            nb3[i * 9 + dy_ * 3 + dx_] = s.dh3[i][py - dy_ + 2][px - dx_ + 2];
-          }
-      __syncthreads();
-      conv1_stats_chunk(s, k, nb, py, px, tid);
-      // xhat -> s.xh ; h2 -> haloed tile ; du = d(h2)*GELU'(u) -> s.du ; per-channel sums
-#pragma unroll 1
-      for (int g = 0; g < CHUNK / CPG; ++g) {
-        const float m = s.mean[g], rs = s.rstd[g];
-#pragma unroll
-        for (int j = 0; j < CPG; ++j) {
-          const int cc = g * CPG + j, c = k * CHUNK + cc;
-          const float xh = (s.tile[cc][py + 1][px + 1] - m) * rs;
-          const float u = fmaf(xh, s.gw[c], s.gb[c]);
-          s.xh[cc][tid] = xh;
-          s.tile[cc][py + 1][px + 1] = gelu_f(u);
-          // d_h2[c] = sum_o sum_taps w2[o][c][tap] * dh3[o][pixel - tap + 1]
-#ifndef NEKO_PATCH_DIAG_NODH2
-          const float a = dot27(&s.w2[c * 28], nb3, 0.f);
-#else
-          const float a = nb3[cc % 27];
-#endif
-          const float du = a * gelu_grad_f(u);
-          s.du[cc][tid] = du;
-        }
-      }
-      __syncthreads();
-      // per-channel sums over the patch: chan[cc] = sum du*xhat, chan[32+cc] = sum du
-      chan_reduce32([&](int cc, int p) { return s.du[cc][p] * s.xh[cc][p]; }, &s.chan[0], tid);
-      chan_reduce32([&](int cc, int p) { return s.du[cc][p]; }, &s.chan[CHUNK], tid);
-      __syncthreads();
-      if (tid < 2 * CHUNK) {
-        const int c = k * CHUNK + (tid & (CHUNK - 1));
-        s.acc_gn[(tid < CHUNK ? 0 : C) + c] += s.chan[tid];      // [0,C) dgamma, [C,2C) dbeta
-      }
-      // ---- dW2 sweep: a2[o*9+tap][e] += dh3[o][px] * h2[2cp+e][px + tap - 1] over pixel row sl ------------------
-#ifndef NEKO_PATCH_DIAG_NOSWEEP
-      {
-        const int c0 = 2 * cp;
-#pragma unroll 2
-        for (int xx = 0; xx < PS; ++xx) {
-          const float d0 = s.dh3[0][sl + 1][xx + 1], d1 = s.dh3[1][sl + 1][xx + 1], d2 = s.dh3[2][sl + 1][xx + 1];
-#pragma unroll
-          for (int dy_ = 0; dy_ < 3; ++dy_)
-#pragma unroll
-            for (int dx_ = 0; dx_ < 3; ++dx_) {
-              const int t = dy_ * 3 + dx_;
-              const float h0 = s.tile[c0][sl + dy_][xx + dx_], h1 = s.tile[c0 + 1][sl + dy_][xx + dx_];
-              a2[t][0] = fmaf(d0, h0, a2[t][0]);      a2[t][1] = fmaf(d0, h1, a2[t][1]);
-              a2[9 + t][0] = fmaf(d1, h0, a2[9 + t][0]);  a2[9 + t][1] = fmaf(d1, h1, a2[9 + t][1]);
-              a2[18 + t][0] = fmaf(d2, h0, a2[18 + t][0]); a2[18 + t][1] = fmaf(d2, h1, a2[18 + t][1]);
-            }
-        }
-      }
-#endif
-      __syncthreads();
-      // ---- d_h1 = rstd_g * (du*gamma - A_g/N - xhat*B_g/N) in place of du (own pixel) -------------------------
-#pragma unroll 1
-      for (int g = 0; g < CHUNK / CPG; ++g) {
-        float A = 0.f, Bv = 0.f;
-#pragma unroll
-        for (int j = 0; j < CPG; ++j) {
-          const int cc = g * CPG + j;
-          A = fmaf(s.gw[k * CHUNK + cc], s.chan[CHUNK + cc], A);
-          Bv = fmaf(s.gw[k * CHUNK + cc], s.chan[cc], Bv);
-        }
-        const float rs = s.rstd[g];
-#pragma unroll
-        for (int j = 0; j < CPG; ++j) {
-          const int cc = g * CPG + j;
-          s.du[cc][tid] = rs * (s.du[cc][tid] * s.gw[k * CHUNK + cc] - A * inv_n - s.xh[cc][tid] * Bv * inv_n);
-        }
-      }
-      __syncthreads();
-      // ---- dW1 / db1 sweep: a1[i*9+tap][e] += d_h1[2cp+e][px] * gx[i][px + tap - 1] over pixel row sl -----------
-#ifndef NEKO_PATCH_DIAG_NOSWEEP
-      {
-        const int c0 = 2 * cp;
-#pragma unroll 2
-        for (int xx = 0; xx < PS; ++xx) {
-          const float u0 = s.du[c0][sl * 16 + xx], u1 = s.du[c0 + 1][sl * 16 + xx];
-          ab[0] += u0;
-          ab[1] += u1;
-#pragma unroll
-          for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int dy_ = 0; dy_ < 3; ++dy_)
-#pragma unroll
-              for (int dx_ = 0; dx_ < 3; ++dx_) {
-                const int t = i * 9 + dy_ * 3 + dx_;
-                const float gv = s.gx[i][sl + dy_][xx + dx_];
-                a1[t][0] = fmaf(u0, gv, a1[t][0]);
-                a1[t][1] = fmaf(u1, gv, a1[t][1]);
-              }
-        }
-      }
-#endif
-    }   // patches
-
-    // ---- combine the 16 pixel-row slices of every channel pair (lanes tid%16) and flush the chunk ------------------
-#pragma unroll
-    for (int i = 0; i < 27; ++i)
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        float v2 = a2[i][e], v1 = a1[i][e];
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) { v2 += __shfl_xor(v2, o, 64); v1 += __shfl_xor(v1, o, 64); }
-        a2[i][e] = v2;
-        a1[i][e] = v1;
-      }
-#pragma unroll
-    for (int e = 0; e < 2; ++e)
-#pragma unroll
-      for (int o = 8; o > 0; o >>= 1) ab[e] += __shfl_xor(ab[e], o, 64);
-    if (sl == 0) {
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const int c = k * CHUNK + 2 * cp + e;
-#pragma unroll
-        for (int i = 0; i < 27; ++i) {
-          dw2[((i / 9) * C + c) * 9 + (i % 9)] = a2[i][e];      // i = o*9 + tap
-          dw1[(c * 3 + (i / 9)) * 9 + (i % 9)] = a1[i][e];      // i = in*9 + tap
-        }
-        db1[c] = ab[e];
+      for (int i = 0; i < 3; ++i) {
+        s.gx[i][py + 1][px + 1] = gelu_f(xv[i]);
+        s.dh3[i][py + 1][px + 1] = g3[i];
       }
     }
-  }   // chunks
+    __syncthreads();
+    write_im2col_row<false>(s.im1, &s.gx[0][0][0], tid, 1.0f);     // rows 64w .. 64w+63: written and read by wave w only
+    write_im2col_row<true>(s.im3, &s.dh3[0][0][0], tid, 0.0f);
 
+    // one 32-channel tile; t must be a compile-time constant (dw?acc[t] are register arrays): the body is too large
+    // for the unroller's threshold, so it is instantiated four times through a generic lambda instead of a loop
+    auto channel_tile = [&](auto TT) __attribute__((always_inline)) {
+      constexpr int t = decltype(TT)::value;
+      // ---- conv1 recompute (tile t) and d_h2 (tile t) for this wave's 2 pixel tiles -------------------------------
+      f32x16 acc[2], dacc[2];
+      {
+        const int c = 32 * t + l32;
+        bf16x8_v a1[2], a2[2];
+#pragma unroll
+        for (int sidx = 0; sidx < 2; ++sidx) {
+          const int o = c * 32 + (((2 * sidx + h) ^ ((c >> 2) & 3)) << 3);
+          a1[sidx] = *reinterpret_cast<const bf16x8_v*>(&s.w1[o]);
+          a2[sidx] = *reinterpret_cast<const bf16x8_v*>(&s.w2c[o]);
+        }
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) {
+          const int pix = 64 * wave + 32 * pt + l32;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { acc[pt][r] = 0.f; dacc[pt][r] = 0.f; }
+#pragma unroll
+          for (int sidx = 0; sidx < 2; ++sidx) {
+            acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[sidx], im2col_frag(s.im1, pix, sidx, h), acc[pt], 0, 0, 0);
+            dacc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[sidx], im2col_frag(s.im3, pix, sidx, h), dacc[pt], 0, 0, 0);
+          }
+        }
+      }
+      // ---- GroupNorm statistics of the tile's 8 groups (qq, h): mean removed, then scaled by rstd, in place ----------
+      float rstd[4];
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+          float v = 0.f;
+#pragma unroll
+          for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float x = acc[pt][4 * qq + e];
+              v = pass == 0 ? v + x : fmaf(x, x, v);
+            }
+#pragma unroll
+          for (int m = 1; m < 32; m <<= 1) v += __shfl_xor(v, m, 64);
+          if (l32 == 0) s.red[pass][2 * qq + h][wave] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+          const float4 r4 = *reinterpret_cast<const float4*>(&s.red[pass][2 * qq + h][0]);
+          const float tot = ((r4.x + r4.y) + (r4.z + r4.w)) * inv_n;
+          const float k = pass == 0 ? tot : rsqrtf(tot + GN_EPS);
+          if (pass == 1) rstd[qq] = k;
+#pragma unroll
+          for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              acc[pt][4 * qq + e] = pass == 0 ? acc[pt][4 * qq + e] - k : acc[pt][4 * qq + e] * k;
+        }
+      }
+      // ---- h2 = GELU(u), du = d_h2 * GELU'(u), u = xhat*gamma + beta; per-channel sums over this lane's 2 pixels -------
+      float gwv[16], sums[32], tv[2][16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int c = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
+        gwv[r] = s.gw[c];
+        const float gbv = s.gb[c];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) {
+          const float xh = acc[pt][r];
+          const float u = fmaf(xh, gwv[r], gbv);
+          float er, e;
+          erf_exp_parts(u, er, e);
+          const float cdf = 0.5f * (1.0f + er);
+          tv[pt][r] = u * cdf;                                                   // h2
+          const float du = dacc[pt][r] * fmaf(u * 0.39894228040143267794f, e, cdf);
+          dacc[pt][r] = du;                                                      // d(GN out)
+          s1 += du;
+          s2 = fmaf(du, xh, s2);
+        }
+        sums[r] = s1;            // kind 0: sum du      -> dbeta
+        sums[16 + r] = s2;       // kind 1: sum du*xhat -> dgamma
+      }
+      // h2 -> wave-private [pixel][channel] tile: registers 4qq..4qq+3 are channels 8qq + 4h + {0..3}
+#pragma unroll
+      for (int pt = 0; pt < 2; ++pt) {
+        const int pix = 64 * wave + 32 * pt + l32;
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq)
+          *reinterpret_cast<uint2*>(&s.t2[pix * 32 + ((qq ^ ((pix >> 2) & 3)) << 3) + 4 * h]) =
+              make_uint2(pack_bf16x2(tv[pt][4 * qq], tv[pt][4 * qq + 1]), pack_bf16x2(tv[pt][4 * qq + 2], tv[pt][4 * qq + 3]));
+      }
+      {
+        const float tot = reduce_scatter32(sums, l32);       // lane l32 holds index l32 = kind*16 + r
+        const int r = l32 & 15;
+        s.cs[wave][l32 >> 4][(r & 3) + 8 * (r >> 2) + 4 * h] = tot;
+      }
+      __syncthreads();
+      if (tid < 64) {
+        const int kind = tid >> 5, cl = tid & 31;
+        const float v = (s.cs[0][kind][cl] + s.cs[1][kind][cl]) + (s.cs[2][kind][cl] + s.cs[3][kind][cl]);
+        s.cst[kind][cl] = v;
+        s.acc_gn[kind == 1 ? 0 : 1][32 * t + cl] += v;       // [0] dgamma, [1] dbeta
+      }
+      __syncthreads();
+      // ---- d_h1 = rstd_g * (du*gamma - A_g/N - xhat*B_g/N) -> t1 tile ---------------------------------------------
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) {
+        float A = 0.f, Bv = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int cl = e + 8 * qq + 4 * h;
+          A = fmaf(gwv[4 * qq + e], s.cst[0][cl], A);
+          Bv = fmaf(gwv[4 * qq + e], s.cst[1][cl], Bv);
+        }
+        A *= inv_n;
+        Bv *= inv_n;
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * qq + e;
+            tv[pt][r] = rstd[qq] * (fmaf(dacc[pt][r], gwv[r], -A) - acc[pt][r] * Bv);
+          }
+      }
+#pragma unroll
+      for (int pt = 0; pt < 2; ++pt) {
+        const int pix = 64 * wave + 32 * pt + l32;
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq)
+          *reinterpret_cast<uint2*>(&s.t1[pix * 32 + ((qq ^ ((pix >> 2) & 3)) << 3) + 4 * h]) =
+              make_uint2(pack_bf16x2(tv[pt][4 * qq], tv[pt][4 * qq + 1]), pack_bf16x2(tv[pt][4 * qq + 2], tv[pt][4 * qq + 3]));
+      }
+      // ---- weight gradients: contraction over this wave's 64 pixels (4 k-steps of 16) --------------------------------
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8_v a4 = tr_frag32(s.im3, 64 * wave, ks, lane);      // rows = q
+        const bf16x8_v b4 = tr_frag32(s.t2, 64 * wave, ks, lane);       // cols = channel of tile t
+        dw2acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a4, b4, dw2acc[t], 0, 0, 0);
+        const bf16x8_v a5 = tr_frag32(s.t1, 64 * wave, ks, lane);       // rows = channel of tile t
+        const bf16x8_v b5 = tr_frag32(s.im1, 64 * wave, ks, lane);      // cols = k (27: ones -> db1)
+        dw1acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a5, b5, dw1acc[t], 0, 0, 0);
+      }
+    };   // channel tile
+    channel_tile(std::integral_constant<int, 0>{});
+    channel_tile(std::integral_constant<int, 1>{});
+    channel_tile(std::integral_constant<int, 2>{});
+    channel_tile(std::integral_constant<int, 3>{});
+  }     // patches
+
+  // ---- block result: sum the 4 waves' accumulators through LDS (im1 is dead), one 32x32 tile at a time --------------
   __syncthreads();
+  float* scr = reinterpret_cast<float*>(s.im1);      // 4 x 1024 floats
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = (r & 3) + 8 * (r >> 2) + 4 * h;
+        scr[wave * 1024 + m * 32 + l32] = which ? dw1acc[t][r] : dw2acc[t][r];
+      }
+      __syncthreads();
+      for (int i = tid; i < 1024; i += 256) {
+        const float v = (scr[i] + scr[1024 + i]) + (scr[2048 + i] + scr[3072 + i]);
+        const int m = i >> 5, n = i & 31;
+        if (which == 0) {                              // dW2[q = m][c = 32t + n]
+          if (m < 27) dw2[((m / 9) * C + 32 * t + n) * 9 + (m % 9)] = v;
+        } else {                                       // dW1[c = 32t + m][k = n]; k == 27 is the ones column
+          if (n < 27) dw1[(32 * t + m) * 27 + n] = v;
+          else if (n == 27) db1[32 * t + m] = v;
+        }
+      }
+      __syncthreads();
+    }
   if (tid < C) {
-    dgw[tid] = s.acc_gn[tid];
-    dgb[tid] = s.acc_gn[C + tid];
+    dgw[tid] = s.acc_gn[0][tid];
+    dgb[tid] = s.acc_gn[1][tid];
   }
-  if (tid < 3) db2[tid] = s.acc_b2[tid];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const float r = wave_sum(b2acc[i]);
+    if (lane == 0) s.fin[i][wave] = r;
+  }
+  __syncthreads();
+  if (tid < 3) db2[tid] = (s.fin[tid][0] + s.fin[tid][1]) + (s.fin[tid][2] + s.fin[tid][3]);
 }
 
-// grads (+)= sum over the per-block partial rows; thread per element, coalesced across elements
+// grads (+)= sum over the per-block partial rows, fixed order.  Block = 64 elements x 4 row groups (row r belongs to
+// group r & 3), coalesced across elements; the 4 group sums meet in LDS.
 __global__ __launch_bounds__(256) void resblock_param_reduce_kernel(const float* __restrict__ part, int nblk,
                                                                     float* __restrict__ dw1, float* __restrict__ db1,
                                                                     float* __restrict__ dgw, float* __restrict__ dgb,
                                                                     float* __restrict__ dw2, float* __restrict__ db2) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= PART_USED) return;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int b = 0;
-  for (; b + 3 < nblk; b += 4) {
-    s0 += part[(long)b * PART_STRIDE + j];
-    s1 += part[(long)(b + 1) * PART_STRIDE + j];
-    s2 += part[(long)(b + 2) * PART_STRIDE + j];
-    s3 += part[(long)(b + 3) * PART_STRIDE + j];
+  __shared__ float sm[4][64];
+  const int e = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + e;
+  float s0 = 0.f, s1 = 0.f;
+  if (j < PART_USED) {
+    int b = rg;
+    for (; b + 4 < nblk; b += 8) {
+      s0 += part[(long)b * PART_STRIDE + j];
+      s1 += part[(long)(b + 4) * PART_STRIDE + j];
+    }
+    if (b < nblk) s0 += part[(long)b * PART_STRIDE + j];
   }
-  for (; b < nblk; ++b) s0 += part[(long)b * PART_STRIDE + j];
-  const float v = (s0 + s1) + (s2 + s3);
+  sm[rg][e] = s0 + s1;
+  __syncthreads();
+  if (rg != 0 || j >= PART_USED) return;
+  const float v = (sm[0][e] + sm[1][e]) + (sm[2][e] + sm[3][e]);
   float* dst;
   if (j < OFF_B1) dst = dw1 + j;
   else if (j < OFF_GW) dst = db1 + (j - OFF_B1);
@@ -639,7 +649,7 @@ int neko_patch_resblock_fwd_impl(const void* images, int images_are_u8, int n, i
 }
 
 // blocks (= partial rows) the backward uses for P patches; workspace = blocks * neko_patch_resblock_ws_stride floats
-int neko_patch_resblock_bwd_blocks_impl(int P) { return P < 512 ? (P < 1 ? 1 : P) : 512; }
+int neko_patch_resblock_bwd_blocks_impl(int P) { return P < 256 ? (P < 1 ? 1 : P) : 256; }   // one block per CU
 int neko_patch_resblock_ws_stride_impl() { return PART_STRIDE; }
 
 int neko_patch_resblock_bwd_impl(const float* x_patches, const float* dy, int P, const float* w1, const float* b1,
@@ -656,7 +666,7 @@ int neko_patch_resblock_bwd_impl(const float* x_patches, const float* dy, int P,
   hipLaunchKernelGGL(resblock_bwd_kernel, dim3(grid), dim3(256), 0, s, x_patches, dy, P, w1, b1, gn_w, gn_b, w2,
                      workspace);
   NEKO_CHECK_LAUNCH();
-  hipLaunchKernelGGL(resblock_param_reduce_kernel, dim3((PART_USED + 255) / 256), dim3(256), 0, s, workspace, grid, dw1,
+  hipLaunchKernelGGL(resblock_param_reduce_kernel, dim3((PART_USED + 63) / 64), dim3(256), 0, s, workspace, grid, dw1,
                      db1, dgn_w, dgn_b, dw2, db2);
   NEKO_CHECK_LAUNCH();
   return NEKO_OK;

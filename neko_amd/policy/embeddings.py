@@ -171,3 +171,35 @@ class ImageEmbedding(nn.Module):
         params = [self._flat.param_of[nm] for nm in self.used_param_names(self._prefix)]
         out = _ImageEmbedFn.apply(self, x, hpos, wpos, *params)
         return out.view(n, nh * nw, self.embed_dim)
+
+    def forward_many(self, xs):
+        """The reference embeds one example's images per call (gato_policy.py:221-233), drawing the patch positions
+        once per call.  Same semantics here -- positions are drawn per example, in example order, so the host RNG
+        sequence is the reference's -- but examples whose images share (H, W, dtype) go through the kernels as ONE
+        batch (one launch chain and one partial-gradient reduce instead of one per example).
+        Returns a list of (n_i * n_h * n_w, embed_dim) tensors, one per input."""
+        if self._flat is None:
+            raise RuntimeError("ImageEmbedding must be owned by a GatoPolicy (flat parameter storage)")
+        dev = self._flat.device
+        prepared, groups = [], {}
+        for i, x in enumerate(xs):
+            if x.dtype not in (torch.float32, torch.uint8):
+                x = x.to(torch.float32)
+            n, c, H, W = x.shape
+            assert H % self.patch_size == 0 and W % self.patch_size == 0, "Image dimensions must be divisible by patch size"
+            nh, nw = H // self.patch_size, W // self.patch_size
+            hp, wp = self.patch_pos_encoding.positions(nh, nw)
+            hpos = hp.to(torch.int32).cpu().view(1, nh, 1).expand(n, nh, nw).reshape(-1)
+            wpos = wp.to(torch.int32).cpu().view(1, 1, nw).expand(n, nh, nw).reshape(-1)
+            prepared.append((x, hpos, wpos, n * nh * nw))
+            groups.setdefault((H, W, x.dtype), []).append(i)
+        params = [self._flat.param_of[nm] for nm in self.used_param_names(self._prefix)]
+        outs = [None] * len(xs)
+        for idxs in groups.values():
+            X = torch.cat([prepared[i][0].to(dev, non_blocking=True) for i in idxs], dim=0)
+            hpos = torch.cat([prepared[i][1] for i in idxs]).contiguous().pin_memory().to(dev, non_blocking=True)
+            wpos = torch.cat([prepared[i][2] for i in idxs]).contiguous().pin_memory().to(dev, non_blocking=True)
+            out = _ImageEmbedFn.apply(self, X, hpos, wpos, *params)
+            for i, o in zip(idxs, torch.split(out, [prepared[i][3] for i in idxs], dim=0)):
+                outs[i] = o
+        return outs

@@ -396,12 +396,12 @@ class GatoPolicy(nn.Module):
         disc = (torch.cat([t.to(dev, torch.int32) for t in pb.disc]) if pb.disc else None)
         img_emb = None
         if pb.img_order:
+            # positions drawn per example (in order), kernels batched per image shape
+            img_ids = [idx for kind, idx in pb.img_order if kind == "img"]
+            embedded = dict(zip(img_ids, self.image_embedding.forward_many([pb.images[i] for i in img_ids])))
             parts = []
             for kind, idx in pb.img_order:
-                if kind == "img":
-                    e = self.image_embedding(pb.images[idx])          # (n, P, d), positions drawn per example
-                else:
-                    e = pb.given_img_emb[idx].to(dev, torch.float32)
+                e = embedded[idx] if kind == "img" else pb.given_img_emb[idx].to(dev, torch.float32)
                 parts.append(e.reshape(-1, self.embed_dim))
             img_emb = parts[0] if len(parts) == 1 else torch.cat(parts, dim=0)
         params = [self._flat.param_of[n] for n in self._frontend_names()]

@@ -304,7 +304,8 @@ def test_patch_resblock_fwd_bwd(ops, u8):
     ops.patch_resblock_bwd(xpd, dy.to(DEV), *[dev[n] for n in names], 128, 32, *[grads[n] for n in names])
     for nme in names:
         ref = leaf[nme].grad
-        close(grads[nme], ref, 2e-3, 2e-4 * float(ref.abs().max()) + 1e-5, f"resblock d{nme}")
+        # bf16 MFMA operands (h2, d_h1, dy, GELU(x) rounded to bf16), fp32 accumulation over up to 18 x 256 pixels
+        close(grads[nme], ref, 1e-2, 1e-2 * float(ref.abs().max()) + 1e-5, f"resblock d{nme}")
 
 
 def test_patch_pos_add(ops):
