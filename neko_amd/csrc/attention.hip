@@ -22,6 +22,9 @@
 namespace {
 
 constexpr int NT = 256;
+#ifndef NEKO_DKV_WAVES
+#define NEKO_DKV_WAVES 3   // dK/dV waves per SIMD at hd = 32: the branch-free inner loop spills at 4 (128 VGPRs) and is 12 % slower
+#endif
 constexpr int KT = 64;          // keys (or queries, in dK/dV) per inner tile
 constexpr int TSTR = KT * 2 + 8;  // transposed image row stride in bytes (136: conflict-free ds_read_b64)
 constexpr float MASK_VAL = -10000.0f;
@@ -109,13 +112,24 @@ __device__ __forceinline__ void row_frags(const bf16_t* __restrict__ rowptr, boo
     f[ks] = __builtin_bit_cast(bf16x8_v, v);
   }
 }
+// attention-probability dropout index (2-D so that four consecutive keys of one query always share a hash word, for
+// any T): element (row = (b*H + h)*T + q, key) keeps iff byte (key & 3) of drop_word(row * T4 + (key >> 2)) >= thr,
+// T4 = ceil(T / 4).
+__device__ __forceinline__ uint32_t quad_bcast(uint32_t x, int i) {   // value of lane (lane & ~3) + i, i literal 0..3
+  switch (i) {
+    case 0: return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x00, 0xf, 0xf, true);
+    case 1: return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x55, 0xf, 0xf, true);
+    case 2: return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0xAA, 0xf, 0xf, true);
+    default: return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0xFF, 0xf, 0xf, true);
+  }
+}
 // index inside a 32-wide accumulator tile of register r for this lane
 __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
 // =====================================================================================================
 // forward
 // =====================================================================================================
-template <int HD>
+template <int HD, bool DROP>
 __global__ __launch_bounds__(NT, (HD <= 32 ? 4 : (HD <= 64 ? 3 : 2))) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ kbias,
                                                       const int* __restrict__ kstart, bf16_t* __restrict__ out,
                                                       float* __restrict__ lse, int B, int T, int H, float scale,
@@ -223,12 +237,15 @@ __global__ __launch_bounds__(NT, (HD <= 32 ? 4 : (HD <= 64 ? 3 : 2))) void attn_
       }
       l_run = fmaf(l_run, alpha, ps0 + ps1);
       m_run = m_new;
-      if (drop_thr) {   // attn_dropout on the probabilities (trajectory_gpt2.py:179): the normaliser stays undropped
-        const uint32_t base = (((uint32_t)(b * H + h) * (uint32_t)T + (uint32_t)q) * (uint32_t)T) +
-                              (uint32_t)(k0 + t * 32 + 4 * (lane >> 5));
+      if (DROP) {   // attn_dropout on the probabilities (trajectory_gpt2.py:179): the normaliser stays undropped
+        const uint32_t g0 = ((uint32_t)(b * H + h) * (uint32_t)T + (uint32_t)q) * (uint32_t)((T + 3) >> 2) +
+                            (uint32_t)((k0 + t * 32 + 4 * (lane >> 5)) >> 2);
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          st[r] = drop_keep(base + (uint32_t)((r & 3) + 8 * (r >> 2)), drop_key, drop_thr) ? st[r] * drop_scale : 0.f;
+        for (int j = 0; j < 4; ++j) {          // registers 4j..4j+3 = keys +8j .. +8j+3: one word
+          const uint32_t w = drop_word(g0 + 2 * j, drop_key);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) st[4 * j + e] = drop_byte_keep(w, e, drop_thr) ? st[4 * j + e] * drop_scale : 0.f;
+        }
       }
 #pragma unroll
       for (int i = 0; i < C::IB; ++i)
@@ -302,7 +319,7 @@ __global__ void attn_bwd_prep_kernel(const bf16_t* __restrict__ o, const bf16_t*
 // =====================================================================================================
 // backward dQ: lanes own queries (same geometry as forward)
 // =====================================================================================================
-template <int HD>
+template <int HD, bool DROP>
 __global__ __launch_bounds__(NT, (HD <= 32 ? 4 : (HD <= 64 ? 2 : 1))) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                          const float* __restrict__ kbias, const int* __restrict__ kstart,
                                                          const float* __restrict__ lse, const float* __restrict__ Dv,
@@ -383,17 +400,22 @@ __global__ __launch_bounds__(NT, (HD <= 32 ? 4 : (HD <= 64 ? 2 : 1))) void attn_
       // dS^T = P^T o (dP^T - D); zero where the score was REPLACED by the causal constant
       const int lim_causal = q - k0 - t * 32 - 4 * (lane >> 5);
       const int lim_len = T - 1 - k0 - t * 32 - 4 * (lane >> 5);
-      const uint32_t dbase = (((uint32_t)(b * H + h) * (uint32_t)T + (uint32_t)q) * (uint32_t)T) +
-                             (uint32_t)(k0 + t * 32 + 4 * (lane >> 5));
+      const uint32_t g0 = ((uint32_t)(b * H + h) * (uint32_t)T + (uint32_t)q) * (uint32_t)((T + 3) >> 2) +
+                          (uint32_t)((k0 + t * 32 + 4 * (lane >> 5)) >> 2);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int c = (r & 3) + 8 * (r >> 2);
-        const bool causal_ok = c <= lim_causal;
-        const float sv = fmaf(ldsKb[t * 32 + c + 4 * (lane >> 5)], LOG2E, causal_ok ? st[r] * scale2 : MASK_VAL * LOG2E);
-        const float pv = (c <= lim_len) ? exp2_fast(sv - my_lse) : 0.f;
-        float dpe = dpt[r];
-        if (drop_thr) dpe = drop_keep(dbase + (uint32_t)c, drop_key, drop_thr) ? dpe * drop_scale : 0.f;
-        st[r] = causal_ok ? pv * (dpe - my_D) : 0.f;
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t w = DROP ? drop_word(g0 + 2 * j, drop_key) : 0u;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * j + e;
+          const int c = (r & 3) + 8 * (r >> 2);
+          const bool causal_ok = c <= lim_causal;
+          const float sv = fmaf(ldsKb[t * 32 + c + 4 * (lane >> 5)], LOG2E, causal_ok ? st[r] * scale2 : MASK_VAL * LOG2E);
+          const float pv = exp2_fast((c <= lim_len) ? sv - my_lse : -INFINITY);      // select, not a branch: 2^-inf = 0
+          float dpe = dpt[r];
+          if (DROP) dpe = drop_byte_keep(w, e, drop_thr) ? dpe * drop_scale : 0.f;
+          st[r] = causal_ok ? pv * (dpe - my_D) : 0.f;
+        }
       }
       // dQ^T += K^T . dS^T
 #pragma unroll
@@ -425,8 +447,8 @@ __global__ __launch_bounds__(NT, (HD <= 32 ? 4 : (HD <= 64 ? 2 : 1))) void attn_
 // =====================================================================================================
 // backward dK/dV: lanes own keys; loop over 64-query tiles
 // =====================================================================================================
-template <int HD>
-__global__ __launch_bounds__(NT, (HD <= 32 ? 3 : (HD <= 64 ? 2 : 1))) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+template <int HD, bool DROP>
+__global__ __launch_bounds__(NT, (HD <= 32 ? NEKO_DKV_WAVES : (HD <= 64 ? 2 : 1))) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                           const float* __restrict__ kbias, const float* __restrict__ lse,
                                                           const float* __restrict__ Dv, const int* __restrict__ qflags,
                                                           bf16_t* __restrict__ dqkv, int B, int T, int H, float scale,
@@ -512,23 +534,33 @@ __global__ __launch_bounds__(NT, (HD <= 32 ? 3 : (HD <= 64 ? 2 : 1))) void attn_
       }
       const int lim_causal = q0 + t * 32 + 4 * (lane >> 5) - key;    // key <= query  <=>  -c(r) <= lim_causal
       const int lim_len = T - 1 - q0 - t * 32 - 4 * (lane >> 5);     // query < T     <=>   c(r) <= lim_len
-      const uint32_t dbase = (((uint32_t)(b * H + h) * (uint32_t)T + (uint32_t)(q0 + t * 32 + 4 * (lane >> 5))) * (uint32_t)T) +
-                             (uint32_t)key;
+      // dropout words: rows of this sub-tile are registers, the 4 lanes of a quad own the 4 keys of one group -> lane
+      // (key & 3) = i hashes rows 4j + i and the quad shares the 16 words by DPP (3.25 instead of 11 ops per element)
+      uint32_t mine[4] = {0u, 0u, 0u, 0u};
+      const int ksh = 8 * (lane & 3);
+      if (DROP) {
+        const uint32_t T4 = (uint32_t)((T + 3) >> 2);
+        const uint32_t gq = ((uint32_t)(b * H + h) * (uint32_t)T + (uint32_t)(q0 + t * 32 + 4 * (lane >> 5) + (lane & 3))) * T4 +
+                            (uint32_t)(key >> 2);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mine[j] = drop_word(gq + (uint32_t)(8 * j) * T4, drop_key);    // row c = (lane&3) + 8j
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int c = (r & 3) + 8 * (r >> 2);
         const int ql = t * 32 + c + 4 * (lane >> 5);
         const bool causal_ok = (-c) <= lim_causal;
         const float sv = (causal_ok ? st[r] * scale2 : MASK_VAL * LOG2E) + my_kb;
-        const float pv = (c <= lim_len && kvalid) ? exp2_fast(sv - ldsLse[ql]) : 0.f;
+        const float lse_q = ldsLse[ql], d_q = ldsD[ql];      // unconditional: a load inside ?: compiles to a branch
+        const float pv = exp2_fast((c <= lim_len && kvalid) ? sv - lse_q : -INFINITY);        // select: 2^-inf = 0
         float pd = pv, dpe = dpt[r];
-        if (drop_thr) {
-          const bool keep = drop_keep(dbase + (uint32_t)c * (uint32_t)T, drop_key, drop_thr);
+        if (DROP) {
+          const bool keep = __builtin_amdgcn_ubfe(quad_bcast(mine[r >> 2], r & 3), ksh, 8) >= drop_thr;   // word of row r
           pd = keep ? pv * drop_scale : 0.f;
           dpe = keep ? dpe * drop_scale : 0.f;
         }
         st[r] = pd;                                              // dropped P (for dV)
-        dpt[r] = causal_ok ? pv * (dpe - ldsD[ql]) : 0.f;        // dS        (for dK)
+        dpt[r] = causal_ok ? pv * (dpe - d_q) : 0.f;             // dS        (for dK)
       }
 #pragma unroll
       for (int h2 = 0; h2 < 2; ++h2) {
@@ -571,8 +603,12 @@ int fwd_launch(const bf16_t* qkv, const float* kbias, const int* kstart, bf16_t*
                int thr, unsigned key, float dscale, hipStream_t s) {
   const float scale = 1.0f / sqrtf((float)HD);
   dim3 grid((T + 127) / 128, H, B);
-  hipLaunchKernelGGL((attn_fwd_kernel<HD>), grid, dim3(NT), 0, s, qkv, kbias, kstart, out, lse, B, T, H, scale,
-                     (uint32_t)thr, key, dscale);
+  if (thr)
+    hipLaunchKernelGGL((attn_fwd_kernel<HD, true>), grid, dim3(NT), 0, s, qkv, kbias, kstart, out, lse, B, T, H, scale,
+                       (uint32_t)thr, key, dscale);
+  else
+    hipLaunchKernelGGL((attn_fwd_kernel<HD, false>), grid, dim3(NT), 0, s, qkv, kbias, kstart, out, lse, B, T, H, scale,
+                       0u, key, dscale);
   NEKO_CHECK_LAUNCH();
   return NEKO_OK;
 }
@@ -586,11 +622,19 @@ int bwd_launch(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const f
                      qflags, B, T, H, HD);
   NEKO_CHECK_LAUNCH();
   dim3 grid((T + 127) / 128, H, B);
-  hipLaunchKernelGGL((attn_bwd_dq_kernel<HD>), grid, dim3(NT), 0, s, qkv, dout, kbias, kstart, lse, D, dqkv, B, T, H,
-                     scale, (uint32_t)thr, key, dscale);
-  NEKO_CHECK_LAUNCH();
-  hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD>), grid, dim3(NT), 0, s, qkv, dout, kbias, lse, D, qflags, dqkv, B, T, H,
-                     scale, (uint32_t)thr, key, dscale);
+  if (thr) {
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, true>), grid, dim3(NT), 0, s, qkv, dout, kbias, kstart, lse, D, dqkv, B, T,
+                       H, scale, (uint32_t)thr, key, dscale);
+    NEKO_CHECK_LAUNCH();
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, true>), grid, dim3(NT), 0, s, qkv, dout, kbias, lse, D, qflags, dqkv, B, T,
+                       H, scale, (uint32_t)thr, key, dscale);
+  } else {
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, false>), grid, dim3(NT), 0, s, qkv, dout, kbias, kstart, lse, D, dqkv, B, T,
+                       H, scale, 0u, key, dscale);
+    NEKO_CHECK_LAUNCH();
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, false>), grid, dim3(NT), 0, s, qkv, dout, kbias, lse, D, qflags, dqkv, B, T,
+                       H, scale, 0u, key, dscale);
+  }
   NEKO_CHECK_LAUNCH();
   return NEKO_OK;
 }

@@ -14,11 +14,9 @@ __global__ __launch_bounds__(256) void dropout_f32_kernel(const float* __restric
   for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
     if (i + 4 <= n) {
       float4 v = *reinterpret_cast<const float4*>(x + i);
-      v.x = drop_keep((uint32_t)i, key, thr) ? v.x * scale : 0.f;
-      v.y = drop_keep((uint32_t)i + 1, key, thr) ? v.y * scale : 0.f;
-      v.z = drop_keep((uint32_t)i + 2, key, thr) ? v.z * scale : 0.f;
-      v.w = drop_keep((uint32_t)i + 3, key, thr) ? v.w * scale : 0.f;
-      *reinterpret_cast<float4*>(y + i) = v;
+      float e[4] = {v.x, v.y, v.z, v.w};
+      drop4(e, (uint32_t)i, key, thr, scale);
+      *reinterpret_cast<float4*>(y + i) = make_float4(e[0], e[1], e[2], e[3]);
     } else {
       for (long j = i; j < n; ++j) y[j] = drop_keep((uint32_t)j, key, thr) ? x[j] * scale : 0.f;
     }

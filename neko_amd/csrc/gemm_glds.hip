@@ -247,8 +247,7 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, f32x16 (&acc)[C::TM]
     }
     if (p.drop_thr) {
       const uint32_t base = (uint32_t)row * (uint32_t)p.N + (uint32_t)col;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = drop_keep(base + e, p.drop_key, p.drop_thr) ? v[e] * p.drop_scale : 0.f;
+      drop4(v, base, p.drop_key, p.drop_thr, p.drop_scale);
     }
     if (p.resid && lead) {
       const float* rs = p.resid + (long)row * p.ldr + col;

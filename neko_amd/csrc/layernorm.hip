@@ -137,10 +137,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
           // site's mask (the fp32 residual-stream gradient above does not)
           if (drop_thr) {
             const uint32_t base = (uint32_t)row * (uint32_t)d + (uint32_t)c * 4u;
-            o.x = drop_keep(base, drop_key, drop_thr) ? o.x * drop_scale : 0.f;
-            o.y = drop_keep(base + 1, drop_key, drop_thr) ? o.y * drop_scale : 0.f;
-            o.z = drop_keep(base + 2, drop_key, drop_thr) ? o.z * drop_scale : 0.f;
-            o.w = drop_keep(base + 3, drop_key, drop_thr) ? o.w * drop_scale : 0.f;
+            float e[4] = {o.x, o.y, o.z, o.w};
+            drop4(e, base, drop_key, drop_thr, drop_scale);
+            o = make_float4(e[0], e[1], e[2], e[3]);
           }
           uint2 pk;
           pk.x = pack_bf16x2(o.x, o.y);

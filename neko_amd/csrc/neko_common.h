@@ -86,15 +86,36 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
   return fmaf(x * 0.39894228040143267794f, e, 0.5f * (1.0f + er));
 }
 
-// ---- dropout: counter-based keep decision (no mask tensor; forward and backward regenerate it) -----------------
-// keep(idx) <=> top byte of a 2-multiply hash of (idx ^ site key) >= thr, thr = round(p*256): the drop rate is
-// quantised to 1/256 (p = 0.1 -> 26/256) and the survivors are scaled by 256/(256-thr), so E[out] = in exactly.
-// The site key (per layer / site / step) is mixed on the host.  7 VALU ops per element.
-__device__ __forceinline__ bool drop_keep(uint32_t idx, uint32_t key, uint32_t thr) {
-  uint32_t h = (idx ^ key) * 0x9E3779B1u;
+// ---- dropout: counter-based keep decisions (no mask tensor; forward and backward regenerate them) ----------------
+// One 32-bit hash word serves FOUR consecutive elements: element idx keeps iff byte (idx & 3) of
+// drop_word(idx >> 2, site key) >= thr, thr = round(p*256).  The drop rate is quantised to 1/256 (p = 0.1 -> 26/256)
+// and the survivors are scaled by 256/(256-thr), so E[out] = in exactly.  The word is built from full-rate 24-bit
+// multiplies (v_mul_u32_u24 / v_mad_u32_u24; a 32-bit v_mul_lo_u32 is quarter rate): 9 VALU ops per 4 elements plus
+// a byte extract + compare each, against 13 slots per element for the earlier 2 x mul_lo hash (dropout was +55 % on
+// the attention forward).  Attention indexes it in 2-D, see attention.hip.  The site key (per layer / site / step) is
+// mixed on the host; tests/test_dropout_gpu.py restates the function in numpy.
+__device__ __forceinline__ uint32_t drop_word(uint32_t g, uint32_t key) {
+  uint32_t h = g ^ key;
+  h = __umul24(h, 0x9E3779u) + __umul24(h >> 8, 0x85EBCBu);   // low 24 bits and bits 8..31: every input bit counts
   h ^= h >> 15;
-  h *= 0x85EBCA77u;
-  return (h >> 24) >= thr;
+  h = __umul24(h, 0xC2B2AFu);
+  h ^= h >> 16;
+  return h;
+}
+__device__ __forceinline__ bool drop_byte_keep(uint32_t word, int i, uint32_t thr) { return ((word >> (8 * i)) & 0xffu) >= thr; }
+__device__ __forceinline__ bool drop_keep(uint32_t idx, uint32_t key, uint32_t thr) {
+  return ((drop_word(idx >> 2, key) >> (8 * (idx & 3u))) & 0xffu) >= thr;
+}
+// v[0..3] = elements base .. base+3: masked and scaled in place (one word when base is a multiple of 4)
+__device__ __forceinline__ void drop4(float (&v)[4], uint32_t base, uint32_t key, uint32_t thr, float scale) {
+  if ((base & 3u) == 0) {
+    const uint32_t w = drop_word(base >> 2, key);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = drop_byte_keep(w, e, thr) ? v[e] * scale : 0.f;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = drop_keep(base + e, key, thr) ? v[e] * scale : 0.f;
+  }
 }
 
 // XCD-aware bijective block remap (8 XCDs, block b runs on XCD b%8): give every XCD a

@@ -13,13 +13,24 @@ from oracle import neko_oracle as O  # noqa: E402
 DEV = "cuda"
 
 
-def keep_np(idx, key, thr):
-    """numpy restatement of drop_keep(idx, key, thr) (neko_amd/csrc/neko_common.h)."""
-    h = (np.asarray(idx, dtype=np.uint64) ^ np.uint64(key)) & np.uint64(0xFFFFFFFF)
-    h = (h * np.uint64(0x9E3779B1)) & np.uint64(0xFFFFFFFF)
+M32, M24 = np.uint64(0xFFFFFFFF), np.uint64(0xFFFFFF)
+
+
+def word_np(g, key):
+    """numpy restatement of drop_word(g, key) (neko_amd/csrc/neko_common.h): 24-bit multiplies, 32-bit wrap."""
+    h = (np.asarray(g, dtype=np.uint64) ^ np.uint64(key)) & M32
+    h = ((h & M24) * np.uint64(0x9E3779) + ((h >> np.uint64(8)) & M24) * np.uint64(0x85EBCB)) & M32
     h ^= h >> np.uint64(15)
-    h = (h * np.uint64(0x85EBCA77)) & np.uint64(0xFFFFFFFF)
-    return (h >> np.uint64(24)) >= np.uint64(thr)
+    h = ((h & M24) * np.uint64(0xC2B2AF)) & M32
+    h ^= h >> np.uint64(16)
+    return h
+
+
+def keep_np(idx, key, thr):
+    """drop_keep(idx, key, thr): byte (idx & 3) of the word of group idx >> 2."""
+    idx = np.asarray(idx, dtype=np.uint64)
+    w = word_np(idx >> np.uint64(2), key)
+    return ((w >> (np.uint64(8) * (idx & np.uint64(3)))) & np.uint64(0xFF)) >= np.uint64(thr)
 
 
 def mask_flat(n, drop):
@@ -27,9 +38,13 @@ def mask_flat(n, drop):
 
 
 def mask_attn(B, H, T, drop):
-    idx = np.arange(B * H * T * T, dtype=np.uint64) & np.uint64(0xFFFFFFFF)
-    m = keep_np(idx, drop.key, drop.thr).astype(np.float32).reshape(B, H, T, T)
-    return torch.from_numpy(m) * drop.scale
+    """attention.hip's 2-D index: row = (b*H + h)*T + q, group = row * ceil(T/4) + (key >> 2), byte key & 3."""
+    T4 = (T + 3) // 4
+    rows = np.arange(B * H * T, dtype=np.uint64)[:, None]
+    keys = np.arange(T, dtype=np.uint64)[None, :]
+    w = word_np((rows * np.uint64(T4) + (keys >> np.uint64(2))) & M32, drop.key)
+    m = ((w >> (np.uint64(8) * (keys & np.uint64(3)))) & np.uint64(0xFF)) >= np.uint64(drop.thr)
+    return torch.from_numpy(m.astype(np.float32).reshape(B, H, T, T)) * drop.scale
 
 
 def rb(x):
@@ -47,7 +62,8 @@ def test_dropout_kernel_exact_and_rate():
     assert torch.equal(y, ref)
     rate = float((y == 0).float().mean())
     assert abs(rate - 26 / 256) < 2e-3, rate                      # quantised rate 26/256 = 0.1016
-    assert abs(float(y.sum()) - float(x.sum())) < 5e-3 * x.numel() ** 0.5 * 3   # unbiased
+    # unbiased: sum(y) - sum(x) = sum x_i (m_i s - 1) has variance n p/(1-p) for unit-variance x (p = 26/256); 4 sigma
+    assert abs(float(y.sum()) - float(x.sum())) < 4 * (float((x * x).sum()) * (26 / 230)) ** 0.5
     assert torch.equal(ops.dropout_f32(x.to(DEV), None).cpu(), x)  # off = identity
 
 

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--pad", type=int, default=0, help="left padding of every sequence")
     ap.add_argument("--only", default="")
+    ap.add_argument("--drop", type=float, default=0.0, help="attention dropout probability")
     a = ap.parse_args()
     B, T, H, hd = a.B, a.T, a.H, a.hd
     d = H * hd
@@ -31,7 +32,8 @@ def main():
     if a.pad:
         mask[:, :a.pad] = 0
     kb, ks = ops.mask_bias(mask)
-    out, lse = ops.attn_fwd(qkv, kb, ks, B, T, H, hd)
+    drop = ops.Drop(a.drop, 0x1234567) if a.drop > 0 else None
+    out, lse = ops.attn_fwd(qkv, kb, ks, B, T, H, hd, drop=drop)
     fl = 4.0 * T * T / 2 * hd * H * B
 
     def timeit(fn, name, flops):
@@ -47,9 +49,9 @@ def main():
         print(f"{name:10s} {us:9.1f} us  {flops / us / 1e6:7.1f} TFLOP/s (useful, causal)")
 
     if "bwd" not in a.only:
-        timeit(lambda: ops.attn_fwd(qkv, kb, ks, B, T, H, hd), "attn fwd", fl)
+        timeit(lambda: ops.attn_fwd(qkv, kb, ks, B, T, H, hd, drop=drop), "attn fwd", fl)
     if "fwd" not in a.only:
-        timeit(lambda: ops.attn_bwd(qkv, out, do, kb, ks, lse, B, T, H, hd), "attn bwd", 2.5 * fl)
+        timeit(lambda: ops.attn_bwd(qkv, out, do, kb, ks, lse, B, T, H, hd, drop=drop), "attn bwd", 2.5 * fl)
 
 
 if __name__ == "__main__":
