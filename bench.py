@@ -77,13 +77,13 @@ def time_dominant_kernel(model, rows: int, iters: int = 10):
     from neko_amd import ops
     hp = model._head_params()
     a = torch.randn(rows, D, device="cuda").to(torch.bfloat16)
-    out = torch.empty(rows, hp.Vpad, dtype=torch.float32, device="cuda")
+    out = torch.empty(rows, hp.Vpad, dtype=torch.bfloat16, device="cuda")    # same call as engine.lm_head_loss
     for _ in range(2):
-        ops.gemm(a, hp.w, rows, hp.V, D, ldb=D, out_f32=out, ldcf=hp.Vpad)
+        ops.gemm(a, hp.w, rows, hp.V, D, ldb=D, out_bf16=out, ldcb=hp.Vpad)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):
-        ops.gemm(a, hp.w, rows, hp.V, D, ldb=D, out_f32=out, ldcf=hp.Vpad)
+        ops.gemm(a, hp.w, rows, hp.V, D, ldb=D, out_bf16=out, ldcb=hp.Vpad)
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters

@@ -33,7 +33,7 @@ extern "C" {
 #define NEKO_ERR_UNSUPPORTED (-2)
 #define NEKO_ERR_LAUNCH (-3)
 
-#define NEKO_ABI_VERSION 4
+#define NEKO_ABI_VERSION 5
 
 int neko_abi_version(void);
 /* human-readable text for a return code (static storage) */
@@ -110,6 +110,12 @@ int neko_attn_bwd(const uint16_t* qkv, const uint16_t* out, const uint16_t* dout
  * ------------------------------------------------------------------------------------------- */
 int neko_ce_fwd_bwd(const float* logits, long ldl, int V, int Vpad, const long long* target, const float* weight,
                     float* loss_row, uint16_t* dlogits, long ldd, int R, void* stream);
+/* Training path: the LM-head GEMM writes bf16 logits straight into the dlogits buffer and this call turns them into
+ * the gradient IN PLACE (one read + one write of the chunk; fp32 logits never reach HBM).
+ *   z bf16 [R, ld]: in = logits (columns < V valid), out = weight * (softmax - onehot), 0 in columns V..Vpad-1
+ *   (untouched when want_grad == 0); loss_row as above (may be null).  Vpad <= 57344. */
+int neko_ce_bf16_inplace(uint16_t* z, long ld, int V, int Vpad, const long long* target, const float* weight,
+                         float* loss_row, int want_grad, int R, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Packing front-end -- GatoPolicy.tokenize_input_dicts (gato_policy.py:195-432) incl.

@@ -96,6 +96,106 @@ __global__ __launch_bounds__(256) void ce_fwd_bwd_kernel(const float* __restrict
   }
 }
 
+// ---- bf16 in-place variant (the training path) --------------------------------------------------------------------
+// z bf16 [R, ld]: on entry the logits of the chunk (columns < V valid), written by the LM-head GEMM straight into the
+// dlogits buffer; on exit weight * (softmax - onehot) in the same place, zeros in columns V..Vpad-1.  One 1024-thread
+// block per row holds the whole row in registers (7 x 16 B per thread for Vpad <= 57344): the logits are read ONCE
+// and never exist in fp32 in HBM -- per 4096-row chunk 0.43 GB read + 0.43 GB written instead of 1.7 GB + 0.43 GB
+// (and the GEMM writes half as much).  The bf16 rounding of the logits perturbs a row's loss by ~2^-9 |z| with zero
+// mean (batch mean: ~1e-6 relative); dlogits are bf16 either way.
+constexpr int CE_NT = 1024, CE_MAXCH = 7;
+
+__global__ __launch_bounds__(CE_NT) void ce_bf16_inplace_kernel(bf16_t* __restrict__ z, long ld, int V, int Vpad,
+                                                               const long long* __restrict__ target,
+                                                               const float* __restrict__ weight,
+                                                               float* __restrict__ loss_row, int want_grad, int R) {
+  __shared__ float red_m[16], red_s[16];
+  const int row = blockIdx.x;
+  if (row >= R) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float w = weight[row];
+  bf16_t* zr = z + (long)row * ld;
+  const int nch = Vpad >> 3;                       // 16-B chunks of the row
+  if (w == 0.f) {                                  // unselected position (block-uniform)
+    if (tid == 0 && loss_row) loss_row[row] = 0.f;
+    if (want_grad)
+      for (int c = tid; c < nch; c += CE_NT) reinterpret_cast<uint4*>(zr)[c] = make_uint4(0, 0, 0, 0);
+    return;
+  }
+  const long long tgt = target[row];
+  const float z_t = bf16_to_f32(zr[tgt]);          // read before anything is overwritten
+  uint4 reg[CE_MAXCH];
+  float m = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < CE_MAXCH; ++i) {
+    const int c = tid + i * CE_NT;
+    reg[i] = make_uint4(0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u);      // -inf bf16 pairs
+    if (c < nch) {
+      uint4 v = reinterpret_cast<const uint4*>(zr)[c];
+      if (c * 8 + 8 > V) {                         // chunk straddles or lies beyond V: invalid columns -> -inf
+        uint32_t wv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (c * 8 + e >= V) wv[e >> 1] = (e & 1) ? ((wv[e >> 1] & 0x0000ffffu) | 0xff800000u) : ((wv[e >> 1] & 0xffff0000u) | 0x0000ff80u);
+        v = make_uint4(wv[0], wv[1], wv[2], wv[3]);
+      }
+      reg[i] = v;
+      const uint32_t wv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) m = fmaxf(m, fmaxf(__uint_as_float(wv[e] << 16), __uint_as_float(wv[e] & 0xffff0000u)));
+    }
+  }
+  // block max
+  m = wave_max(m);
+  if (lane == 0) red_m[wave] = m;
+  __syncthreads();
+  float gm = red_m[0];
+#pragma unroll
+  for (int i = 1; i < 16; ++i) gm = fmaxf(gm, red_m[i]);
+  // sum of exp (invalid columns are -inf -> 0)
+  const float gm2 = gm * 1.4426950408889634f;
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < CE_MAXCH; ++i) {
+    const uint32_t wv[4] = {reg[i].x, reg[i].y, reg[i].z, reg[i].w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      s += __builtin_amdgcn_exp2f(fmaf(__uint_as_float(wv[e] << 16), 1.4426950408889634f, -gm2)) +
+           __builtin_amdgcn_exp2f(fmaf(__uint_as_float(wv[e] & 0xffff0000u), 1.4426950408889634f, -gm2));
+  }
+  s = wave_sum(s);
+  if (lane == 0) red_s[wave] = s;
+  __syncthreads();
+  float gs = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) gs += red_s[i];
+  const float lse = gm + __logf(gs);
+  if (tid == 0 && loss_row) loss_row[row] = lse - z_t;
+  if (!want_grad) return;
+  const float lse2 = lse * 1.4426950408889634f;
+#pragma unroll
+  for (int i = 0; i < CE_MAXCH; ++i) {
+    const int c = tid + i * CE_NT;
+    if (c >= nch) continue;
+    const uint32_t wv[4] = {reg[i].x, reg[i].y, reg[i].z, reg[i].w};
+    float p[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      p[2 * e] = __builtin_amdgcn_exp2f(fmaf(__uint_as_float(wv[e] << 16), 1.4426950408889634f, -lse2));
+      p[2 * e + 1] = __builtin_amdgcn_exp2f(fmaf(__uint_as_float(wv[e] & 0xffff0000u), 1.4426950408889634f, -lse2));
+    }
+    const int c0 = c * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float g = p[e];
+      if (c0 + e == tgt) g -= 1.f;
+      p[e] = g * w;
+    }
+    reinterpret_cast<uint4*>(zr)[c] = make_uint4(pack_bf16x2(p[0], p[1]), pack_bf16x2(p[2], p[3]),
+                                                 pack_bf16x2(p[4], p[5]), pack_bf16x2(p[6], p[7]));
+  }
+}
+
 }  // namespace
 
 int neko_ce_fwd_bwd_impl(const float* logits, long ldl, int V, int Vpad, const long long* target, const float* weight,
@@ -105,6 +205,19 @@ int neko_ce_fwd_bwd_impl(const float* logits, long ldl, int V, int Vpad, const l
   if (V <= 0 || Vpad < V || (Vpad & 7) || (ldl & 3) || (dlogits && ((ldd & 7) || ldd < Vpad))) return NEKO_ERR_ARG;
   hipLaunchKernelGGL(ce_fwd_bwd_kernel, dim3(R), dim3(256), 0, s, logits, ldl, V, Vpad, target, weight, loss_row,
                      dlogits, ldd, R);
+  NEKO_CHECK_LAUNCH();
+  return NEKO_OK;
+}
+
+int neko_ce_bf16_inplace_impl(bf16_t* z, long ld, int V, int Vpad, const long long* target, const float* weight,
+                              float* loss_row, int want_grad, int R, hipStream_t s) {
+  if (R <= 0) return NEKO_OK;
+  if (!z || !target || !weight || (!loss_row && !want_grad)) return NEKO_ERR_ARG;
+  if (V <= 0 || Vpad < V || (Vpad & 7) || (ld & 7) || ld < Vpad) return NEKO_ERR_ARG;
+  if ((reinterpret_cast<uintptr_t>(z) & 15)) return NEKO_ERR_ARG;
+  if ((Vpad >> 3) > CE_NT * CE_MAXCH) return NEKO_ERR_UNSUPPORTED;      // row does not fit the register file
+  hipLaunchKernelGGL(ce_bf16_inplace_kernel, dim3(R), dim3(CE_NT), 0, s, z, ld, V, Vpad, target, weight, loss_row,
+                     want_grad, R);
   NEKO_CHECK_LAUNCH();
   return NEKO_OK;
 }

@@ -59,6 +59,10 @@ int neko_ce_fwd_bwd(const float* logits, long ldl, int V, int Vpad, const long l
                     float* loss_row, uint16_t* dlogits, long ldd, int R, void* stream) {
   return neko_ce_fwd_bwd_impl(logits, ldl, V, Vpad, target, weight, loss_row, dlogits, ldd, R, S(stream));
 }
+int neko_ce_bf16_inplace(uint16_t* z, long ld, int V, int Vpad, const long long* target, const float* weight,
+                         float* loss_row, int want_grad, int R, void* stream) {
+  return neko_ce_bf16_inplace_impl(z, ld, V, Vpad, target, weight, loss_row, want_grad, R, S(stream));
+}
 
 int neko_pack_embed_fwd(const int* desc, const float* cont_vals, const int* disc_vals, const float* img_emb,
                         const float* embed, const float* pos_embed, const float* sep, float* x, long long* tokens,

@@ -51,6 +51,8 @@ int neko_attn_bwd_impl(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout,
                        int drop_thr, unsigned drop_key, float drop_scale, hipStream_t s);
 int neko_ce_fwd_bwd_impl(const float* logits, long ldl, int V, int Vpad, const long long* target, const float* weight,
                          float* loss_row, bf16_t* dlogits, long ldd, int R, hipStream_t s);
+int neko_ce_bf16_inplace_impl(bf16_t* z, long ld, int V, int Vpad, const long long* target, const float* weight,
+                              float* loss_row, int want_grad, int R, hipStream_t s);
 int neko_pack_embed_fwd_impl(const int* desc, const float* cont_vals, const int* disc_vals, const float* img_emb,
                              const float* embed, const float* pos_embed, const float* sep, float* x,
                              long long* tokens, float* tmask, float* pmask, int ntok, int d, float mu, float M,

@@ -230,17 +230,19 @@ def lm_head_loss(Hp: HeadParams, hf16: torch.Tensor, target: torch.Tensor, sel: 
     dev = hf16.device
     weight = sel / count.clamp(min=1.0)
     loss_rows = torch.empty(M, dtype=F32, device=dev)
-    dlogits = torch.empty(M, Hp.Vpad, dtype=BF16, device=dev) if want_grad else None
     R = min(chunk_rows, M)
-    logits = torch.empty(R, Hp.Vpad, dtype=F32, device=dev)
+    # the GEMM writes bf16 logits straight into the gradient buffer and the CE kernel turns them into dlogits in place
+    # (fp32 logits never reach HBM); without a gradient one chunk-sized scratch buffer is reused
+    dlogits = torch.empty(M if want_grad else R, Hp.Vpad, dtype=BF16, device=dev)
     for r0 in range(0, M, R):
         r1 = min(M, r0 + R)
         n = r1 - r0
-        ops.gemm(hf16[r0:r1], Hp.w, n, Hp.V, d, ldb=d, out_f32=logits, ldcf=Hp.Vpad)
-        ops.ce_fwd_bwd(logits[:n], Hp.V, Hp.Vpad, target[r0:r1], weight[r0:r1], loss_row=loss_rows[r0:r1],
-                       dlogits=None if dlogits is None else dlogits[r0:r1])
+        z = dlogits[r0:r1] if want_grad else dlogits[:n]
+        ops.gemm(hf16[r0:r1], Hp.w, n, Hp.V, d, ldb=d, out_bf16=z, ldcb=Hp.Vpad)
+        ops.ce_bf16_inplace(z, Hp.V, Hp.Vpad, target[r0:r1], weight[r0:r1], loss_row=loss_rows[r0:r1],
+                            want_grad=want_grad)
     loss = torch.dot(loss_rows, weight)
-    return loss, dlogits
+    return loss, (dlogits if want_grad else None)
 
 
 def lm_head_loss_selected(Hp: HeadParams, hf16: torch.Tensor, target: torch.Tensor, idx: torch.Tensor, n: int,

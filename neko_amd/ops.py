@@ -178,6 +178,14 @@ def attn_bwd(qkv, out, dout, kbias, kstart, lse, B, T, H, hd, drop=None):
     return dqkv
 
 
+def ce_bf16_inplace(z, V, Vpad, target, weight, loss_row=None, want_grad=True):
+    """z bf16 [R, >=Vpad]: logits in, weight * (softmax - onehot) out (in place); see neko_ce_bf16_inplace."""
+    _chk(z, BF16, "z"); _chk(target, torch.int64, "target"); _chk(weight, torch.float32, "weight")
+    assert z.stride(1) == 1
+    _lib.call("neko_ce_bf16_inplace", _p(z), z.stride(0), V, Vpad, _p(target), _p(weight), _p(loss_row),
+              int(bool(want_grad)), z.shape[0], _stream())
+
+
 def ce_fwd_bwd(logits, V, Vpad, target, weight, loss_row=None, dlogits=None):
     _chk(logits, torch.float32, "logits"); _chk(target, torch.int64, "target"); _chk(weight, torch.float32, "weight")
     R = logits.shape[0]

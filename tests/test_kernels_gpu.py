@@ -275,6 +275,33 @@ def test_tokenizer_golden_and_sweep(ops, golden):
         assert torch.equal(got, ref), f"mu_law={mu_law}: {int((got != ref).sum())} of {x.numel()} bins differ"
 
 
+@pytest.mark.parametrize("R,V", [(5, 1000), (3, 52305), (4, 77)])
+def test_ce_bf16_inplace(ops, R, V):
+    """Training-path CE: bf16 logits in, gradient out in the same buffer; reference = fp32 math on the SAME bf16 logits."""
+    g = torch.Generator().manual_seed(V)
+    Vpad = (V + 63) // 64 * 64
+    z16 = (torch.randn(R, V, generator=g) * 3).to(torch.bfloat16)
+    buf = torch.full((R, Vpad), float("nan"), dtype=torch.bfloat16)        # pad columns arrive uninitialised
+    buf[:, :V] = z16
+    tgt = torch.randint(0, V, (R,), generator=g)
+    w = torch.rand(R, generator=g)
+    w[1] = 0.0
+    z = z16.float()
+    lse = torch.logsumexp(z, dim=1)
+    loss_ref = (lse - z.gather(1, tgt[:, None])[:, 0]) * (w != 0)
+    d_ref = (torch.softmax(z, dim=1) - torch.nn.functional.one_hot(tgt, V)) * w[:, None]
+    zb = buf.to(DEV)
+    loss = torch.empty(R, device=DEV)
+    ops.ce_bf16_inplace(zb, V, Vpad, tgt.to(DEV), w.to(DEV), loss_row=loss, want_grad=False)
+    close(loss, loss_ref, 1e-5, 1e-5, "ce loss (no grad)")
+    assert torch.equal(zb.cpu()[:, :V], z16)                               # untouched without a gradient
+    ops.ce_bf16_inplace(zb, V, Vpad, tgt.to(DEV), w.to(DEV), loss_row=loss, want_grad=True)
+    close(loss, loss_ref, 1e-5, 1e-5, "ce loss")
+    out = zb.cpu().float()
+    assert float(out[:, V:].abs().max()) == 0.0 if Vpad > V else True
+    close(out[:, :V], d_ref, 2 ** -7, 1e-6, "ce dlogits")
+
+
 # ----------------------------------------------------------------------------------------------------
 # patch embedding residual block
 # ----------------------------------------------------------------------------------------------------
