@@ -171,6 +171,14 @@ def main():
         lm_frac = (model._loss_rows[3] / float(B * Tlen)) if (model._loss_rows and model.lm_head_selected_rows) else 1.0
         fpt = 3 * flops_per_token_fwd(t=Tlen, lm_rows_frac=lm_frac)
         dom = time_dominant_kernel(model, min(4096, B * Tlen))
+        # HBM bytes per launch of that kernel: PMC counters cannot be collected from inside the timed process, so the
+        # number is the committed rocprofv3 --pmc measurement of the same call (tools/pmc_lmhead.sh), null if absent
+        traffic, traffic_src = None, None
+        tp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_lmhead_traffic.json")
+        if os.path.exists(tp):
+            tj = json.load(open(tp))
+            if tj.get("shape_MNK") == dom["shape"]:
+                traffic, traffic_src = tj["traffic_bytes_per_launch"], "profiles/r01_lmhead_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, calibrated)"
         out = {
             "metric": "multimodal tokens/sec (fwd+bwd+optimizer, whole job)", "value": value, "unit": "tokens/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps,
@@ -186,7 +194,8 @@ def main():
             "flops_per_token_fwd_bwd": fpt,
             "lm_head_rows_fraction": lm_frac,
             "roofline": {"bound": "mfma", "achieved": dom["tflops"], "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": dom["tflops"] / MFMA_PEAK_TFLOPS, "traffic": None, "kernel": dom["kernel"],
+                         "frac": dom["tflops"] / MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch",
+                         "traffic_source": traffic_src, "kernel": dom["kernel"],
                          "shape_MNK": dom["shape"], "ms_per_launch": dom["ms"]},
         }
         if not args.no_cpu_baseline:
