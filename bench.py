@@ -117,6 +117,9 @@ def main():
     from neko_amd.policy.gato_policy import GatoPolicy
     from neko_amd.training.optim import NekoAdamW
 
+    # the host side of a step is a few hundred tiny tensor ops: with torch's default of one intra-op thread per
+    # hardware thread (256 here) every small CPU op pays a fork/join of milliseconds
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
     torch.manual_seed(0)
     dropout = args.dropout   # reference default 0.1 (arguments.py:69); embd_pdrop is 0.1 regardless
     model = GatoPolicy(dev, D, L, H, dropout, resid_mid_channels=128, context_len=T, text_tokenizer=V_TEXT)

@@ -162,6 +162,9 @@ __global__ __launch_bounds__(NT, (HD <= 32 ? 4 : (HD <= 64 ? 3 : 2))) void attn_
   int masked_q = 0;
   if (tid < 128 && q0 + tid < T) masked_q = (kb[q0 + tid] != 0.f);
   const int full = __syncthreads_or(masked_q);
+  // only the waves that hold a masked (padded) query row need the keys beyond their diagonal: for every other
+  // row those scores are -1e4 and exp(-1e4 - m) == 0 in fp32
+  const bool wave_full = __builtin_amdgcn_ballot_w64(qvalid && kb[min(q, T - 1)] != 0.f) != 0;
   const int qmax = min(q0 + 127, T - 1);
   const int kt_end = full ? (T + KT - 1) / KT : qmax / KT + 1;
   const int kt_beg = full ? 0 : (kstart ? kstart[b] / KT : 0);
@@ -199,6 +202,7 @@ __global__ __launch_bounds__(NT, (HD <= 32 ? 4 : (HD <= 64 ? 3 : 2))) void attn_
     // softmax (lane pair (l, l^32) shares a query) -> O^T += V^T.P^T
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
+      if (!wave_full && k0 + t * 32 > qw0 + 31) continue;     // wave-uniform: nothing visible, no masked row
       f32x16 st;
 #pragma unroll
       for (int r = 0; r < 16; ++r) st[r] = 0.f;
@@ -208,8 +212,8 @@ __global__ __launch_bounds__(NT, (HD <= 32 ? 4 : (HD <= 64 ? 3 : 2))) void attn_
       // wave-uniform choice of the cheap path: every key of the sub-tile is visible to every query of the wave
       const bool interior = (k0 + t * 32 + 31 <= qw0) && !has_pad && (k0 + KT <= T);
       if (interior) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) st[r] *= scale2;
+        // scale folded into the exp2 argument below: the running max is tracked on scaled values, max commutes with a
+        // positive scale
       } else {
         const int lim_causal = q - k0 - t * 32 - 4 * (lane >> 5);        // key <= q  <=>  c(r) <= lim_causal
         const int lim_len = T - 1 - k0 - t * 32 - 4 * (lane >> 5);       // key <  T  <=>  c(r) <= lim_len
@@ -225,13 +229,14 @@ __global__ __launch_bounds__(NT, (HD <= 32 ? 4 : (HD <= 64 ? 3 : 2))) void attn_
 #pragma unroll
       for (int r = 2; r < 16; ++r) mx = fmaxf(mx, st[r]);
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float m_new = fmaxf(m_run, mx);
+      const float sc = interior ? scale2 : 1.0f;      // interior scores are still unscaled
+      const float m_new = fmaxf(m_run, mx * sc);
       const float alpha = exp2_fast(m_run - m_new);   // 2^(-inf) = 0 on the first tile
       float ps0 = 0.f, ps1 = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
-        st[r] = exp2_fast(st[r] - m_new);
-        st[r + 1] = exp2_fast(st[r + 1] - m_new);
+        st[r] = exp2_fast(fmaf(st[r], sc, -m_new));
+        st[r + 1] = exp2_fast(fmaf(st[r + 1], sc, -m_new));
         ps0 += st[r];
         ps1 += st[r + 1];
       }
@@ -307,11 +312,12 @@ __global__ void attn_bwd_prep_kernel(const bf16_t* __restrict__ o, const bf16_t*
     }
     D[((long)b * H + h) * T + q] = acc;
   }
+  // bit 0 / bit 1: the first / second 32-query half of the 64-query tile holds a masked (padded) query row
   const int nqt = (T + KT - 1) / KT;
   if (idx < (long)B * nqt) {
     const int b = idx / nqt, t = idx % nqt;
     int f = 0;
-    for (int i = t * KT; i < min(T, (t + 1) * KT); ++i) f |= (kbias[(long)b * T + i] != 0.f);
+    for (int i = t * KT; i < min(T, (t + 1) * KT); ++i) f |= (kbias[(long)b * T + i] != 0.f) << ((i - t * KT) >> 5);
     qflags[idx] = f;
   }
 }
@@ -356,6 +362,9 @@ __global__ __launch_bounds__(NT, (HD <= 32 ? 4 : (HD <= 64 ? 2 : 1))) void attn_
   int masked_q = 0;
   if (tid < 128 && q0 + tid < T) masked_q = (kb[q0 + tid] != 0.f);
   const int full = __syncthreads_or(masked_q);
+  // only the waves that hold a masked (padded) query row need the keys beyond their diagonal: for every other
+  // row those scores are -1e4 and exp(-1e4 - m) == 0 in fp32
+  const bool wave_full = __builtin_amdgcn_ballot_w64(qvalid && kb[min(q, T - 1)] != 0.f) != 0;
   const int qmax = min(q0 + 127, T - 1);
   const int kt_end = full ? (T + KT - 1) / KT : qmax / KT + 1;
   const int kt_beg = full ? 0 : (kstart ? kstart[b] / KT : 0);
@@ -383,12 +392,13 @@ __global__ __launch_bounds__(NT, (HD <= 32 ? 4 : (HD <= 64 ? 2 : 1))) void attn_
     tile_store_tr<HD>(ldsKt, tid, rk);
     tile_store_nat<HD>(ldsV, tid, rv);
     if (tid < KT) ldsKb[tid] = rkb;
-    __syncthreads();
+    const int has_pad = __syncthreads_or(tid < KT && rkb != 0.f);
     if (kt + 1 < kt_end) prefetch(kt + 1);
 
     // one 32-key sub-tile at a time (16 score + 16 dP registers live)
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
+      if (!wave_full && k0 + t * 32 > qw0 + 31) continue;     // wave-uniform: nothing visible, no masked row
       f32x16 st, dpt;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { st[r] = 0.f; dpt[r] = 0.f; }
@@ -402,6 +412,23 @@ __global__ __launch_bounds__(NT, (HD <= 32 ? 4 : (HD <= 64 ? 2 : 1))) void attn_
       const int lim_len = T - 1 - k0 - t * 32 - 4 * (lane >> 5);
       const uint32_t g0 = ((uint32_t)(b * H + h) * (uint32_t)T + (uint32_t)q) * (uint32_t)((T + 3) >> 2) +
                           (uint32_t)((k0 + t * 32 + 4 * (lane >> 5)) >> 2);
+      // wave-uniform fast path: every key of the sub-tile is visible to every query of the wave and none is padded
+      const bool interior = (k0 + t * 32 + 31 <= qw0) && !has_pad && (k0 + KT <= T);
+      if (interior) {
+        const float nlse = -my_lse;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const uint32_t w = DROP ? drop_word(g0 + 2 * j, drop_key) : 0u;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * j + e;
+            const float pv = exp2_fast(fmaf(st[r], scale2, nlse));
+            float dpe = dpt[r];
+            if (DROP) dpe = drop_byte_keep(w, e, drop_thr) ? dpe * drop_scale : 0.f;
+            st[r] = pv * (dpe - my_D);
+          }
+        }
+      } else
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const uint32_t w = DROP ? drop_word(g0 + 2 * j, drop_key) : 0u;
@@ -522,8 +549,11 @@ __global__ __launch_bounds__(NT, (HD <= 32 ? NEKO_DKV_WAVES : (HD <= 64 ? 2 : 1)
     if (qn < nqt) prefetch(qn);
 
     // S = Q . K^T and dP = dO . V^T : rows = queries, lane column = own key; one 32-query sub-tile at a time
+    const int qfl = qflags[b * nqt + qt];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
+      // wave-uniform skip: no query of the sub-tile sees a key of this wave causally and none is a masked row
+      if (q0 + t * 32 + 31 < kw0 && !((qfl >> t) & 1)) continue;
       f32x16 st, dpt;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { st[r] = 0.f; dpt[r] = 0.f; }
@@ -545,6 +575,25 @@ __global__ __launch_bounds__(NT, (HD <= 32 ? NEKO_DKV_WAVES : (HD <= 64 ? 2 : 1)
 #pragma unroll
         for (int j = 0; j < 4; ++j) mine[j] = drop_word(gq + (uint32_t)(8 * j) * T4, drop_key);    // row c = (lane&3) + 8j
       }
+      // wave-uniform fast path: every query of the sub-tile sees every key of this wave, no key is padded or invalid
+      const bool interior = (q0 + t * 32 >= kw0 + 31) && (q0 + t * 32 + 31 < T) && (kw0 + 31 < T) &&
+                            __builtin_amdgcn_ballot_w64(my_kb != 0.f) == 0;
+      if (interior) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ql = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          const float lse_q = ldsLse[ql], d_q = ldsD[ql];
+          const float pv = exp2_fast(fmaf(st[r], scale2, -lse_q));
+          float pd = pv, dpe = dpt[r];
+          if (DROP) {
+            const bool keep = __builtin_amdgcn_ubfe(quad_bcast(mine[r >> 2], r & 3), ksh, 8) >= drop_thr;
+            pd = keep ? pv * drop_scale : 0.f;
+            dpe = keep ? dpe * drop_scale : 0.f;
+          }
+          st[r] = pd;
+          dpt[r] = pv * (dpe - d_q);
+        }
+      } else
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int c = (r & 3) + 8 * (r >> 2);

@@ -13,6 +13,7 @@ from __future__ import annotations
 import math
 from typing import Optional, Tuple
 
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -172,6 +173,13 @@ class ImageEmbedding(nn.Module):
         out = _ImageEmbedFn.apply(self, x, hpos, wpos, *params)
         return out.view(n, nh * nw, self.embed_dim)
 
+    def _upload(self, t: torch.Tensor, dev) -> torch.Tensor:
+        """Asynchronous pinned H2D copy (neko_amd.utils.utils.HostStager); the policy shares its stager."""
+        if getattr(self, "_stager", None) is None:
+            from ..utils.utils import HostStager
+            self._stager = HostStager()
+        return self._stager.upload(t, dev)
+
     def forward_many(self, xs):
         """The reference embeds one example's images per call (gato_policy.py:221-233), drawing the patch positions
         once per call.  Same semantics here -- positions are drawn per example, in example order, so the host RNG
@@ -189,16 +197,28 @@ class ImageEmbedding(nn.Module):
             assert H % self.patch_size == 0 and W % self.patch_size == 0, "Image dimensions must be divisible by patch size"
             nh, nw = H // self.patch_size, W // self.patch_size
             hp, wp = self.patch_pos_encoding.positions(nh, nw)
-            hpos = hp.to(torch.int32).cpu().view(1, nh, 1).expand(n, nh, nw).reshape(-1)
-            wpos = wp.to(torch.int32).cpu().view(1, 1, nw).expand(n, nh, nw).reshape(-1)
+            # per-patch index arrays in (image, row, col) order; numpy: tiny CPU torch ops pay a fork/join per call
+            hpos = np.broadcast_to(hp.numpy().astype(np.int32).reshape(1, nh, 1), (n, nh, nw)).reshape(-1)
+            wpos = np.broadcast_to(wp.numpy().astype(np.int32).reshape(1, 1, nw), (n, nh, nw)).reshape(-1)
             prepared.append((x, hpos, wpos, n * nh * nw))
             groups.setdefault((H, W, x.dtype), []).append(i)
         params = [self._flat.param_of[nm] for nm in self.used_param_names(self._prefix)]
         outs = [None] * len(xs)
         for idxs in groups.values():
-            X = torch.cat([prepared[i][0].to(dev, non_blocking=True) for i in idxs], dim=0)
-            hpos = torch.cat([prepared[i][1] for i in idxs]).contiguous().pin_memory().to(dev, non_blocking=True)
-            wpos = torch.cat([prepared[i][2] for i in idxs]).contiguous().pin_memory().to(dev, non_blocking=True)
+            on_dev = [prepared[i][0] for i in idxs if prepared[i][0].is_cuda]
+            on_cpu = [prepared[i][0] for i in idxs if not prepared[i][0].is_cuda]
+            if on_cpu and on_dev:       # keep example order: bring the stragglers over first (mixed residency is rare)
+                X = torch.cat([self._upload(prepared[i][0], dev) if not prepared[i][0].is_cuda else prepared[i][0]
+                               for i in idxs], dim=0)
+            elif on_cpu:
+                # a pageable .to(device) blocks the host until the stream drains (13 ms/step on the m-mix batch):
+                # concatenate on the host, stage through a cached pinned buffer, copy asynchronously
+                X = self._upload(on_cpu[0] if len(on_cpu) == 1 else torch.cat(on_cpu, dim=0), dev)
+            else:
+                X = on_dev[0] if len(on_dev) == 1 else torch.cat(on_dev, dim=0)
+            pos = np.stack([np.concatenate([prepared[i][1] for i in idxs]), np.concatenate([prepared[i][2] for i in idxs])])
+            pos = self._upload(torch.from_numpy(np.ascontiguousarray(pos)), dev)
+            hpos, wpos = pos[0], pos[1]
             out = _ImageEmbedFn.apply(self, X, hpos, wpos, *params)
             for i, o in zip(idxs, torch.split(out, [prepared[i][3] for i in idxs], dim=0)):
                 outs[i] = o

@@ -383,6 +383,18 @@ class GatoPolicy(nn.Module):
     def _dev(self) -> torch.device:
         return self._flat.device
 
+    def _gather_values(self, parts, dtype, dev):
+        """Concatenated value buffer on the device.  Host-resident parts are concatenated on the host and go over in
+        one asynchronous pinned copy (a pageable .to(device) would block the host until the stream drains)."""
+        if not parts:
+            return None
+        if all(t.is_cuda for t in parts):
+            return torch.cat([t.to(dev, dtype) for t in parts])
+        if not any(t.is_cuda for t in parts):
+            return self.image_embedding._upload(torch.cat([t.to(dtype).reshape(-1) for t in parts]), dev)
+        return torch.cat([(t if t.is_cuda else self.image_embedding._upload(t.to(dtype).contiguous(), dev)).to(dev, dtype).reshape(-1)
+                          for t in parts])
+
     # ---- packing (gato_policy.py:195-432) -----------------------------------------------------------
     def tokenize_input_dicts(self, inputs: list):
         """Returns (token_embeddings (B,T,d) f32, tokens (B,T) i64, token_target_masks (B,T) f32,
@@ -391,9 +403,9 @@ class GatoPolicy(nn.Module):
         if dev.type != "cuda":
             raise RuntimeError("neko_amd.GatoPolicy computes on the GPU only (no CPU fallback)")
         pb = build_layout(inputs, self.use_pos_encoding, self.context_len, self.pad_seq)
-        desc = torch.from_numpy(pb.desc).pin_memory().to(dev, non_blocking=True)
-        cont = (torch.cat([t.to(dev, torch.float32) for t in pb.cont]) if pb.cont else None)
-        disc = (torch.cat([t.to(dev, torch.int32) for t in pb.disc]) if pb.disc else None)
+        desc = self.image_embedding._upload(torch.from_numpy(pb.desc), dev)
+        cont = self._gather_values(pb.cont, torch.float32, dev)
+        disc = self._gather_values(pb.disc, torch.int32, dev)
         img_emb = None
         if pb.img_order:
             # positions drawn per example (in order), kernels batched per image shape
@@ -413,7 +425,7 @@ class GatoPolicy(nn.Module):
         selm = np.zeros((B, T), dtype=bool)
         selm[:, :-1] = (dk[:, :-1, 0] != K_PAD) & (dk[:, 1:, 3] != 0)
         sel_idx = np.flatnonzero(selm.reshape(-1)).astype(np.int32)
-        idx_dev = torch.from_numpy(sel_idx if sel_idx.size else np.zeros(1, np.int32)).pin_memory().to(dev, non_blocking=True)
+        idx_dev = self.image_embedding._upload(torch.from_numpy(sel_idx if sel_idx.size else np.zeros(1, np.int32)), dev)
         self._loss_rows = (tokens.data_ptr(), B * T, idx_dev, int(sel_idx.size))
         return x.view(B, T, d), tokens.view(B, T), tmask.view(B, T), pmask.view(B, T)
 

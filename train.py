@@ -26,6 +26,8 @@ from neko_amd.training.trainer import Trainer  # noqa: E402
 
 
 def main(args: TrainingArgs):
+    import os as _os
+    torch.set_num_threads(min(8, _os.cpu_count() or 1))   # host side = many tiny tensor ops (see bench.py)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
