@@ -255,6 +255,7 @@ int neko_gemm_bf16_impl(GemmArgs a, int a_kstrided, int b_kstrided, int safe_tra
   if (a_kstrided && (a.M & 7)) return NEKO_ERR_ARG;
   if (b_kstrided && (a.N & 7)) return NEKO_ERR_ARG;
   if (a.act == 2 && !a.act_in) return NEKO_ERR_ARG;
+  if (a.act < 0 || a.act > 2) return NEKO_ERR_ARG;
   if (a.splitk > 1) {
     if (!a.Cf || a.Cb || a.act != 0) return NEKO_ERR_ARG;  // atomics need a linear f32 epilogue
     if (a.k_per_split <= 0 || (a.k_per_split % BK)) return NEKO_ERR_ARG;

@@ -22,7 +22,7 @@
 #include "neko_kernels.h"
 
 #ifndef NEKO_GEMM_DIAG
-#define NEKO_GEMM_DIAG 0   // ablations for tools/gemm_bench.py: 1 no in-loop DMA, 2 fragments read once, 3 no MFMA (ping-pong kernel)
+#define NEKO_GEMM_DIAG 0   // ablations for tools/gemm_bench.py: 1 no in-loop DMA, 4 no epilogue
 #endif
 
 namespace {
@@ -79,26 +79,6 @@ __device__ __forceinline__ void stage_ks(const bf16_t* __restrict__ P, long ld, 
     const int kr = chunk * (64 / PPR) + lane / PPR;
     const int piece = (lane % PPR) ^ ((kr & 3) << 2);
     const int gc = min(c0 + piece * 8, ncols - 8);
-    glds16(P + (long)(k0 + kr) * ld + gc, lds + chunk * 1024);
-  }
-}
-
-// one 1-KiB piece (index i of this wave's EXT/16/NW) of the tiles above, for issue interleaved with MFMAs
-template <int EXT, int NW, bool KC>
-__device__ __forceinline__ void stage_piece(const bf16_t* __restrict__ P, long ld, int e0, int next, int k0, char* lds,
-                                            int wave, int lane, int i) {
-  constexpr int PER = EXT / 16 / NW;
-  const int chunk = wave * PER + i;
-  if (KC) {
-    const int row = chunk * 16 + (lane >> 2);
-    const int piece = (lane & 3) ^ ((row >> 2) & 3);
-    const int gr = min(e0 + row, next - 1);
-    glds16(P + (long)gr * ld + k0 + piece * 8, lds + chunk * 1024);
-  } else {
-    constexpr int PPR = EXT / 8;
-    const int kr = chunk * (64 / PPR) + lane / PPR;
-    const int piece = (lane % PPR) ^ ((kr & 3) << 2);
-    const int gc = min(e0 + piece * 8, next - 8);
     glds16(P + (long)(k0 + kr) * ld + gc, lds + chunk * 1024);
   }
 }
@@ -164,11 +144,155 @@ struct Cfg {
   static constexpr int WAVES_PER_SIMD = (BLOCKS_PER_CU * NW + 3) / 4;
 };
 
+// ---- fast epilogue --------------------------------------------------------------------------------------------------
+// The generic epilogue below decides everything per 4-element step at run time (output kinds, activation, dropout,
+// bounds): ~10 uniform branches and several 64-bit multiplies per step, 10k instructions, ~23 VALU slots per output
+// element even for a plain bf16 store -- at K = 768 that was 30-55 % of the GEMM (a 256x256 tile is 1024 elements
+// per physical VALU lane).  This version is compiled per FEATURE SET (template mask F), takes only full interior
+// tiles with 16-B aligned rows (the caller checks), parks 32 accumulator rows in a PADDED slab (row stride +4
+// floats: every ds_write_b32 / ds_read_b128 address is lane base + literal offset, no swizzle arithmetic) and walks
+// the output with pointers that advance by a constant row step.
+enum : unsigned { F_BIAS = 1, F_GELU = 2, F_PRE = 4, F_GELUBWD = 8, F_DROP = 16, F_RESID = 32, F_CF = 64, F_ACCUM = 128,
+                  F_CB = 256, F_ALPHA = 512 };
+
+template <class C>
+struct FastEpi {
+  static constexpr int SW = 32 * C::TN, SWP = SW + 4;          // slab row stride (floats), padded
+  static constexpr int SLAB_BYTES = 32 * SWP * 4;
+  static constexpr int CPR = SW / 4, RPI = 64 / CPR;           // float4 chunks per row, rows per wave-instruction
+  static_assert(C::NW * SLAB_BYTES <= C::LDS_BYTES, "padded slabs must fit the ring");
+};
+
+template <class C, unsigned F>
+__device__ __forceinline__ void epilogue_fast(const GemmArgs& p, f32x16 (&acc)[C::TM][C::TN], char* smem, int m0, int n0,
+                                              int wm, int wn, int wave, int lane, float* Cf_out, long ldcf_out) {
+  using E = FastEpi<C>;
+  constexpr int TM = C::TM, TN = C::TN, SWP = E::SWP, CPR = E::CPR, RPI = E::RPI;
+  float* slab = reinterpret_cast<float*>(smem + wave * E::SLAB_BYTES);
+  float* wbase = slab + 4 * (lane >> 5) * SWP + (lane & 31);             // + ((r&3) + 8(r>>2)) * SWP + 32 j
+  const int cchunk = lane % CPR, rsub = lane / CPR;
+  const float* rbase = slab + rsub * SWP + cchunk * 4;                   // + s * RPI * SWP
+  const int col = n0 + wn * E::SW + cchunk * 4;
+  const int row0 = m0 + wm * TM * 32 + rsub;
+  float alpha = 1.0f;
+  if (F & F_ALPHA) alpha = p.alpha_dev ? p.alpha * (*p.alpha_dev) : p.alpha;
+  float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (F & F_BIAS) bv = *reinterpret_cast<const float4*>(p.bias + col);
+  // row pointers at row0; advanced by RPI rows per step (and 32 rows per pass by construction: 32 = 8 steps * RPI ... )
+  float* pcf = (F & F_CF) ? Cf_out + (long)row0 * ldcf_out + col : nullptr;
+  bf16_t* pcb = (F & F_CB) ? p.Cb + (long)row0 * p.ldcb + col : nullptr;
+  bf16_t* ppre = (F & F_PRE) ? p.pre_out + (long)row0 * p.ldpre + col : nullptr;
+  const bf16_t* pact = (F & F_GELUBWD) ? p.act_in + (long)row0 * p.ldact + col : nullptr;
+  const float* pres = (F & F_RESID) ? p.resid + (long)row0 * p.ldr + col : nullptr;
+  uint32_t didx = (F & F_DROP) ? (uint32_t)row0 * (uint32_t)p.N + (uint32_t)col : 0u;
+  const long scf = (long)RPI * ldcf_out, scb = (long)RPI * p.ldcb, spre = (long)RPI * p.ldpre, sact = (long)RPI * p.ldact,
+             sres = (long)RPI * p.ldr;
+  const uint32_t sdrop = (uint32_t)RPI * (uint32_t)p.N;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) wbase[((r & 3) + 8 * (r >> 2)) * SWP + 32 * j] = acc[i][j][r];
+    // same-wave LDS write -> read: ordered by the LDS queue, no barrier (a slab is private to its wave)
+#pragma unroll
+    for (int st = 0; st < 32 / RPI; ++st) {
+      const float4 a4 = *reinterpret_cast<const float4*>(rbase + st * RPI * SWP);
+      float v[4] = {a4.x, a4.y, a4.z, a4.w};
+      if (F & F_ALPHA) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= alpha;
+      }
+      if (F & F_BIAS) { v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w; }
+      if (F & F_GELU) {
+        const uint32_t p01 = pack_bf16x2(v[0], v[1]), p23 = pack_bf16x2(v[2], v[3]);     // bf16 pre-activation
+        if (F & F_PRE) *reinterpret_cast<uint2*>(ppre) = make_uint2(p01, p23);
+        v[0] = gelu_f(__uint_as_float(p01 << 16));
+        v[1] = gelu_f(__uint_as_float(p01 & 0xffff0000u));
+        v[2] = gelu_f(__uint_as_float(p23 << 16));
+        v[3] = gelu_f(__uint_as_float(p23 & 0xffff0000u));
+      }
+      if (F & F_GELUBWD) {
+        const uint2 q = *reinterpret_cast<const uint2*>(pact);
+        v[0] *= gelu_grad_f(__uint_as_float(q.x << 16));
+        v[1] *= gelu_grad_f(__uint_as_float(q.x & 0xffff0000u));
+        v[2] *= gelu_grad_f(__uint_as_float(q.y << 16));
+        v[3] *= gelu_grad_f(__uint_as_float(q.y & 0xffff0000u));
+      }
+      if (F & F_DROP) drop4(v, didx, p.drop_key, p.drop_thr, p.drop_scale);
+      if (F & F_RESID) {
+        const float4 q = *reinterpret_cast<const float4*>(pres);
+        v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w;
+      }
+      if (F & F_CF) {
+        float4 o = make_float4(v[0], v[1], v[2], v[3]);
+        if (F & F_ACCUM) {
+          const float4 q = *reinterpret_cast<const float4*>(pcf);
+          o.x += q.x; o.y += q.y; o.z += q.z; o.w += q.w;
+        }
+        *reinterpret_cast<float4*>(pcf) = o;
+      }
+      if (F & F_CB) *reinterpret_cast<uint2*>(pcb) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+      // next RPI rows
+      if (F & F_CF) pcf += scf;
+      if (F & F_CB) pcb += scb;
+      if (F & F_PRE) ppre += spre;
+      if (F & F_GELUBWD) pact += sact;
+      if (F & F_RESID) pres += sres;
+      if (F & F_DROP) didx += sdrop;
+    }
+  }
+}
+
+// dispatch: feature mask of this launch -> a compiled fast epilogue, or false (caller runs the generic one)
+template <class C>
+__device__ __forceinline__ bool try_epilogue_fast(const GemmArgs& p, f32x16 (&acc)[C::TM][C::TN], char* smem, int m0,
+                                                  int n0, int wm, int wn, int wave, int lane) {
+  const bool to_ws = p.splitk > 1 && p.splitk_ws;
+  if (p.splitk > 1 && !to_ws) return false;                                   // atomic split-K: generic path
+  if (m0 + C::BM > p.M || n0 + C::BN > p.N) return false;                     // edge tile
+  float* Cf_out = to_ws ? p.splitk_ws + (long)blockIdx.y * p.M * p.N : p.Cf;
+  const long ldcf_out = to_ws ? p.N : p.ldcf;
+  const bool lead = !to_ws || blockIdx.y == 0;                                // bias/resid only once over split-K slices
+  if (to_ws && (p.bias || p.resid || p.act || p.Cb || p.drop_thr)) return false;
+  if (((ldcf_out | p.ldr | p.ldcb | p.ldact | p.ldpre) & 3) || (p.N & 3)) return false;
+  unsigned f = 0;
+  if (p.bias && lead) f |= F_BIAS;
+  if (p.act == 1) f |= F_GELU | (p.pre_out ? F_PRE : 0);
+  if (p.act == 2) f |= F_GELUBWD;
+  if (p.drop_thr) f |= F_DROP;
+  if (p.resid && lead) f |= F_RESID;
+  if (Cf_out) f |= F_CF | ((!to_ws && p.accumulate) ? F_ACCUM : 0);
+  if (p.Cb) f |= F_CB;
+  if (p.alpha != 1.0f || p.alpha_dev) f |= F_ALPHA;
+#define NEKO_FAST_EPI(MASK)                                                                          \
+  case (MASK): epilogue_fast<C, (MASK)>(p, acc, smem, m0, n0, wm, wn, wave, lane, Cf_out, ldcf_out); \
+    return true;
+  switch (f) {
+    NEKO_FAST_EPI(F_BIAS | F_CB)                                  // forward qkv
+    NEKO_FAST_EPI(F_BIAS | F_GELU | F_PRE | F_CB)                 // forward fc
+    NEKO_FAST_EPI(F_BIAS | F_RESID | F_CF)                        // forward proj (dropout off)
+    NEKO_FAST_EPI(F_BIAS | F_DROP | F_RESID | F_CF)               // forward proj (residual dropout)
+    NEKO_FAST_EPI(F_GELUBWD | F_CB)                               // dgrad through the MLP projection (* GELU')
+    NEKO_FAST_EPI(F_CB)                                           // dgrad attention out, LM-head logits
+    NEKO_FAST_EPI(F_CF)                                           // dgrad fc / qkv, split-K slices
+    NEKO_FAST_EPI(F_CF | F_ALPHA)                                 // LM-head dH (device-side grad_output)
+    NEKO_FAST_EPI(F_CF | F_ACCUM)                                 // weight gradient, single slice
+    NEKO_FAST_EPI(F_CF | F_ACCUM | F_ALPHA)                       // LM-head dW
+    NEKO_FAST_EPI(F_BIAS | F_CF)                                  // patch projection
+    default: return false;
+  }
+#undef NEKO_FAST_EPI
+}
+
 // ---- epilogue (shared by both kernels): the caller has passed a block barrier after the last ring read -------
 template <class C>
 __device__ __forceinline__ void epilogue(const GemmArgs& p, f32x16 (&acc)[C::TM][C::TN], char* smem, int m0, int n0,
                                          int wm, int wn, int wave, int lane) {
   constexpr int TM = C::TM, TN = C::TN;
+#if NEKO_GEMM_DIAG == 4
+  if (p.M != 12345) return;      // ablation: no epilogue at all
+#endif
   // ---- epilogue through this wave's private slab, TM passes of 32 rows ---------------------------------------
   constexpr int SW = 32 * TN;              // slab row length (f32)
   constexpr int CPR = SW / 4;              // float4 chunks per slab row (16 or 32)
@@ -356,241 +480,7 @@ __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void gemm_glds_kernel(Gem
     }
   }
   __syncthreads();   // all waves done with the ring before the slabs overwrite it
-  epilogue<C>(p, acc, smem, m0, n0, wm, wn, wave, lane);
-}
-
-// ---- ping-pong variant (WM == 2, one wave of each M-half per SIMD) ------------------------------------------
-// The two M-halves of the block run one barrier apart: while one half issues its 16 MFMAs of k-tile t, the other
-// half reads its fragments of k-tile t (12 ds_read_b128) and issues its share of the DMA for tile t+NSTAGE-1, then
-// they swap.  Interval n (between barriers n and n+1):  half 0: LOAD(t) at n = 2t, MFMA(t) at 2t+1;
-//                                                       half 1: LOAD(t) at n = 2t+1, MFMA(t) at 2t+2.
-//   RAW (DMA -> ds_read): every wave waits for its own pieces of tile t+1 (counted vmcnt) at the end of its LOAD(t),
-//       i.e. in an interval <= 2t+1; tile t+1 is first read in interval 2t+2.
-//   WAR (ds_read -> DMA): tile t+NSTAGE-1 reuses the slot of tile t-1, last read by half 1 in interval 2t-1 (retired
-//       by lgkmcnt(0) before barrier 2t); it is issued in LOAD(t), interval >= 2t.
-template <bool A_KC, bool B_KC, class C>
-__global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void gemm_pp_kernel(GemmArgs p) {
-  static_assert(C::WM == 2, "ping-pong needs exactly two M-halves");
-  constexpr int NSTAGE = C::RING_BYTES / C::STAGE_BYTES, BM = C::BM, BN = C::BN, TM = C::TM, TN = C::TN;
-  constexpr int GL = C::GLDS_PER_STAGE, D = NSTAGE - 1;
-  static_assert(NSTAGE == 4, "wait immediates below assume 3 tiles ahead");
-  __shared__ __attribute__((aligned(1024))) char smem[C::LDS_BYTES];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / C::WN, wn = wave % C::WN;
-  int tm, tn;
-  tile_coords<BM, BN>(p, tm, tn);
-  const int m0 = tm * BM, n0 = tn * BN;
-  int kbeg = 0, kend = p.K;
-  if (p.splitk > 1) {
-    kbeg = blockIdx.y * p.k_per_split;
-    kend = min(p.K, kbeg + p.k_per_split);
-  }
-  const int nkt = (kend - kbeg) / BK;
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  auto stage = [&](int kt) {
-    const int k0 = kbeg + kt * BK;
-    char* la = smem + (kt % NSTAGE) * C::STAGE_BYTES;
-    char* lb = la + C::A_BYTES;
-    if (A_KC) stage_kc<BM, C::NW>(p.A, p.lda, m0, p.M, k0, la, wave, lane);
-    else stage_ks<BM, C::NW>(p.A, p.lda, m0, p.M, k0, la, wave, lane);
-    if (B_KC) stage_kc<BN, C::NW>(p.B, p.ldb, n0, p.N, k0, lb, wave, lane);
-    else stage_ks<BN, C::NW>(p.B, p.ldb, n0, p.N, k0, lb, wave, lane);
-  };
-
-#pragma unroll
-  for (int t = 0; t < D; ++t)
-    if (t < nkt) stage(t);
-  {
-    const int later = min(D - 1, nkt - 1);          // tiles issued after tile 0
-    if (later >= 2) wait_dma_and_barrier<2 * GL>();
-    else if (later == 1) wait_dma_and_barrier<GL>();
-    else wait_dma_and_barrier<0>();
-  }
-  if (wm == 1) __builtin_amdgcn_s_barrier();        // half 1 runs one interval behind
-
-#if NEKO_GEMM_DIAG == 2
-  bf16x8_v a[BK / 16][TM] = {}, b[BK / 16][TN] = {};
-#endif
-  for (int t = 0; t < nkt; ++t) {
-    // ---- LOAD(t)
-    const char* la = smem + (t % NSTAGE) * C::STAGE_BYTES;
-    const char* lb = la + C::A_BYTES;
-#if NEKO_GEMM_DIAG != 2
-    bf16x8_v a[BK / 16][TM], b[BK / 16][TN];
-#else
-    if (t == 0 || p.K == 12345)
-#endif
-    {
-#pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks) {
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-        b[ks][j] = B_KC ? frag_kc(lb, (wn * TN + j) * 32, ks, lane) : frag_ks<BN>(lb, (wn * TN + j) * 32, ks, lane);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-        a[ks][i] = A_KC ? frag_kc(la, (wm * TM + i) * 32, ks, lane) : frag_ks<BM>(la, (wm * TM + i) * 32, ks, lane);
-    }
-    }
-#if NEKO_GEMM_DIAG != 1
-    if (t + D < nkt) stage(t + D);
-#endif
-    {
-      const int later = min(D - 1, nkt - 2 - t);    // tiles issued after tile t+1 (negative: nothing left to wait for)
-      if (later >= 2) wait_dma_and_barrier<2 * GL>();
-      else if (later == 1) wait_dma_and_barrier<GL>();
-      else wait_dma_and_barrier<0>();
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- MFMA(t)
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks)
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#if NEKO_GEMM_DIAG == 3
-          acc[i][j][0] += __builtin_bit_cast(float, (int)a[ks][i][0] ^ (int)b[ks][j][1]);
-#else
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][i], b[ks][j], acc[i][j], 0, 0, 0);
-#endif
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  if (wm == 0) __builtin_amdgcn_s_barrier();        // match half 1's extra barrier: all ring reads are retired after it
-  epilogue<C>(p, acc, smem, m0, n0, wm, wn, wave, lane);
-}
-
-// ---- ping-pong variant 2: as above, but the DMA pieces of tile t+NSTAGE-1 are issued BETWEEN the MFMA groups of
-// MFMA(t) (cheapest issue slot) and the LOAD phase carries only the 12 ds_reads; lgkmcnt(0) is taken after the barrier.
-// RAW: tile t+1 (issued in MFMA(t-2)) is waited for at the end of LOAD(t) with one later tile (t+2) allowed in flight.
-// The two M-halves of the block run one barrier apart: while one half issues its 16 MFMAs of k-tile t, the other
-// half reads its fragments of k-tile t (12 ds_read_b128) and issues its share of the DMA for tile t+NSTAGE-1, then
-// they swap.  Interval n (between barriers n and n+1):  half 0: LOAD(t) at n = 2t, MFMA(t) at 2t+1;
-//                                                       half 1: LOAD(t) at n = 2t+1, MFMA(t) at 2t+2.
-//   RAW (DMA -> ds_read): every wave waits for its own pieces of tile t+1 (counted vmcnt) at the end of its LOAD(t),
-//       i.e. in an interval <= 2t+1; tile t+1 is first read in interval 2t+2.
-//   WAR (ds_read -> DMA): tile t+NSTAGE-1 reuses the slot of tile t-1, last read by half 1 in interval 2t-1 (retired
-//       by lgkmcnt(0) before barrier 2t); it is issued in LOAD(t), interval >= 2t.
-template <bool A_KC, bool B_KC, class C>
-__global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void gemm_pp2_kernel(GemmArgs p) {
-  static_assert(C::WM == 2, "ping-pong needs exactly two M-halves");
-  constexpr int NSTAGE = C::RING_BYTES / C::STAGE_BYTES, BM = C::BM, BN = C::BN, TM = C::TM, TN = C::TN;
-  constexpr int GL = C::GLDS_PER_STAGE, D = NSTAGE - 1;
-  static_assert(NSTAGE == 4, "wait immediates below assume 3 tiles ahead");
-  __shared__ __attribute__((aligned(1024))) char smem[C::LDS_BYTES];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / C::WN, wn = wave % C::WN;
-  int tm, tn;
-  tile_coords<BM, BN>(p, tm, tn);
-  const int m0 = tm * BM, n0 = tn * BN;
-  int kbeg = 0, kend = p.K;
-  if (p.splitk > 1) {
-    kbeg = blockIdx.y * p.k_per_split;
-    kend = min(p.K, kbeg + p.k_per_split);
-  }
-  const int nkt = (kend - kbeg) / BK;
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  auto stage = [&](int kt) {
-    const int k0 = kbeg + kt * BK;
-    char* la = smem + (kt % NSTAGE) * C::STAGE_BYTES;
-    char* lb = la + C::A_BYTES;
-    if (A_KC) stage_kc<BM, C::NW>(p.A, p.lda, m0, p.M, k0, la, wave, lane);
-    else stage_ks<BM, C::NW>(p.A, p.lda, m0, p.M, k0, la, wave, lane);
-    if (B_KC) stage_kc<BN, C::NW>(p.B, p.ldb, n0, p.N, k0, lb, wave, lane);
-    else stage_ks<BN, C::NW>(p.B, p.ldb, n0, p.N, k0, lb, wave, lane);
-  };
-
-#pragma unroll
-  for (int t = 0; t < D; ++t)
-    if (t < nkt) stage(t);
-  {
-    const int later = min(D - 1, nkt - 1);          // tiles issued after tile 0
-    if (later >= 2) wait_dma_and_barrier<2 * GL>();
-    else if (later == 1) wait_dma_and_barrier<GL>();
-    else wait_dma_and_barrier<0>();
-  }
-  if (wm == 1) __builtin_amdgcn_s_barrier();        // half 1 runs one interval behind
-
-#if NEKO_GEMM_DIAG == 2
-  bf16x8_v a[BK / 16][TM] = {}, b[BK / 16][TN] = {};
-#endif
-  for (int t = 0; t < nkt; ++t) {
-    // ---- LOAD(t)
-    const char* la = smem + (t % NSTAGE) * C::STAGE_BYTES;
-    const char* lb = la + C::A_BYTES;
-#if NEKO_GEMM_DIAG != 2
-    bf16x8_v a[BK / 16][TM], b[BK / 16][TN];
-#else
-    if (t == 0 || p.K == 12345)
-#endif
-    {
-#pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks) {
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-        b[ks][j] = B_KC ? frag_kc(lb, (wn * TN + j) * 32, ks, lane) : frag_ks<BN>(lb, (wn * TN + j) * 32, ks, lane);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-        a[ks][i] = A_KC ? frag_kc(la, (wm * TM + i) * 32, ks, lane) : frag_ks<BM>(la, (wm * TM + i) * 32, ks, lane);
-    }
-    }
-    {
-      // issued so far: tiles <= t+2; tile t+1 must have landed
-      if (t + 2 < nkt) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier\n\ts_waitcnt lgkmcnt(0)" ::"n"(GL) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    const bool issue = t + D < nkt;
-    const int k0n = kbeg + (t + D) * BK;
-    char* lan = smem + ((t + D) % NSTAGE) * C::STAGE_BYTES;
-    char* lbn = lan + C::A_BYTES;
-    // ---- MFMA(t)
-    __builtin_amdgcn_s_setprio(1);
-    static_assert(TM == 4 && TN == 2 && GL == 4, "interleave below is written for 128x64 wave tiles");
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {            // g = (ks, i-pair): 4 MFMAs, then one DMA piece
-      const int ks = g >> 1, i0 = (g & 1) * 2;
-#pragma unroll
-      for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i0 + ii][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][i0 + ii], b[ks][j], acc[i0 + ii][j], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-#if NEKO_GEMM_DIAG != 1
-      if (issue) {
-        if (g < 2) stage_piece<BM, C::NW, A_KC>(p.A, p.lda, m0, p.M, k0n, lan, wave, lane, g);
-        else stage_piece<BN, C::NW, B_KC>(p.B, p.ldb, n0, p.N, k0n, lbn, wave, lane, g - 2);
-      }
-#endif
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  if (wm == 0) __builtin_amdgcn_s_barrier();        // match half 1's extra barrier: all ring reads are retired after it
+  if (try_epilogue_fast<C>(p, acc, smem, m0, n0, wm, wn, wave, lane)) return;
   epilogue<C>(p, acc, smem, m0, n0, wm, wn, wave, lane);
 }
 
@@ -607,24 +497,6 @@ int launch_cfg(const GemmArgs& a, hipStream_t s) {
   const int nbm = (a.M + C::BM - 1) / C::BM, nbn = (a.N + C::BN - 1) / C::BN;
   dim3 grid(nbm * nbn, a.splitk > 1 ? a.splitk : 1);
   hipLaunchKernelGGL((gemm_glds_kernel<A_KC, B_KC, C>), grid, dim3(C::NT), 0, s, a);
-  NEKO_CHECK_LAUNCH();
-  return NEKO_OK;
-}
-
-template <bool A_KC, bool B_KC, class C>
-int launch_pp(const GemmArgs& a, hipStream_t s) {
-  const int nbm = (a.M + C::BM - 1) / C::BM, nbn = (a.N + C::BN - 1) / C::BN;
-  dim3 grid(nbm * nbn, a.splitk > 1 ? a.splitk : 1);
-  hipLaunchKernelGGL((gemm_pp_kernel<A_KC, B_KC, C>), grid, dim3(C::NT), 0, s, a);
-  NEKO_CHECK_LAUNCH();
-  return NEKO_OK;
-}
-
-template <bool A_KC, bool B_KC, class C>
-int launch_pp2(const GemmArgs& a, hipStream_t s) {
-  const int nbm = (a.M + C::BM - 1) / C::BM, nbn = (a.N + C::BN - 1) / C::BN;
-  dim3 grid(nbm * nbn, a.splitk > 1 ? a.splitk : 1);
-  hipLaunchKernelGGL((gemm_pp2_kernel<A_KC, B_KC, C>), grid, dim3(C::NT), 0, s, a);
   NEKO_CHECK_LAUNCH();
   return NEKO_OK;
 }
@@ -656,8 +528,6 @@ int launch(const GemmArgs& a, hipStream_t s) {
     case 1: return launch_cfg<A_KC, B_KC, C128s4>(a, s);
     case 2: return launch_cfg<A_KC, B_KC, C256x128>(a, s);
     case 3: return launch_cfg<A_KC, B_KC, C256x256>(a, s);
-    case 4: return launch_pp<A_KC, B_KC, C256x256>(a, s);
-    case 5: return launch_pp2<A_KC, B_KC, C256x256>(a, s);
     default: return launch_cfg<A_KC, B_KC, C128s3>(a, s);
   }
 }
