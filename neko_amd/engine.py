@@ -238,7 +238,9 @@ def lm_head_loss(Hp: HeadParams, hf16: torch.Tensor, target: torch.Tensor, sel: 
         r1 = min(M, r0 + R)
         n = r1 - r0
         z = dlogits[r0:r1] if want_grad else dlogits[:n]
-        ops.gemm(hf16[r0:r1], Hp.w, n, Hp.V, d, ldb=d, out_bf16=z, ldcb=Hp.Vpad)
+        # N = Vpad, not V: the padded rows of the table are zero, the CE kernel masks columns >= V, and every tile is
+        # then an interior tile with 16-B aligned rows (fast GEMM epilogue)
+        ops.gemm(hf16[r0:r1], Hp.w, n, Hp.Vpad, d, ldb=d, out_bf16=z, ldcb=Hp.Vpad)
         ops.ce_bf16_inplace(z, Hp.V, Hp.Vpad, target[r0:r1], weight[r0:r1], loss_row=loss_rows[r0:r1],
                             want_grad=want_grad)
     loss = torch.dot(loss_rows, weight)

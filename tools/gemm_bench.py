@@ -29,6 +29,7 @@ SHAPES = [
     ("wgrad o   TN", D, D, M, True, True, "splitk"),
     ("wgrad qkv TN", D, 3 * D, M, True, True, "splitk"),
     ("lm logits NT", 4096, V, D, False, False, "f32,ldc=%d" % VP),
+    ("lm logit16 NT", 4096, VP, D, False, False, "bf16,ldc=%d" % VP),
     ("lm dH     NN", M, D, VP, False, True, "f32"),
     ("lm dW     TN", VP, D, M, True, True, "acc"),
     ("rl k768   NN", M, 1024, 768, False, True, "bf16"),
@@ -71,7 +72,8 @@ def main():
             kw["act"] = 2
             kw["act_in"] = torch.randn(m, n, device=dev).to(BF)
         if "bf16" in ex:
-            kw["out_bf16"] = torch.empty(m, n, dtype=BF, device=dev)
+            kw["out_bf16"] = torch.empty(m, ldc, dtype=BF, device=dev)
+            kw["ldcb"] = ldc
         else:
             kw["out_f32"] = torch.zeros(m, ldc, device=dev)
             kw["ldcf"] = ldc

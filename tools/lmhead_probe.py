@@ -19,6 +19,6 @@ out = torch.empty(ROWS, VP, dtype=torch.bfloat16, device=dev)
 x = torch.randn(256 * 1024 * 1024, device=dev)
 y = torch.empty_like(x, dtype=torch.bfloat16)
 for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 5):
-    ops.gemm(a, w, ROWS, V, D, ldb=D, out_bf16=out, ldcb=VP)
+    ops.gemm(a, w, ROWS, VP, D, ldb=D, out_bf16=out, ldcb=VP)
     ops.cast_f32_bf16(x, y)
 torch.cuda.synchronize()

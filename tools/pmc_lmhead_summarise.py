@@ -1,0 +1,44 @@
+#!/usr/bin/env python
+"""gpurun_out/pmcL1 (FETCH_SIZE pass) + gpurun_out/pmcL2 (WRITE_SIZE pass) of tools/pmc_lmhead.sh ->
+profiles/r01_lmhead_traffic.json: HBM bytes per launch of the LM-head logits GEMM, corrected with the calibration
+kernel of known byte count that runs in the same passes (MI355X_MICROARCH.md, HBM section)."""
+import collections
+import csv
+import glob
+import json
+import os
+
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+res = {}
+for d, cn in [("pmcL1", "FETCH_SIZE"), ("pmcL2", "WRITE_SIZE")]:
+    f = glob.glob(os.path.join(root, "gpurun_out", d, "*counter_collection.csv"))[0]
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] != cn:
+            continue
+        k = "gemm" if "gemm_glds" in r["Kernel_Name"] else ("cast" if "cast_f32_bf16" in r["Kernel_Name"] else None)
+        if k:
+            agg[k].append(float(r["Counter_Value"]))
+    res[cn] = {k: sum(v) / len(v) for k, v in agg.items()}
+cast_read, cast_write = 256 * 1024 * 1024 * 4, 256 * 1024 * 1024 * 2
+fcorr = cast_read / (res["FETCH_SIZE"]["cast"] * 1024)
+wcorr = cast_write / (res["WRITE_SIZE"]["cast"] * 1024)
+fetch = res["FETCH_SIZE"]["gemm"] * 1024 * fcorr
+write = res["WRITE_SIZE"]["gemm"] * 1024 * wcorr
+M, V, VP, K = 4096, 52305, 52352, 768
+out = {
+    "kernel": "gemm_glds_kernel<A k-contig, B k-contig> (LM head logits, bf16 out, N = Vpad)",
+    "shape_MNK": [M, V, K], "computed_columns": VP,
+    "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (pass 1) / --pmc WRITE_SIZE (pass 2) -- python3 "
+               "tools/lmhead_probe.py 5   (tools/pmc_lmhead.sh, summarised by tools/pmc_lmhead_summarise.py)",
+    "raw_KiB_per_launch": {"FETCH_SIZE": res["FETCH_SIZE"]["gemm"], "WRITE_SIZE": res["WRITE_SIZE"]["gemm"]},
+    "calibration": {"kernel": "cast_f32_bf16_kernel over 256 Mi elements (1 GiB read, 0.5 GiB written)",
+                    "raw_KiB": {"FETCH_SIZE": res["FETCH_SIZE"]["cast"], "WRITE_SIZE": res["WRITE_SIZE"]["cast"]},
+                    "fetch_correction": round(fcorr, 4), "write_correction": round(wcorr, 4),
+                    "note": "FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950; WRITE_SIZE is exact"},
+    "fetch_bytes_per_launch": round(fetch), "write_bytes_per_launch": round(write),
+    "traffic_bytes_per_launch": round(fetch + write),
+    "algorithmic_bytes_per_launch": M * K * 2 + VP * K * 2 + M * VP * 2,
+}
+json.dump(out, open(os.path.join(root, "profiles", "r01_lmhead_traffic.json"), "w"), indent=1)
+print(json.dumps(out, indent=1))
