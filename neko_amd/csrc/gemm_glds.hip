@@ -248,6 +248,9 @@ __device__ __forceinline__ void epilogue_fast(const GemmArgs& p, f32x16 (&acc)[C
 template <class C>
 __device__ __forceinline__ bool try_epilogue_fast(const GemmArgs& p, f32x16 (&acc)[C::TM][C::TN], char* smem, int m0,
                                                   int n0, int wm, int wn, int wave, int lane) {
+#if NEKO_GEMM_DIAG == 4
+  if (p.M != 12345) return true;      // ablation: no epilogue at all
+#endif
   const bool to_ws = p.splitk > 1 && p.splitk_ws;
   if (p.splitk > 1 && !to_ws) return false;                                   // atomic split-K: generic path
   if (m0 + C::BM > p.M || n0 + C::BN > p.N) return false;                     // edge tile

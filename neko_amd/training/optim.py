@@ -33,9 +33,7 @@ class NekoAdamW(torch.optim.Optimizer):
         self.groups = [g for g in f.group_ranges if g != "never"]
         self.steps: Dict[str, torch.Tensor] = {g: torch.zeros(1, dtype=torch.int32, device=dev) for g in self.groups}
         self.active = torch.zeros(len(self.groups), dtype=torch.int32, device=dev)
-        self._active_host = torch.zeros(len(self.groups), dtype=torch.int32)
-        if dev.type == "cuda":
-            self._active_host = self._active_host.pin_memory()
+        self._stager = None        # pinned staging for the per-step flag upload (event-guarded reuse)
         self.gnorm_sq = torch.zeros(1, dtype=torch.float64, device=dev)
         self._pending_clip: Optional[float] = None
         self.grad_scale: Optional[torch.Tensor] = None    # set by the DP reducer (1/world)
@@ -71,8 +69,13 @@ class NekoAdamW(torch.optim.Optimizer):
         grp = self.param_groups[0]
         lr, (b1, b2), eps, wd = grp["lr"], grp["betas"], grp["eps"], grp["weight_decay"]
         act = self._active_groups()
-        self._active_host.copy_(torch.tensor(act, dtype=torch.int32))
-        self.active.copy_(self._active_host, non_blocking=True)
+        if self.active.is_cuda:
+            if self._stager is None:
+                from ..utils.utils import HostStager
+                self._stager = HostStager()
+            self.active.copy_(self._stager.upload(torch.tensor(act, dtype=torch.int32), self.active.device))
+        else:
+            self.active.copy_(torch.tensor(act, dtype=torch.int32))
         if self.flags_reduce is not None:
             self.flags_reduce(self.active)
         clip = self._pending_clip
