@@ -201,6 +201,66 @@ def stack_backward(P: StackParams, ctx: StackCtx, dhf: torch.Tensor,
 # ------------------------------------------------------------------------------------------------------
 # LM head + masked cross-entropy (gato_policy.py:172-186)
 # ------------------------------------------------------------------------------------------------------
+class KVDecoder:
+    """Incremental inference over ONE sequence (B = 1, no padding): SURVEY.md 8(f) rank 2.  The reference's
+    predict_* helpers (gato_policy.py:434-614) re-run the whole forward -- T positions through the stack and a (T, V)
+    logits tensor -- for every generated token.  Here the rows already seen keep their q/k/v in a per-layer [cap, 3d]
+    bf16 buffer (the layout the attention kernel reads): extend() pushes only the NEW rows through LayerNorm and the
+    GEMMs, appends their q/k/v, runs the attention kernel over the buffer (B = 1: cheap) and continues with the new
+    rows.  Exact as long as the window does not slide: a causal row never depends on later rows.  When the context is
+    full the reference truncates on the left and recomputes every remaining row WITHOUT the dropped ones, so the
+    caller resets and re-primes on the truncated window (same semantics, see GatoPolicy._decode_tokens)."""
+
+    def __init__(self, P: StackParams, cap: int, device):
+        self.P, self.cap, self.n = P, int(cap), 0
+        self.qkv = [torch.zeros(self.cap, 3 * P.d, dtype=BF16, device=device) for _ in P.layers]
+        self.kbias = torch.zeros(1, self.cap, dtype=F32, device=device)       # all positions real: no key bias
+        self.kstart = torch.zeros(1, dtype=torch.int32, device=device)
+
+    def reset(self) -> None:
+        self.n = 0
+
+    @torch.no_grad()
+    def extend(self, x_new: torch.Tensor) -> torch.Tensor:
+        """x_new (n, d) fp32 embeddings of the next n positions -> ln_f(hidden) of those positions, bf16 (n, d)."""
+        P = self.P
+        d, H = P.d, P.heads
+        hd = d // H
+        x = x_new.reshape(-1, d).to(F32).contiguous()
+        n, dev = x.shape[0], x.device
+        n0, T = self.n, self.n + n
+        if T > self.cap:
+            raise ValueError(f"KVDecoder: {T} positions exceed the capacity {self.cap}")
+        kb = self.kbias[:, :T].contiguous()
+        for li, lp in enumerate(P.layers):
+            a1 = torch.empty(n, d, dtype=BF16, device=dev)
+            ops.layernorm_fwd(x, lp.ln1_w, lp.ln1_b, y16=a1, eps=P.eps)
+            ops.gemm(a1, lp.w_qkv, n, 3 * d, d, b_kstrided=True, bias=lp.b_qkv, out_bf16=self.qkv[li][n0:T], ldcb=3 * d)
+            o_all, _ = ops.attn_fwd(self.qkv[li][:T], kb, self.kstart, 1, T, H, hd)
+            o = o_all[n0:T]
+            x1 = torch.empty(n, d, dtype=F32, device=dev)
+            ops.gemm(o, lp.w_o, n, d, d, b_kstrided=True, bias=lp.b_o, resid=x, out_f32=x1)
+            a2 = torch.empty(n, d, dtype=BF16, device=dev)
+            ops.layernorm_fwd(x1, lp.ln2_w, lp.ln2_b, y16=a2, eps=P.eps)
+            h = torch.empty(n, 4 * d, dtype=BF16, device=dev)
+            ops.gemm(a2, lp.w_fc, n, 4 * d, d, b_kstrided=True, bias=lp.b_fc, act=1, out_bf16=h)
+            x2 = torch.empty(n, d, dtype=F32, device=dev)
+            ops.gemm(h, lp.w_pr, n, d, 4 * d, b_kstrided=True, bias=lp.b_pr, resid=x1, out_f32=x2)
+            x = x2
+        hf16 = torch.empty(n, d, dtype=BF16, device=dev)
+        ops.layernorm_fwd(x, P.lnf_w, P.lnf_b, y16=hf16, eps=P.eps)
+        self.n = T
+        return hf16
+
+
+def lm_head_rows(Hp: HeadParams, h16: torch.Tensor) -> torch.Tensor:
+    """fp32 logits (n, V) of a few rows (decode: the last position only) -- never the (T, V) tensor."""
+    n, d = h16.shape
+    out = torch.empty(n, Hp.Vpad, dtype=F32, device=h16.device)
+    ops.gemm(h16.contiguous(), Hp.w, n, Hp.Vpad, d, ldb=d, out_f32=out, ldcf=Hp.Vpad)
+    return out[:, :Hp.V]
+
+
 def shift_targets(tokens: torch.Tensor, tmask: torch.Tensor, pmask: torch.Tensor):
     """Position t predicts token t+1 (gato_policy.py:176-181): returns (target [M] int64,
     sel [M] fp32 0/1 = pad_mask[:, :-1]*target_mask[:, 1:] with the last position 0, count)."""

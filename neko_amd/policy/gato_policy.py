@@ -452,10 +452,47 @@ class GatoPolicy(nn.Module):
         return (logits if return_logits else None), (loss if compute_loss else None)
 
     # ---- inference helpers (gato_policy.py:434-614): same loops, full forward per token -----------------
+    # KV-cached decode.  The reference re-runs the whole forward for every generated token;
+    # with kv_cache=True (default) only the new positions go through the stack (engine.KVDecoder) and the LM head
+    # runs on the last row only.  Semantics are the reference's, including the sliding window: once context_len
+    # positions are in flight the window is truncated on the left and RE-PRIMED (every remaining row recomputed
+    # without the dropped ones, exactly what the full forward does).  kv_cache=False keeps the full-forward loops.
+    def _decode_tokens(self, token_embeddings, n_tokens, start_token, end_token, deterministic):
+        """Autoregressive continuation of ONE unpadded sequence.  Returns (logits (n_tokens, end-start+1) fp32,
+        list of 0-d token tensors in the global vocabulary)."""
+        assert token_embeddings.shape[0] == 1, "decode works on a single sequence"
+        emb = token_embeddings[0, -self.context_len:, :].to(torch.float32)
+        dec = engine.KVDecoder(self.transformer._stack_params(), self.context_len, emb.device)
+        hp = self._head_params()
+        self._flat.ensure_shadow()
+        h = dec.extend(emb)
+        table = self._flat.view("embed_token.weight")
+        all_logits, tokens = [], []
+        for _ in range(n_tokens):
+            logits = engine.lm_head_rows(hp, h[-1:])[0, start_token:(end_token + 1)]
+            if deterministic:
+                token = torch.argmax(logits, dim=-1)
+            else:
+                token = torch.multinomial(torch.nn.functional.softmax(logits, dim=-1), num_samples=1)[0]
+            token = token + start_token
+            all_logits.append(logits)
+            tokens.append(token)
+            new = table[token].reshape(1, -1)
+            emb = torch.cat([emb, new], dim=0)
+            if emb.shape[0] > self.context_len:           # window slides: reference semantics = recompute the window
+                emb = emb[-self.context_len:]
+                dec.reset()
+                h = dec.extend(emb)
+            else:
+                h = dec.extend(new)
+        return torch.stack(all_logits, dim=0), tokens
+
     @torch.no_grad()
-    def predict_text(self, batch_dict, max_length=20, deterministic=True):
+    def predict_text(self, batch_dict, max_length=20, deterministic=True, kv_cache=True):
         start_token, end_token = self.token_starts["text"], self.token_ends["text"]
         token_embeddings, _, _, token_masks = self.tokenize_input_dicts([batch_dict])
+        if kv_cache:
+            return self._decode_tokens(token_embeddings, max_length, start_token, end_token, deterministic)
         concat_logits, predicted_tokens = None, []
         for _ in range(max_length):
             logits, _ = self.forward(token_embeddings=token_embeddings, token_masks=token_masks,
@@ -476,11 +513,14 @@ class GatoPolicy(nn.Module):
         return concat_logits, predicted_tokens
 
     @torch.no_grad()
-    def predict_response(self, image, prompt_tokens=[], max_length=128, deterministic=True):
+    def predict_response(self, image, prompt_tokens=[], max_length=128, deterministic=True, kv_cache=True):
         start_token, end_token = self.token_starts["text"], self.token_ends["text"]
         image_embeddings = self.image_embedding(image)
         n_images, n_patches = image_embeddings.shape[0], image_embeddings.shape[1]
         assert n_images == 1, "number of images should always be 1 for predicting response"
+        if kv_cache:
+            return self._predict_response_cached(image_embeddings, list(prompt_tokens), max_length, start_token, end_token,
+                                                 deterministic)
         pred_logits, response_tokens = None, []
         for idx in range(max_length):
             batch_dict = {"image_embeddings": image_embeddings, "text": torch.tensor(prompt_tokens + response_tokens)}
@@ -495,6 +535,36 @@ class GatoPolicy(nn.Module):
             response_tokens.append(next_token)
         return pred_logits, self.text_tokenizer.decode(response_tokens)
 
+    def _predict_response_cached(self, image_embeddings, prompt_tokens, max_length, start_token, end_token, deterministic):
+        """The packed sequence is [patches | prompt | response ... | SEP]: the logits of the last text position do not
+        depend on the trailing separator (causal), so the cache holds the sequence WITHOUT it and every step appends
+        the embedding row of the newly chosen token, taken from the packing kernels (token + local position embedding)
+        so the rows are the very ones the full forward would see."""
+        dev = self._dev()
+        dec = engine.KVDecoder(self.transformer._stack_params(), self.context_len, dev)
+        hp = self._head_params()
+        self._flat.ensure_shadow()
+        n_patches = image_embeddings.shape[1]
+        pred_logits, response_tokens = [], []
+        for idx in range(max_length):
+            batch_dict = {"image_embeddings": image_embeddings, "text": torch.tensor(prompt_tokens + response_tokens)}
+            emb, _, _, _ = self.tokenize_input_dicts([batch_dict])
+            n_seq = n_patches + len(prompt_tokens) + idx          # positions before the separator
+            rows = emb[0, :n_seq, :].to(torch.float32)
+            if n_seq > self.context_len:
+                raise ValueError("predict_response: sequence exceeds context_len")
+            if n_seq == 0:
+                raise ValueError("predict_response needs at least one position (image or prompt)")
+            h = dec.extend(rows[dec.n:])
+            nxt = engine.lm_head_rows(hp, h[-1:])[0, start_token:(end_token + 1)]
+            if deterministic:
+                next_token = torch.argmax(nxt).item()
+            else:
+                next_token = torch.multinomial(torch.nn.functional.softmax(nxt, dim=-1), num_samples=1).item()
+            pred_logits.append(nxt)
+            response_tokens.append(next_token)
+        return torch.stack(pred_logits, dim=0), self.text_tokenizer.decode(response_tokens)
+
     def predict_caption(self, image, max_length=128, deterministic=True):
         return self.predict_response(image, prompt_tokens=[], max_length=max_length, deterministic=deterministic)
 
@@ -503,7 +573,7 @@ class GatoPolicy(nn.Module):
                                      deterministic=deterministic)
 
     @torch.no_grad()
-    def predict_control(self, input: dict, task, deterministic: bool = True):
+    def predict_control(self, input: dict, task, deterministic: bool = True, kv_cache: bool = True):
         """gato_policy.py:556-614.  ``task.action_type`` is compared by class name (gymnasium is not a dependency)."""
         kind = getattr(task.action_type, "__name__", str(task.action_type))
         action_tokens = task.action_tokens
@@ -520,6 +590,11 @@ class GatoPolicy(nn.Module):
         token_embeddings = token_embeddings[:, :-action_tokens, :]
         token_masks = token_masks[:, :-action_tokens]
         predicted_tokens = []
+        if kv_cache:       # one priming pass over the history, then one cached step per action token
+            _, predicted_tokens = self._decode_tokens(token_embeddings, action_tokens, start_token, end_token, deterministic)
+            if kind == "Discrete":
+                return predicted_tokens[0] - start_token
+            return self.continuous_action_tokenizer.decode(torch.stack(predicted_tokens, dim=0))
         for _ in range(action_tokens):
             logits, _ = self.forward(token_embeddings=token_embeddings.contiguous(), token_masks=token_masks.contiguous(),
                                      token_target_masks=None, tokens=None)
