@@ -230,18 +230,30 @@ __global__ __launch_bounds__(NT, (HD <= 32 ? 4 : (HD <= 64 ? 3 : 2))) void attn_
       for (int r = 2; r < 16; ++r) mx = fmaxf(mx, st[r]);
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float sc = interior ? scale2 : 1.0f;      // interior scores are still unscaled
-      const float m_new = fmaxf(m_run, mx * sc);
-      const float alpha = exp2_fast(m_run - m_new);   // 2^(-inf) = 0 on the first tile
+      // lazy rescale: the reference maximum only moves when some row's maximum grew by more than 2^8 (wave-uniform
+      // decision).  Probabilities are then taken relative to a slightly stale maximum (p <= 256, harmless in fp32
+      // accumulators and bf16 operands) and the result is algebraically the same after the final division by l;
+      // it removes the per-sub-tile o *= alpha (8 packed multiplies of ~53 VALU instructions) almost always.
+      const float cand = mx * sc;
+      if (__builtin_amdgcn_ballot_w64(cand > m_run + 8.0f) != 0) {
+        const float m_new = fmaxf(m_run, cand);
+        const float alpha = exp2_fast(m_run - m_new);   // 2^(-inf) = 0 on the first tile
+        l_run *= alpha;
+#pragma unroll
+        for (int i = 0; i < C::IB; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+        m_run = m_new;
+      }
       float ps0 = 0.f, ps1 = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
-        st[r] = exp2_fast(fmaf(st[r], sc, -m_new));
-        st[r + 1] = exp2_fast(fmaf(st[r + 1], sc, -m_new));
+        st[r] = exp2_fast(fmaf(st[r], sc, -m_run));
+        st[r + 1] = exp2_fast(fmaf(st[r + 1], sc, -m_run));
         ps0 += st[r];
         ps1 += st[r + 1];
       }
-      l_run = fmaf(l_run, alpha, ps0 + ps1);
-      m_run = m_new;
+      l_run += ps0 + ps1;
       if (DROP) {   // attn_dropout on the probabilities (trajectory_gpt2.py:179): the normaliser stays undropped
         const uint32_t g0 = ((uint32_t)(b * H + h) * (uint32_t)T + (uint32_t)q) * (uint32_t)((T + 3) >> 2) +
                             (uint32_t)((k0 + t * 32 + 4 * (lane >> 5)) >> 2);
@@ -252,10 +264,6 @@ __global__ __launch_bounds__(NT, (HD <= 32 ? 4 : (HD <= 64 ? 3 : 2))) void attn_
           for (int e = 0; e < 4; ++e) st[4 * j + e] = drop_byte_keep(w, e, drop_thr) ? st[4 * j + e] * drop_scale : 0.f;
         }
       }
-#pragma unroll
-      for (int i = 0; i < C::IB; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
 #pragma unroll
       for (int h2 = 0; h2 < 2; ++h2) {
         const uint4 pw = make_uint4(pack_bf16x2(st[8 * h2 + 0], st[8 * h2 + 1]), pack_bf16x2(st[8 * h2 + 2], st[8 * h2 + 3]),
