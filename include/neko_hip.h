@@ -33,7 +33,7 @@ extern "C" {
 #define NEKO_ERR_UNSUPPORTED (-2)
 #define NEKO_ERR_LAUNCH (-3)
 
-#define NEKO_ABI_VERSION 5
+#define NEKO_ABI_VERSION 6
 
 int neko_abi_version(void);
 /* human-readable text for a return code (static storage) */
@@ -100,6 +100,21 @@ int neko_attn_fwd(const uint16_t* qkv, const float* kbias, const int* kstart, ui
 int neko_attn_bwd(const uint16_t* qkv, const uint16_t* out, const uint16_t* dout, const float* kbias,
                   const int* kstart, const float* lse, float* D, int* qflags, uint16_t* dqkv, int B, int T, int H,
                   int hd, int drop_thr, unsigned drop_key, float drop_scale, void* stream);
+
+/* Skinny-M (M <= 8, K <= 3072) companion of neko_gemm_bf16 for incremental decode: a pure weight stream instead of
+ * the tiled MFMA loop.  y[M,N] = x[M,K] . W (+ bias[N]) (act 1 = GELU on the bf16-rounded pre-activation) (+ resid),
+ * W bf16 either [K, ldw] (b_kstrided = 1, HF Conv1D (in,out) layout) or [N, ldw] (b_kstrided = 0, e.g. predict_token);
+ * outputs f32 and/or bf16 like the GEMM. */
+int neko_gemv_bf16(const uint16_t* x, long ldx, const uint16_t* W, long ldw, int b_kstrided, int M, int N, int K,
+                   const float* bias, const float* resid, long ldr, int act, float* Cf, long ldcf, uint16_t* Cb, long ldcb,
+                   void* stream);
+
+/* Single-query attention for KV-cached decode (gato_policy.py:434-614 re-run the whole forward per generated
+ * token; trajectory_gpt2.py:163-188 with a query length of 1).  cache bf16 [cap, 3*H*hd] (q|k|v rows, the layout
+ * neko_attn_fwd reads), row bf16 [3*H*hd] = the freshly projected q|k|v of position *pos (device int32, so the launch
+ * is shape-independent and HIP-graph capturable), out bf16 [H*hd].  Appends the row's k/v to cache[*pos]. */
+int neko_attn_decode(uint16_t* cache, const uint16_t* row, const int* pos, uint16_t* out, int H, int hd, int cap,
+                     void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Masked cross-entropy over a chunk of logits -- gato_policy.py:174-186 (shift, mask product,

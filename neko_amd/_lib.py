@@ -26,6 +26,8 @@ SIGNATURES = {
     "neko_mask_bias": [_vp, _vp, _vp, _i, _i, _vp],
     "neko_attn_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, C.c_uint, _f, _vp],
     "neko_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, C.c_uint, _f, _vp],
+    "neko_gemv_bf16": [_vp, _l, _vp, _l, _i, _i, _i, _i, _vp, _vp, _l, _i, _vp, _l, _vp, _l, _vp],
+    "neko_attn_decode": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "neko_ce_fwd_bwd": [_vp, _l, _i, _i, _vp, _vp, _vp, _vp, _l, _i, _vp],
     "neko_ce_bf16_inplace": [_vp, _l, _i, _i, _vp, _vp, _vp, _i, _i, _vp],
     "neko_pack_embed_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _i, _i, _i, _vp],

@@ -55,6 +55,15 @@ int neko_attn_bwd(const uint16_t* qkv, const uint16_t* out, const uint16_t* dout
                             S(stream));
 }
 
+int neko_gemv_bf16(const uint16_t* x, long ldx, const uint16_t* W, long ldw, int b_kstrided, int M, int N, int K,
+                   const float* bias, const float* resid, long ldr, int act, float* Cf, long ldcf, uint16_t* Cb, long ldcb,
+                   void* stream) {
+  return neko_gemv_bf16_impl(x, ldx, W, ldw, b_kstrided, M, N, K, bias, resid, ldr, act, Cf, ldcf, Cb, ldcb, S(stream));
+}
+int neko_attn_decode(uint16_t* cache, const uint16_t* row, const int* pos, uint16_t* out, int H, int hd, int cap,
+                     void* stream) {
+  return neko_attn_decode_impl(cache, row, pos, out, H, hd, cap, S(stream));
+}
 int neko_ce_fwd_bwd(const float* logits, long ldl, int V, int Vpad, const long long* target, const float* weight,
                     float* loss_row, uint16_t* dlogits, long ldd, int R, void* stream) {
   return neko_ce_fwd_bwd_impl(logits, ldl, V, Vpad, target, weight, loss_row, dlogits, ldd, R, S(stream));

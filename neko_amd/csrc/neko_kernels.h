@@ -49,6 +49,11 @@ int neko_attn_fwd_impl(const bf16_t* qkv, const float* kbias, const int* kstart,
 int neko_attn_bwd_impl(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const float* kbias, const int* kstart,
                        const float* lse, float* D, int* qflags, bf16_t* dqkv, int B, int T, int H, int hd,
                        int drop_thr, unsigned drop_key, float drop_scale, hipStream_t s);
+int neko_gemv_bf16_impl(const bf16_t* x, long ldx, const bf16_t* W, long ldw, int b_kstrided, int M, int N, int K,
+                        const float* bias, const float* resid, long ldr, int act, float* Cf, long ldcf, bf16_t* Cb,
+                        long ldcb, hipStream_t s);
+int neko_attn_decode_impl(bf16_t* cache, const bf16_t* row, const int* pos, bf16_t* out, int H, int hd, int cap,
+                          hipStream_t s);
 int neko_ce_fwd_bwd_impl(const float* logits, long ldl, int V, int Vpad, const long long* target, const float* weight,
                          float* loss_row, bf16_t* dlogits, long ldd, int R, hipStream_t s);
 int neko_ce_bf16_inplace_impl(bf16_t* z, long ld, int V, int Vpad, const long long* target, const float* weight,

@@ -216,9 +216,83 @@ class KVDecoder:
         self.qkv = [torch.zeros(self.cap, 3 * P.d, dtype=BF16, device=device) for _ in P.layers]
         self.kbias = torch.zeros(1, self.cap, dtype=F32, device=device)       # all positions real: no key bias
         self.kstart = torch.zeros(1, dtype=torch.int32, device=device)
+        self.pos = torch.zeros(1, dtype=torch.int32, device=device)           # device-side index of the next row
+        self.fast_row = P.d % 8 == 0 and 4 * P.d <= 3072                      # neko_gemv_bf16 limits (K <= 3072)
 
     def reset(self) -> None:
         self.n = 0
+        self.pos.zero_()
+
+    # ---- single-row step with a device-side position (HIP-graph capturable) -------------------------------------
+    def _one_row(self, x: torch.Tensor) -> torch.Tensor:
+        """x (1, d) fp32 at position *self.pos -> ln_f(hidden) (1, d) bf16.  No host-side shape depends on the position
+        (the attention call reads it from device memory), so this body can be captured once; the products are weight
+        streams (neko_gemv_bf16), not tiled GEMMs."""
+        P = self.P
+        d, H = P.d, P.heads
+        hd = d // H
+        dev = x.device
+        for li, lp in enumerate(P.layers):
+            a1 = torch.empty(1, d, dtype=BF16, device=dev)
+            ops.layernorm_fwd(x, lp.ln1_w, lp.ln1_b, y16=a1, eps=P.eps)
+            row = torch.empty(1, 3 * d, dtype=BF16, device=dev)
+            ops.gemv(a1, lp.w_qkv, 1, 3 * d, d, b_kstrided=True, bias=lp.b_qkv, out_bf16=row)
+            o = torch.empty(1, d, dtype=BF16, device=dev)
+            ops.attn_decode(self.qkv[li], row, self.pos, o, H, hd)
+            x1 = torch.empty(1, d, dtype=F32, device=dev)
+            ops.gemv(o, lp.w_o, 1, d, d, b_kstrided=True, bias=lp.b_o, resid=x, out_f32=x1)
+            a2 = torch.empty(1, d, dtype=BF16, device=dev)
+            ops.layernorm_fwd(x1, lp.ln2_w, lp.ln2_b, y16=a2, eps=P.eps)
+            h = torch.empty(1, 4 * d, dtype=BF16, device=dev)
+            ops.gemv(a2, lp.w_fc, 1, 4 * d, d, b_kstrided=True, bias=lp.b_fc, act=1, out_bf16=h)
+            x2 = torch.empty(1, d, dtype=F32, device=dev)
+            ops.gemv(h, lp.w_pr, 1, d, 4 * d, b_kstrided=True, bias=lp.b_pr, resid=x1, out_f32=x2)
+            x = x2
+        hf16 = torch.empty(1, d, dtype=BF16, device=dev)
+        ops.layernorm_fwd(x, P.lnf_w, P.lnf_b, y16=hf16, eps=P.eps)
+        return hf16
+
+    def capture_greedy_step(self, Hp: "HeadParams", table: torch.Tensor, start: int, end: int) -> None:
+        """Capture ONE greedy decode step as a HIP graph: embedding row g_x at position *pos -> stack -> LM head on that
+        row -> argmax over [start, end] -> g_logits / g_token, then g_x <- embedding of the chosen token and pos += 1.
+        At B = 1 a step is ~70 launches and launch-bound; replaying the graph costs one.  Call before priming (the
+        warm-up runs write cache row 0, which the prime overwrites)."""
+        d = self.P.d
+        dev = self.qkv[0].device
+        self.g_x = torch.zeros(1, d, dtype=F32, device=dev)
+        self.g_logits = torch.zeros(end - start + 1, dtype=F32, device=dev)
+        self.g_token = torch.zeros((), dtype=torch.int64, device=dev)
+
+        def body():
+            h = self._one_row(self.g_x)
+            lg = lm_head_rows(Hp, h)[0, start:(end + 1)]
+            tok = torch.argmax(lg, dim=-1) + start
+            self.g_logits.copy_(lg)
+            self.g_token.copy_(tok)
+            self.g_x.copy_(torch.index_select(table, 0, tok.reshape(1)))     # no host read: capturable
+            self.pos.add_(1)
+
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(2):                      # warm-up outside capture (allocator, lazy module loads)
+                self.pos.zero_()
+                body()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        self.pos.zero_()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            body()
+        self.pos.zero_()
+
+    def replay_greedy_step(self):
+        """One captured step; the caller has put the embedding of the previous token into g_x (the graph itself does
+        that for every step after the first).  Returns clones of (logits, token) -- device tensors, no host sync."""
+        if self.n >= self.cap:
+            raise ValueError("KVDecoder: capacity exhausted (slide the window on the eager path)")
+        self.graph.replay()
+        self.n += 1
+        return self.g_logits.clone(), self.g_token.clone()
 
     @torch.no_grad()
     def extend(self, x_new: torch.Tensor) -> torch.Tensor:
@@ -231,6 +305,11 @@ class KVDecoder:
         n0, T = self.n, self.n + n
         if T > self.cap:
             raise ValueError(f"KVDecoder: {T} positions exceed the capacity {self.cap}")
+        if n == 1 and self.fast_row:                # the decode step proper: weight-streaming products, 1-query attention
+            hf16 = self._one_row(x)                 # reads / appends at *pos == n0
+            self.n = T
+            self.pos.fill_(T)
+            return hf16
         kb = self.kbias[:, :T].contiguous()
         for li, lp in enumerate(P.layers):
             a1 = torch.empty(n, d, dtype=BF16, device=dev)
@@ -250,6 +329,7 @@ class KVDecoder:
         hf16 = torch.empty(n, d, dtype=BF16, device=dev)
         ops.layernorm_fwd(x, P.lnf_w, P.lnf_b, y16=hf16, eps=P.eps)
         self.n = T
+        self.pos.fill_(T)                           # device-side position of the next row
         return hf16
 
 
@@ -257,7 +337,10 @@ def lm_head_rows(Hp: HeadParams, h16: torch.Tensor) -> torch.Tensor:
     """fp32 logits (n, V) of a few rows (decode: the last position only) -- never the (T, V) tensor."""
     n, d = h16.shape
     out = torch.empty(n, Hp.Vpad, dtype=F32, device=h16.device)
-    ops.gemm(h16.contiguous(), Hp.w, n, Hp.Vpad, d, ldb=d, out_f32=out, ldcf=Hp.Vpad)
+    if n <= 8 and d <= 3072 and d % 8 == 0:
+        ops.gemv(h16.contiguous(), Hp.w, n, Hp.Vpad, d, b_kstrided=False, ldw=d, out_f32=out)     # streams the table once
+    else:
+        ops.gemm(h16.contiguous(), Hp.w, n, Hp.Vpad, d, ldb=d, out_f32=out, ldcf=Hp.Vpad)
     return out[:, :Hp.V]
 
 

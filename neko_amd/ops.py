@@ -178,6 +178,23 @@ def attn_bwd(qkv, out, dout, kbias, kstart, lse, B, T, H, hd, drop=None):
     return dqkv
 
 
+def gemv(x, W, M, N, K, *, b_kstrided, ldw=None, bias=None, resid=None, act=0, out_f32=None, out_bf16=None):
+    """y[M<=8, N] = x[M,K] . W (+bias)(GELU)(+resid): weight-streaming product for the decode step (neko_gemv_bf16)."""
+    _chk(x, BF16, "x"); _chk(W, BF16, "W")
+    assert x.stride(-1) == 1 and (out_f32 is not None or out_bf16 is not None)
+    _lib.call("neko_gemv_bf16", _p(x), x.stride(0) if x.dim() == 2 else K, _p(W), ldw if ldw is not None else W.stride(0),
+              int(b_kstrided), M, N, K, _p(bias), _p(resid), resid.stride(0) if resid is not None else 0, int(act),
+              _p(out_f32), out_f32.stride(0) if out_f32 is not None else 0,
+              _p(out_bf16), out_bf16.stride(0) if out_bf16 is not None else 0, _stream())
+
+
+def attn_decode(cache, row, pos, out, H, hd):
+    """Newest row (index *pos, device int32) of one sequence against its [cap, 3d] q|k|v cache; see neko_attn_decode."""
+    _chk(cache, BF16, "cache"); _chk(row, BF16, "row"); _chk(out, BF16, "out"); _chk(pos, torch.int32, "pos")
+    assert cache.is_contiguous() and cache.shape[1] == 3 * H * hd and row.numel() == 3 * H * hd and out.numel() == H * hd
+    _lib.call("neko_attn_decode", _p(cache), _p(row), _p(pos), _p(out), H, hd, cache.shape[0], _stream())
+
+
 def ce_bf16_inplace(z, V, Vpad, target, weight, loss_row=None, want_grad=True):
     """z bf16 [R, >=Vpad]: logits in, weight * (softmax - onehot) out (in place); see neko_ce_bf16_inplace."""
     _chk(z, BF16, "z"); _chk(target, torch.int64, "target"); _chk(weight, torch.float32, "weight")

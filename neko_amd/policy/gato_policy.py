@@ -18,6 +18,8 @@ from __future__ import annotations
 from collections import OrderedDict
 from typing import List, Optional, Sequence, Union
 
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -462,11 +464,38 @@ class GatoPolicy(nn.Module):
         list of 0-d token tensors in the global vocabulary)."""
         assert token_embeddings.shape[0] == 1, "decode works on a single sequence"
         emb = token_embeddings[0, -self.context_len:, :].to(torch.float32)
-        dec = engine.KVDecoder(self.transformer._stack_params(), self.context_len, emb.device)
         hp = self._head_params()
         self._flat.ensure_shadow()
-        h = dec.extend(emb)
         table = self._flat.view("embed_token.weight")
+        use_graph = (deterministic and n_tokens > 1 and emb.shape[0] + n_tokens - 1 <= self.context_len
+                     and os.environ.get("NEKO_DECODE_GRAPH", "1") != "0")
+        # decoders (cache buffers + the captured step) are kept per token range: capture costs ~100 ms, a rollout calls
+        # this thousands of times.  The graph holds pointers into the flat parameter storage and its bf16 shadow, which
+        # never move, so it stays valid across optimiser steps (ensure_shadow above refreshes the shadow in place).
+        if not hasattr(self, "_decoders"):
+            self._decoders = {}
+        key = (start_token, end_token) if use_graph else None
+        dec = self._decoders.get(key)
+        if dec is None:
+            dec = engine.KVDecoder(self.transformer._stack_params(), self.context_len, emb.device)
+            if use_graph:
+                dec.capture_greedy_step(hp, table, start_token, end_token)
+            self._decoders[key] = dec
+        dec.reset()
+        if use_graph:
+            # greedy continuation that never slides the window: one eager step on the primed rows, then every further
+            # token is ONE replay of a captured HIP graph (stack on the new row + LM head + argmax + embedding lookup)
+            h = dec.extend(emb)
+            logits = engine.lm_head_rows(hp, h[-1:])[0, start_token:(end_token + 1)]
+            token = torch.argmax(logits, dim=-1) + start_token
+            all_logits, tokens = [logits], [token]
+            dec.g_x.copy_(torch.index_select(table, 0, token.reshape(1)))
+            for _ in range(n_tokens - 1):
+                lg, tk = dec.replay_greedy_step()
+                all_logits.append(lg)
+                tokens.append(tk)
+            return torch.stack(all_logits, dim=0), tokens
+        h = dec.extend(emb)
         all_logits, tokens = [], []
         for _ in range(n_tokens):
             logits = engine.lm_head_rows(hp, h[-1:])[0, start_token:(end_token + 1)]
