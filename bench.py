@@ -107,11 +107,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # NEKO_BENCH_BACKEND=gloo + NEKO_BENCH_ONE_DEVICE=1: dry run of the multi-rank flow on a 1-GPU box (every rank on
+    # cuda:0, gradients reduced through the host) -- exercises the DP hooks, barriers and max-over-ranks timing, not
+    # a performance configuration
+    backend = os.environ.get("NEKO_BENCH_BACKEND", "nccl")
+    if os.environ.get("NEKO_BENCH_ONE_DEVICE") == "1":
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.distributed.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=dev)
+        else:
+            torch.distributed.init_process_group(backend)
 
     from neko_amd.dp import GradReducer
     from neko_amd.policy.gato_policy import GatoPolicy
@@ -223,7 +232,7 @@ def main():
                        "global_batch": world * B, "seq_len": Tlen, "parallelism": f"dp{world}"},
             "tokens_per_sec_per_gpu": value / world,
             "fwd_bwd_only_tokens_per_sec": (world * B * Tlen / el_fb) if el_fb else None,
-            "final_loss": float(loss),
+            "final_loss": float(loss.detach()),
             "step_mfma_frac": value / world * fpt / (MFMA_PEAK_TFLOPS * 1e12),
             "flops_per_token_fwd_bwd": fpt,
             "lm_head_rows_fraction": lm_frac,
