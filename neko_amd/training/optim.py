@@ -89,6 +89,36 @@ class NekoAdamW(torch.optim.Optimizer):
         self._pending_clip = None
         f.mark_shadow_fresh()
 
+    # ---- checkpoint / resume ("optimizer state for true resume") -------------------------
+    def state_dict(self):
+        """Adam moments of the flat storage, the per-range step counters and the hyper-parameters.  The moments are
+        stored per PARAMETER NAME (state_dict keys of the model), not as the flat buffer, so a checkpoint survives a
+        change of the flat layout (padding, range order)."""
+        f = self.flat
+        m, v = {}, {}
+        for name, (off, numel, shape) in f.offsets.items():
+            m[name] = self.m[off:off + numel].view(shape).detach().cpu().clone()
+            v[name] = self.v[off:off + numel].view(shape).detach().cpu().clone()
+        return {"format": "neko_amd.NekoAdamW/1", "exp_avg": m, "exp_avg_sq": v,
+                "steps": {g: int(t.item()) for g, t in self.steps.items()},
+                "param_groups": [{k: val for k, val in grp.items() if k != "params"} for grp in self.param_groups]}
+
+    def load_state_dict(self, sd):
+        if sd.get("format") != "neko_amd.NekoAdamW/1":
+            raise ValueError("not a NekoAdamW state_dict")
+        f = self.flat
+        missing = [n for n in f.offsets if n not in sd["exp_avg"]]
+        if missing:
+            raise KeyError(f"optimizer state lacks {missing[:3]}{'...' if len(missing) > 3 else ''}")
+        with torch.no_grad():
+            for name, (off, numel, shape) in f.offsets.items():
+                self.m[off:off + numel].copy_(sd["exp_avg"][name].reshape(-1).to(self.m.device))
+                self.v[off:off + numel].copy_(sd["exp_avg_sq"][name].reshape(-1).to(self.v.device))
+            for g, t in self.steps.items():
+                t.fill_(int(sd["steps"].get(g, 0)))
+        for grp, saved in zip(self.param_groups, sd["param_groups"]):
+            grp.update(saved)
+
     def zero_grad(self, set_to_none: bool = True):
         """One memset of the flat gradient; ``.grad`` of every parameter is detached again (set to None) so the
         next backward knows which parameters took part (torch's set_to_none semantics)."""

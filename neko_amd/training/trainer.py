@@ -44,7 +44,7 @@ class Trainer:
             logs = self.train_iteration(self.args.log_eval_freq, i)
         if self.args.save_model and self.args.save_mode == "last" and self.is_main:
             from ..utils.utils import save_model
-            save_model(self.model, self.exp_dir, f"checkpoint_{self.steps}", self.args)
+            save_model(self.model, self.exp_dir, f"checkpoint_{self.steps}", self.args, self.optimizer, self.scheduler)
         return logs
 
     def train_iteration(self, num_steps, iter):
@@ -79,7 +79,7 @@ class Trainer:
             print("=" * 80)
         if self.args.save_model and self.args.save_mode == "checkpoint" and self.is_main:
             from ..utils.utils import save_model
-            save_model(self.model, self.exp_dir, f"checkpoint_{self.steps}", self.args)
+            save_model(self.model, self.exp_dir, f"checkpoint_{self.steps}", self.args, self.optimizer, self.scheduler)
         return logs
 
     def sample_batch(self):

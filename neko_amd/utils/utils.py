@@ -12,7 +12,9 @@ class DotDict(dict):
     __delattr__ = dict.__delitem__
 
 
-def save_model(model, save_dir, save_name, config_args):
+def save_model(model, save_dir, save_name, config_args, optimizer=None, scheduler=None):
+    """gato/utils/utils.py:19-32: args.json + <save_name>.pt (the model state_dict, reference keys).  With `optimizer`
+    (and `scheduler`) a second file <save_name>.opt.pt holds what a true resume needs -- the reference never saves it."""
     os.makedirs(save_dir, exist_ok=True)
     args_path = os.path.join(save_dir, "args.json")
     if not os.path.exists(args_path):
@@ -21,6 +23,10 @@ def save_model(model, save_dir, save_name, config_args):
             json.dump(cfg, f)
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     torch.save(sd, os.path.join(save_dir, save_name + ".pt"))
+    if optimizer is not None:
+        torch.save({"optimizer": optimizer.state_dict(),
+                    "scheduler": scheduler.state_dict() if scheduler is not None else None},
+                   os.path.join(save_dir, save_name + ".opt.pt"))
 
 
 class HostStager:

@@ -107,3 +107,49 @@ def test_training_with_reference_default_dropout_trains():
     b = SyntheticTextTask(100, 256, seed=2, device=DEV).sample_batch(8)
     losses = _run(m, [b], 30, lr=2e-3, dropout_off=False)
     assert torch.isfinite(losses).all() and float(losses[-5:].mean()) < float(losses[:5].mean()) - 0.3, losses
+
+
+def test_checkpoint_resume_continues_the_same_trajectory(tmp_path):
+    """model.state_dict() + NekoAdamW.state_dict() after 3 steps, loaded into fresh objects, then 3 more steps ==
+    6 uninterrupted steps (the embedding scatter uses fp32 atomics, so equality is to rounding, not bitwise)."""
+    from neko_amd.tasks.synthetic import SyntheticTextTask
+    from neko_amd.training.optim import NekoAdamW
+
+    def fresh():
+        m = _policy(128, 2, 4, 64, vocab=256)
+        m.transformer.drop.p = 0.0
+        m.train()
+        return m, NekoAdamW(m, lr=1e-3, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.1)
+
+    batches = [SyntheticTextTask(50, 256, seed=s, device=DEV).sample_batch(4) for s in (1, 2)]
+
+    def run(m, opt, steps, first):
+        out = []
+        for s in range(first, first + steps):
+            _, loss = m.forward(inputs=batches[s % 2], compute_loss=True, return_logits=False)
+            loss.backward()
+            opt.clip_grad_norm_(1.0)
+            opt.step()
+            opt.zero_grad()
+            out.append(float(loss.detach()))
+        return out
+
+    m0, o0 = fresh()
+    ref = run(m0, o0, 6, 0)
+    m1, o1 = fresh()
+    part1 = run(m1, o1, 3, 0)
+    torch.save({"model": m1.state_dict(), "opt": o1.state_dict()}, tmp_path / "ck.pt")
+    m2, o2 = fresh()
+    ck = torch.load(tmp_path / "ck.pt", weights_only=False)
+    m2.load_state_dict(ck["model"])
+    o2.load_state_dict(ck["opt"])
+    part2 = run(m2, o2, 3, 3)
+    got = part1 + part2
+    assert all(abs(a - b) < 2e-5 * abs(b) for a, b in zip(got, ref)), (got, ref)
+    for k, v in m0.state_dict().items():
+        if v.dtype == torch.float32:
+            assert torch.allclose(m2.state_dict()[k], v, rtol=1e-4, atol=1e-6), k
+    # resuming WITHOUT the optimiser state diverges (the test would be vacuous otherwise)
+    m3, o3 = fresh()
+    m3.load_state_dict(ck["model"])
+    assert abs(run(m3, o3, 3, 3)[-1] - ref[-1]) > 2e-5 * abs(ref[-1])

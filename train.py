@@ -81,6 +81,15 @@ def main(args: TrainingArgs):
     scheduler = get_linear_warmup_cosine_decay_scheduler(
         optimizer, args.warmup_steps, args.training_steps, base_lr=args.learning_rate, init_lr=args.init_lr,
         min_lr=args.learning_rate / args.min_factor, cosine_decay=not args.disable_cosine_decay)
+    if args.init_checkpoint is not None:        # true resume when the optimiser file sits next to the checkpoint
+        opt_path = args.init_checkpoint[:-3] + ".opt.pt" if args.init_checkpoint.endswith(".pt") else None
+        if opt_path and os.path.exists(opt_path):
+            st = torch.load(opt_path, map_location="cpu", weights_only=False)
+            optimizer.load_state_dict(st["optimizer"])
+            if st.get("scheduler") is not None:
+                scheduler.load_state_dict(st["scheduler"])
+            if rank == 0:
+                print("resumed optimizer / scheduler state from", opt_path)
     dp = None
     if world > 1:
         dp = GradReducer(model._flat)
