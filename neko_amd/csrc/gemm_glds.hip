@@ -513,8 +513,7 @@ int forced_tile() {
 // Per-shape choice, from tools/gemm_bench.py on the shapes of the 768d step (MI355X, random operands):
 //   long contraction (weight gradients incl. split-K slices, LM-head dH/dW): 256x256, +5..15 % over 128x128;
 //   A k-contiguous x B k-strided (forward) with N >= 2048: 256x256 (+6..8 %);
-//   both k-contiguous (dgrad) with K >= 2048: 256x128 (+7..9 %); K = 768 dgrad keeps 128x128 (GELU' epilogue
-//   overlaps better at 3 blocks/CU);
+//   both k-contiguous (dgrad): K >= 2048 or N = 768: 256x128 (+7..9 %); K = 768 with N >= 2048 (GELU' dgrad): 256x256;
 //   LM-head logits (both k-contiguous, N = 52352): 256x256 (+4 % and fewer table re-reads);
 //   everything else 128x128 (3-stage, 3 blocks/CU).
 template <bool A_KC, bool B_KC>
@@ -526,7 +525,8 @@ int launch(const GemmArgs& a, hipStream_t s) {
     if (a.splitk > 1 || (klen >= 4096 && (long)a.M * a.N >= (long)256 * 256 * 8)) cfg = 3;
     else if (A_KC && !B_KC && a.N >= 2048 && big_out) cfg = 3;
     else if (A_KC && B_KC && klen >= 2048 && big_out && a.N % 128 == 0) cfg = 2;
-    else if (A_KC && B_KC && a.N >= 8192 && big_out) cfg = 3;       // LM-head logits: 4096 x 52352, K = 768
+    else if (A_KC && B_KC && a.N >= 2048 && big_out) cfg = 3;       // K = 768 dgrad through the MLP, LM-head logits
+    else if (A_KC && B_KC && big_out && a.N % 128 == 0) cfg = 2;    // K = 768, N = 768 dgrad (attention out)
     else cfg = klen >= 16384 ? 1 : 0;
   }
   switch (cfg) {
