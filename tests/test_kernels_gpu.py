@@ -70,6 +70,35 @@ def test_gemm_layouts(ops, layout, M, N, K, safe):
     close(out, ref, 2e-4, 2e-4 * math.sqrt(K), f"gemm {layout} safe={safe}")
 
 
+def test_gemm_many_tiles_fast_epilogues(ops):
+    """A shape with several hundred 256x256 / 128x128 tiles (more than one round of the chip) through the specialised
+    epilogues: forward-like (bias + bf16 / GELU + pre-activation / bias + residual f32) and dgrad-like (both operands
+    k-contiguous) launches against an fp32 matmul of the same bf16 inputs."""
+    g = torch.Generator().manual_seed(11)
+    M, N, K = 8192 + 256, 2304, 192                  # 33 x 9 = 297 tiles, 6 k-tiles each
+    A = rb(torch.randn(M, K, generator=g)); W = rb(torch.randn(K, N, generator=g) * 0.1)
+    bias = torch.randn(N, generator=g); resid = torch.randn(M, N, generator=g)
+    Ad, Wd = bf(A), bf(W)
+    ref = (Ad.float() @ Wd.float()).cpu() + bias
+    out16 = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(Ad, Wd, M, N, K, b_kstrided=True, bias=bias.to(DEV), out_bf16=out16)
+    close(out16, ref, 2 ** -7, 2e-3, "many-tiles bias+bf16")
+    pre = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(Ad, Wd, M, N, K, b_kstrided=True, bias=bias.to(DEV), act=1, pre_out=pre, out_bf16=out16)
+    close(pre, ref, 2 ** -7, 2e-3, "many-tiles pre")
+    close(out16, torch.nn.functional.gelu(pre.float().cpu()), 2 ** -7, 2e-3, "many-tiles gelu")
+    out32 = torch.empty(M, N, device=DEV)
+    ops.gemm(Ad, Wd, M, N, K, b_kstrided=True, bias=bias.to(DEV), resid=resid.to(DEV), out_f32=out32)
+    close(out32, ref + resid, 1e-4, 2e-3, "many-tiles bias+resid")
+    Wt = bf(W.t().contiguous())                      # [N, K]: both operands k-contiguous (dgrad form)
+    ops.gemm(Ad, Wt, M, N, K, out_bf16=out16)
+    close(out16, ref - bias, 2 ** -7, 2e-3, "many-tiles NT")
+    # run-to-run identical
+    o2 = torch.empty_like(out16)
+    ops.gemm(Ad, Wt, M, N, K, out_bf16=o2)
+    assert torch.equal(o2, out16)
+
+
 def test_gemm_epilogues(ops):
     g = torch.Generator().manual_seed(5)
     M, N, K = 300, 256, 192
