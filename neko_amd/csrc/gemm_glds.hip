@@ -194,9 +194,22 @@ __device__ __forceinline__ void epilogue_fast(const GemmArgs& p, f32x16 (&acc)[C
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) wbase[((r & 3) + 8 * (r >> 2)) * SWP + 32 * j] = acc[i][j][r];
+    // every global INPUT of this pass (GELU' argument, residual, accumulate target) is fetched up front: inside the step
+    // loop each load would sit behind the previous step's stores (possible aliasing) and cost a full HBM round trip,
+    // 32 of them per tile (the dgrad through the MLP projection spent half its time there)
+    constexpr int NST = 32 / RPI;
+    uint2 pre_act[(F & F_GELUBWD) ? NST : 1];
+    float4 pre_res[(F & F_RESID) ? NST : 1];
+    float4 pre_acc[(F & F_ACCUM) ? NST : 1];
+#pragma unroll
+    for (int st = 0; st < NST; ++st) {
+      if (F & F_GELUBWD) pre_act[st] = *reinterpret_cast<const uint2*>(pact + (long)st * sact);
+      if (F & F_RESID) pre_res[st] = *reinterpret_cast<const float4*>(pres + (long)st * sres);
+      if (F & F_ACCUM) pre_acc[st] = *reinterpret_cast<const float4*>(pcf + (long)st * scf);
+    }
     // same-wave LDS write -> read: ordered by the LDS queue, no barrier (a slab is private to its wave)
 #pragma unroll
-    for (int st = 0; st < 32 / RPI; ++st) {
+    for (int st = 0; st < NST; ++st) {
       const float4 a4 = *reinterpret_cast<const float4*>(rbase + st * RPI * SWP);
       float v[4] = {a4.x, a4.y, a4.z, a4.w};
       if (F & F_ALPHA) {
@@ -213,7 +226,7 @@ __device__ __forceinline__ void epilogue_fast(const GemmArgs& p, f32x16 (&acc)[C
         v[3] = gelu_f(__uint_as_float(p23 & 0xffff0000u));
       }
       if (F & F_GELUBWD) {
-        const uint2 q = *reinterpret_cast<const uint2*>(pact);
+        const uint2 q = pre_act[st];
         v[0] *= gelu_grad_f(__uint_as_float(q.x << 16));
         v[1] *= gelu_grad_f(__uint_as_float(q.x & 0xffff0000u));
         v[2] *= gelu_grad_f(__uint_as_float(q.y << 16));
@@ -221,13 +234,13 @@ __device__ __forceinline__ void epilogue_fast(const GemmArgs& p, f32x16 (&acc)[C
       }
       if (F & F_DROP) drop4(v, didx, p.drop_key, p.drop_thr, p.drop_scale);
       if (F & F_RESID) {
-        const float4 q = *reinterpret_cast<const float4*>(pres);
+        const float4 q = pre_res[st];
         v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w;
       }
       if (F & F_CF) {
         float4 o = make_float4(v[0], v[1], v[2], v[3]);
         if (F & F_ACCUM) {
-          const float4 q = *reinterpret_cast<const float4*>(pcf);
+          const float4 q = pre_acc[st];
           o.x += q.x; o.y += q.y; o.z += q.z; o.w += q.w;
         }
         *reinterpret_cast<float4*>(pcf) = o;
@@ -237,10 +250,11 @@ __device__ __forceinline__ void epilogue_fast(const GemmArgs& p, f32x16 (&acc)[C
       if (F & F_CF) pcf += scf;
       if (F & F_CB) pcb += scb;
       if (F & F_PRE) ppre += spre;
-      if (F & F_GELUBWD) pact += sact;
-      if (F & F_RESID) pres += sres;
       if (F & F_DROP) didx += sdrop;
     }
+    // the inputs were indexed from the pass base: advance them by the whole pass (32 rows)
+    if (F & F_GELUBWD) pact += (long)NST * sact;
+    if (F & F_RESID) pres += (long)NST * sres;
   }
 }
 
@@ -250,6 +264,17 @@ __device__ __forceinline__ bool try_epilogue_fast(const GemmArgs& p, f32x16 (&ac
                                                   int n0, int wm, int wn, int wave, int lane) {
 #if NEKO_GEMM_DIAG == 4
   if (p.M != 12345) return true;      // ablation: no epilogue at all
+#endif
+#if NEKO_GEMM_DIAG == 7
+  {                                   // ablation: accumulators kept live (MFMAs cannot be eliminated), no epilogue work
+#pragma unroll
+    for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+      for (int j = 0; j < C::TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[i][j][r]));
+    if (p.M != 12345) return true;
+  }
 #endif
   const bool to_ws = p.splitk > 1 && p.splitk_ws;
   if (p.splitk > 1 && !to_ws) return false;                                   // atomic split-K: generic path
