@@ -22,6 +22,9 @@
 namespace {
 
 constexpr int NT = 256;
+#ifndef NEKO_FWD_WAVES
+#define NEKO_FWD_WAVES 4   // forward waves per SIMD at hd = 32
+#endif
 #ifndef NEKO_DKV_WAVES
 #define NEKO_DKV_WAVES 3   // dK/dV waves per SIMD at hd = 32: the branch-free inner loop spills at 4 (128 VGPRs) and is 12 % slower
 #endif
@@ -130,7 +133,7 @@ __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (
 // forward
 // =====================================================================================================
 template <int HD, bool DROP>
-__global__ __launch_bounds__(NT, (HD <= 32 ? 4 : (HD <= 64 ? 3 : 2))) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ kbias,
+__global__ __launch_bounds__(NT, (HD <= 32 ? NEKO_FWD_WAVES : (HD <= 64 ? 3 : 2))) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ kbias,
                                                       const int* __restrict__ kstart, bf16_t* __restrict__ out,
                                                       float* __restrict__ lse, int B, int T, int H, float scale,
                                                       uint32_t drop_thr, uint32_t drop_key, float drop_scale) {
