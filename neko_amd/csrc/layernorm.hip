@@ -7,6 +7,7 @@
 // backward: dy f32 [M,d], x, mean, rstd, gamma (+ g_in f32 residual-stream grad)
 //           -> dx f32 = g_in + LN'(dy), dx16 bf16 copy (next dgrad/wgrad operand),
 //              per-block partial dgamma/dbeta -> reduced by a second kernel into the grads.
+#include <cstdlib>
 #include "neko_kernels.h"
 
 namespace {
@@ -92,20 +93,43 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     db[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   const float inv_d = 1.0f / (float)d;
-  for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
-    const float mu = mean[row], rs = rstd[row];
+  // Software-pipelined over rows: the three input rows (x, dy, residual-stream gradient) of row r + stride are requested
+  // before row r is reduced and stored, so a wave always has a full row of loads in flight.  (The first version loaded
+  // g_in only after the wave reduction -- a second serialized HBM round trip per row -- and ran at 3.6 TB/s; the
+  // forward, which has nothing between load and store, runs at 6.1 TB/s.)
+  const int stride = gridDim.x * 4;
+  float4 nx[NV], nd[NV], ng[NV];
+  float nmu = 0.f, nrs = 0.f;
+  auto fetch = [&](int row) {
+    nmu = mean[row];
+    nrs = rstd[row];
     const float4* xr = reinterpret_cast<const float4*>(x + (long)row * d);
     const float4* dr = reinterpret_cast<const float4*>(dy + (long)row * d);
-    float4 xh[NV], dv[NV];
+    const float4* gr = g_in ? reinterpret_cast<const float4*>(g_in + (long)row * d) : nullptr;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = lane + 64 * i;
+      const bool ok = c < nvec;
+      nx[i] = ok ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+      nd[i] = ok ? dr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+      ng[i] = (ok && gr) ? gr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  int row = blockIdx.x * 4 + wave;
+  if (row < M) fetch(row);
+  for (; row < M; row += stride) {
+    const float mu = nmu, rs = nrs;
+    float4 xh[NV], dv[NV], gv[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { xh[i] = nx[i]; dv[i] = nd[i]; gv[i] = ng[i]; }
+    if (row + stride < M) fetch(row + stride);            // next row in flight during this row's reduction
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int c = lane + 64 * i;
       if (c < nvec) {
-        const float4 xv = xr[c];
-        dv[i] = dr[c];
-        xh[i].x = (xv.x - mu) * rs; xh[i].y = (xv.y - mu) * rs;
-        xh[i].z = (xv.z - mu) * rs; xh[i].w = (xv.w - mu) * rs;
+        xh[i].x = (xh[i].x - mu) * rs; xh[i].y = (xh[i].y - mu) * rs;
+        xh[i].z = (xh[i].z - mu) * rs; xh[i].w = (xh[i].w - mu) * rs;
         dg[i].x += dv[i].x * xh[i].x; dg[i].y += dv[i].y * xh[i].y;
         dg[i].z += dv[i].z * xh[i].z; dg[i].w += dv[i].w * xh[i].w;
         db[i].x += dv[i].x; db[i].y += dv[i].y; db[i].z += dv[i].z; db[i].w += dv[i].w;
@@ -127,10 +151,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
         o.y = rs * (dv[i].y - m1 - xh[i].y * m2);
         o.z = rs * (dv[i].z - m1 - xh[i].z * m2);
         o.w = rs * (dv[i].w - m1 - xh[i].w * m2);
-        if (g_in) {
-          const float4 g = reinterpret_cast<const float4*>(g_in + (long)row * d)[c];
-          o.x += g.x; o.y += g.y; o.z += g.z; o.w += g.w;
-        }
+        if (g_in) { o.x += gv[i].x; o.y += gv[i].y; o.z += gv[i].z; o.w += gv[i].w; }
         if (dx) reinterpret_cast<float4*>(dx + (long)row * d)[c] = o;
         if (dx16) {
           // the bf16 copy feeds the dgrad/wgrad of the Linear that sits behind a residual dropout: it carries that
@@ -235,8 +256,9 @@ int neko_layernorm_fwd_impl(const float* x, const float* gamma, const float* bet
 
 // number of partial rows the backward writes for a given M (workspace = nblk*2*d floats)
 int neko_layernorm_bwd_blocks_impl(int M) {
+  static const int cap = [] { const char* e = getenv("NEKO_LN_BWD_BLOCKS"); return e ? atoi(e) : 256; }();   // one block per CU measured best (tools/ln_bench.py: 88 us vs 99 at 512)
   int nb = (M + 3) / 4;
-  return nb < 512 ? (nb < 1 ? 1 : nb) : 512;
+  return nb < cap ? (nb < 1 ? 1 : nb) : cap;
 }
 
 int neko_layernorm_bwd_impl(const float* dy, const float* x, const float* gamma, const float* mean,
