@@ -112,22 +112,31 @@ __global__ __launch_bounds__(256, 2) void resblock_fwd_kernel(const void* __rest
   const float bias2[3] = {b2[0], b2[1], b2[2]};
   const float inv_n = 1.0f / (float)(CPG * PS * PS);
 
-  for (int p = blockIdx.x; p < P; p += gridDim.x) {
-    const int b = p / (nh * nw), ph = (p / nw) % nh, pw = p % nw;
-    float xv[3];
+  // this thread's pixel of patch q (raw values): requested one patch ahead so the HBM latency hides behind the previous
+  // patch's compute instead of sitting in front of the first barrier
+  auto load_raw = [&](int q, float (&raw)[3]) {
+    const int b = q / (nh * nw), ph = (q / nw) % nh, pw = q % nw;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       const long off = (((long)b * 3 + i) * H + ph * PS + py) * W + pw * PS + px;
-      const float raw = U8 ? (float)reinterpret_cast<const unsigned char*>(images)[off]
-                           : reinterpret_cast<const float*>(images)[off];
+      raw[i] = U8 ? (float)reinterpret_cast<const unsigned char*>(images)[off] : reinterpret_cast<const float*>(images)[off];
+    }
+  };
+  float nraw[3] = {0.f, 0.f, 0.f};
+  if ((int)blockIdx.x < P) load_raw(blockIdx.x, nraw);
+  for (int p = blockIdx.x; p < P; p += gridDim.x) {
+    float xv[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
       // embeddings.py:40-42: x = (x / 255.0 * 2) - 1 ; x = x / sqrt(patch_size)
-      xv[i] = __fsub_rn(__fmul_rn(__fdiv_rn(raw, 255.0f), 2.0f), 1.0f) * 0.25f;
+      xv[i] = __fsub_rn(__fmul_rn(__fdiv_rn(nraw[i], 255.0f), 2.0f), 1.0f) * 0.25f;
       if (xp) xp[(long)p * 768 + i * 256 + tid] = xv[i];
     }
     __syncthreads();   // previous patch finished reading gx / z
 #pragma unroll
     for (int i = 0; i < 3; ++i) s.gx[i][py + 1][px + 1] = gelu_f(xv[i]);
     __syncthreads();
+    if (p + (int)gridDim.x < P) load_raw(p + gridDim.x, nraw);
     write_im2col_row<false>(s.im, &s.gx[0][0][0], tid, 1.0f);      // rows 64w .. 64w+63 are written and read by wave w only
 
     // ---- conv1: this wave's 2 pixel tiles x 4 channel tiles -----------------------------------------------------
@@ -353,14 +362,24 @@ __global__ __launch_bounds__(256, 1) void resblock_bwd_kernel(const float* __res
     for (int r = 0; r < 16; ++r) { dw2acc[t][r] = 0.f; dw1acc[t][r] = 0.f; }
   float b2acc[3] = {0.f, 0.f, 0.f};
 
+  // next patch's pixels are requested one patch ahead (see the forward kernel)
+  float nxv[3] = {0.f, 0.f, 0.f}, ng3[3] = {0.f, 0.f, 0.f};
+  auto load_px = [&](int q) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      nxv[i] = xp[(long)q * 768 + i * 256 + tid];
+      ng3[i] = dy[(long)q * 768 + i * 256 + tid];
+    }
+  };
+  if ((int)blockIdx.x < P) load_px(blockIdx.x);
 #pragma unroll 1
   for (int p = blockIdx.x; p < P; p += gridDim.x) {
     {
       float xv[3], g3[3];
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
-        xv[i] = xp[(long)p * 768 + i * 256 + tid];
-        g3[i] = dy[(long)p * 768 + i * 256 + tid];
+        xv[i] = nxv[i];
+        g3[i] = ng3[i];
         b2acc[i] += g3[i];
       }
       __syncthreads();      // previous patch is done with the halo tiles, cs/cst and red
@@ -371,6 +390,7 @@ __global__ __launch_bounds__(256, 1) void resblock_bwd_kernel(const float* __res
       }
     }
     __syncthreads();
+    if (p + (int)gridDim.x < P) load_px(p + gridDim.x);
     write_im2col_row<false>(s.im1, &s.gx[0][0][0], tid, 1.0f);     // rows 64w .. 64w+63: written and read by wave w only
     write_im2col_row<true>(s.im3, &s.dh3[0][0][0], tid, 0.0f);
 
