@@ -264,7 +264,7 @@ __global__ __launch_bounds__(NT, (HD <= 32 ? NEKO_FWD_WAVES : (HD <= 64 ? 3 : 2)
         for (int j = 0; j < 4; ++j) {          // registers 4j..4j+3 = keys +8j .. +8j+3: one word
           const uint32_t w = drop_word(g0 + 2 * j, drop_key);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) st[4 * j + e] = drop_byte_keep(w, e, drop_thr) ? st[4 * j + e] * drop_scale : 0.f;
+          for (int e = 0; e < 4; ++e) st[4 * j + e] = drop_byte_keep(w, e, drop_thr) ? st[4 * j + e] : 0.f;   // survivor scale: folded into the final 1/l
         }
       }
 #pragma unroll
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(NT, (HD <= 32 ? NEKO_FWD_WAVES : (HD <= 64 ? 3 : 2)
 
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   if (qvalid) {
-    const float inv = 1.0f / l_tot;
+    const float inv = (DROP ? drop_scale : 1.0f) / l_tot;
     bf16_t* orow = out + ((long)b * T + q) * d + h * HD;
 #pragma unroll
     for (int i = 0; i < C::IB; ++i)
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(NT, (HD <= 32 ? NEKO_FWD_WAVES : (HD <= 64 ? 3 : 2)
 // =====================================================================================================
 __global__ void attn_bwd_prep_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
                                      const float* __restrict__ kbias, float* __restrict__ D, int* __restrict__ qflags,
-                                     int B, int T, int H, int HD) {
+                                     int B, int T, int H, int HD, float inv_drop_scale) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;   // over B*T*H
   const long total = (long)B * T * H;
   if (idx < total) {
@@ -321,7 +321,7 @@ __global__ void attn_bwd_prep_kernel(const bf16_t* __restrict__ o, const bf16_t*
         acc += bf16_to_f32((bf16_t)(aw[e] >> 16)) * bf16_to_f32((bf16_t)(gw[e] >> 16));
       }
     }
-    D[((long)b * H + h) * T + q] = acc;
+    D[((long)b * H + h) * T + q] = acc * inv_drop_scale;      // D / s: the survivor scale s is folded out of dS (see dq / dkv)
   }
   // bit 0 / bit 1: the first / second 32-query half of the 64-query tile holds a masked (padded) query row
   const int nqt = (T + KT - 1) / KT;
@@ -435,7 +435,7 @@ __global__ __launch_bounds__(NT, (HD <= 32 ? 4 : (HD <= 64 ? 2 : 1))) void attn_
             const int r = 4 * j + e;
             const float pv = exp2_fast(fmaf(st[r], scale2, nlse));
             float dpe = dpt[r];
-            if (DROP) dpe = drop_byte_keep(w, e, drop_thr) ? dpe * drop_scale : 0.f;
+            if (DROP) dpe = drop_byte_keep(w, e, drop_thr) ? dpe : 0.f;
             st[r] = pv * (dpe - my_D);
           }
         }
@@ -451,7 +451,7 @@ __global__ __launch_bounds__(NT, (HD <= 32 ? 4 : (HD <= 64 ? 2 : 1))) void attn_
           const float sv = fmaf(ldsKb[t * 32 + c + 4 * (lane >> 5)], LOG2E, causal_ok ? st[r] * scale2 : MASK_VAL * LOG2E);
           const float pv = exp2_fast((c <= lim_len) ? sv - my_lse : -INFINITY);      // select, not a branch: 2^-inf = 0
           float dpe = dpt[r];
-          if (DROP) dpe = drop_byte_keep(w, e, drop_thr) ? dpe * drop_scale : 0.f;
+          if (DROP) dpe = drop_byte_keep(w, e, drop_thr) ? dpe : 0.f;
           st[r] = causal_ok ? pv * (dpe - my_D) : 0.f;
         }
       }
@@ -468,6 +468,8 @@ __global__ __launch_bounds__(NT, (HD <= 32 ? 4 : (HD <= 64 ? 2 : 1))) void attn_
     }
   }
 
+  // dS was formed as P o (keep*dP - D/s): the dropout survivor scale s multiplies the result once, here
+  const float qs = scale * (DROP ? drop_scale : 1.0f);
   if (qvalid) {
     bf16_t* orow = dqkv + ((long)b * T + q) * ld + h * HD;
 #pragma unroll
@@ -475,8 +477,8 @@ __global__ __launch_bounds__(NT, (HD <= 32 ? 4 : (HD <= 64 ? 2 : 1))) void attn_
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         uint2 pk;
-        pk.x = pack_bf16x2(dq[i][4 * g + 0] * scale, dq[i][4 * g + 1] * scale);
-        pk.y = pack_bf16x2(dq[i][4 * g + 2] * scale, dq[i][4 * g + 3] * scale);
+        pk.x = pack_bf16x2(dq[i][4 * g + 0] * qs, dq[i][4 * g + 1] * qs);
+        pk.y = pack_bf16x2(dq[i][4 * g + 2] * qs, dq[i][4 * g + 3] * qs);
         *reinterpret_cast<uint2*>(orow + i * 32 + 8 * g + 4 * (lane >> 5)) = pk;
       }
   }
@@ -598,8 +600,8 @@ __global__ __launch_bounds__(NT, (HD <= 32 ? NEKO_DKV_WAVES : (HD <= 64 ? 2 : 1)
           float pd = pv, dpe = dpt[r];
           if (DROP) {
             const bool keep = __builtin_amdgcn_ubfe(quad_bcast(mine[r >> 2], r & 3), ksh, 8) >= drop_thr;
-            pd = keep ? pv * drop_scale : 0.f;
-            dpe = keep ? dpe * drop_scale : 0.f;
+            pd = keep ? pv : 0.f;
+            dpe = keep ? dpe : 0.f;
           }
           st[r] = pd;
           dpt[r] = pv * (dpe - d_q);
@@ -616,8 +618,8 @@ __global__ __launch_bounds__(NT, (HD <= 32 ? NEKO_DKV_WAVES : (HD <= 64 ? 2 : 1)
         float pd = pv, dpe = dpt[r];
         if (DROP) {
           const bool keep = __builtin_amdgcn_ubfe(quad_bcast(mine[r >> 2], r & 3), ksh, 8) >= drop_thr;   // word of row r
-          pd = keep ? pv * drop_scale : 0.f;
-          dpe = keep ? dpe * drop_scale : 0.f;
+          pd = keep ? pv : 0.f;
+          dpe = keep ? dpe : 0.f;
         }
         st[r] = pd;                                              // dropped P (for dV)
         dpt[r] = causal_ok ? pv * (dpe - d_q) : 0.f;             // dS        (for dK)
@@ -640,6 +642,8 @@ __global__ __launch_bounds__(NT, (HD <= 32 ? NEKO_DKV_WAVES : (HD <= 64 ? 2 : 1)
     qt = qn;
   }
 
+  // P and dP were masked but not scaled in the loop (ldsD holds D/s): the survivor scale s is applied once, here
+  const float vsc = DROP ? drop_scale : 1.0f, ksc = scale * vsc;
   if (kvalid) {
     bf16_t* krow = dqkv + ((long)b * T + key) * ld + d + h * HD;
     bf16_t* vrow = krow + d;
@@ -648,11 +652,11 @@ __global__ __launch_bounds__(NT, (HD <= 32 ? NEKO_DKV_WAVES : (HD <= 64 ? 2 : 1)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         uint2 pk;
-        pk.x = pack_bf16x2(dk[i][4 * g + 0] * scale, dk[i][4 * g + 1] * scale);
-        pk.y = pack_bf16x2(dk[i][4 * g + 2] * scale, dk[i][4 * g + 3] * scale);
+        pk.x = pack_bf16x2(dk[i][4 * g + 0] * ksc, dk[i][4 * g + 1] * ksc);
+        pk.y = pack_bf16x2(dk[i][4 * g + 2] * ksc, dk[i][4 * g + 3] * ksc);
         *reinterpret_cast<uint2*>(krow + i * 32 + 8 * g + 4 * (lane >> 5)) = pk;
-        pk.x = pack_bf16x2(dv[i][4 * g + 0], dv[i][4 * g + 1]);
-        pk.y = pack_bf16x2(dv[i][4 * g + 2], dv[i][4 * g + 3]);
+        pk.x = pack_bf16x2(dv[i][4 * g + 0] * vsc, dv[i][4 * g + 1] * vsc);
+        pk.y = pack_bf16x2(dv[i][4 * g + 2] * vsc, dv[i][4 * g + 3] * vsc);
         *reinterpret_cast<uint2*>(vrow + i * 32 + 8 * g + 4 * (lane >> 5)) = pk;
       }
   }
@@ -679,7 +683,7 @@ int bwd_launch(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const f
   const float scale = 1.0f / sqrtf((float)HD);
   const long total = (long)B * T * H;
   hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, out, dout, kbias, D,
-                     qflags, B, T, H, HD);
+                     qflags, B, T, H, HD, thr ? 1.0f / dscale : 1.0f);
   NEKO_CHECK_LAUNCH();
   dim3 grid((T + 127) / 128, H, B);
   if (thr) {
