@@ -33,7 +33,7 @@ extern "C" {
 #define NEKO_ERR_UNSUPPORTED (-2)
 #define NEKO_ERR_LAUNCH (-3)
 
-#define NEKO_ABI_VERSION 6
+#define NEKO_ABI_VERSION 7
 
 int neko_abi_version(void);
 /* human-readable text for a return code (static storage) */
@@ -93,7 +93,11 @@ int neko_layernorm_bwd(const float* dy, const float* x, const float* gamma, cons
  *   out  bf16 [B*T, H*hd]    lse f32 [B,H,T]
  *   bwd workspace: D f32 [B*H*T], qflags int32 [B*ceil(T/64)]; dqkv bf16 [B*T, 3*H*hd] fully written.
  *   hd in {32, 64, 128}.
+ *   Two schedules compute the same sums: head-resident kernels (hd = 32, T <= 1024: one workgroup per (b, h) keeps
+ *   the head's K/V or Q/dO in LDS) and streaming kernels (any T, hd).  neko_attn_set_path(0) = automatic (default),
+ *   (1) = always streaming; returns the previous mode (any other argument only queries).  Process-wide tuning knob.
  * ------------------------------------------------------------------------------------------- */
+int neko_attn_set_path(int mode);
 int neko_mask_bias(const float* mask, float* kbias, int* kstart, int B, int T, void* stream);
 int neko_attn_fwd(const uint16_t* qkv, const float* kbias, const int* kstart, uint16_t* out, float* lse, int B,
                   int T, int H, int hd, int drop_thr, unsigned drop_key, float drop_scale, void* stream);

@@ -25,6 +25,7 @@ SIGNATURES = {
     "neko_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, C.c_uint, _f, _vp],
     "neko_mask_bias": [_vp, _vp, _vp, _i, _i, _vp],
     "neko_attn_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, C.c_uint, _f, _vp],
+    "neko_attn_set_path": [_i],
     "neko_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, C.c_uint, _f, _vp],
     "neko_gemv_bf16": [_vp, _l, _vp, _l, _i, _i, _i, _i, _vp, _vp, _l, _i, _vp, _l, _vp, _l, _vp],
     "neko_attn_decode": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],

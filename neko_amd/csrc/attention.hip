@@ -19,6 +19,8 @@
 // tiles are staged through padded LDS images; everything is fp32 except MFMA operands.
 #include "neko_kernels.h"
 
+extern int neko_attn_path_mode();
+
 namespace {
 
 constexpr int NT = 256;
@@ -685,6 +687,8 @@ int bwd_launch(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const f
   hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, out, dout, kbias, D,
                      qflags, B, T, H, HD, thr ? 1.0f / dscale : 1.0f);
   NEKO_CHECK_LAUNCH();
+  if (neko_attn_path_mode() == 0 && neko_attn_res_applicable(T, HD))
+    return neko_attn_bwd_res_impl(qkv, dout, kbias, kstart, lse, D, dqkv, B, T, H, thr, key, dscale, s);
   dim3 grid((T + 127) / 128, H, B);
   if (thr) {
     hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, true>), grid, dim3(NT), 0, s, qkv, dout, kbias, kstart, lse, D, dqkv, B, T,
@@ -705,10 +709,22 @@ int bwd_launch(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const f
 
 }  // namespace
 
+// schedule selection: 0 = automatic (head-resident kernels of attention_res.hip when they apply), 1 = always the
+// streaming kernels of this file.  A tuning / test knob, not part of the numerics: both schedules compute the same sums.
+static int g_attn_path = 0;
+int neko_attn_path_mode() { return g_attn_path; }
+int neko_attn_set_path_impl(int mode) {
+  const int prev = g_attn_path;
+  if (mode == 0 || mode == 1) g_attn_path = mode;
+  return prev;
+}
+
 int neko_attn_fwd_impl(const bf16_t* qkv, const float* kbias, const int* kstart, bf16_t* out, float* lse, int B, int T,
                        int H, int hd, int drop_thr, unsigned drop_key, float drop_scale, hipStream_t s) {
   if (B <= 0 || T <= 0) return NEKO_OK;
   if (!qkv || !kbias || !out || !lse || H <= 0 || drop_thr < 0 || drop_thr > 255) return NEKO_ERR_ARG;
+  if (g_attn_path == 0 && neko_attn_res_applicable(T, hd))
+    return neko_attn_fwd_res_impl(qkv, kbias, kstart, out, lse, B, T, H, drop_thr, drop_key, drop_scale, s);
   switch (hd) {
     case 32: return fwd_launch<32>(qkv, kbias, kstart, out, lse, B, T, H, drop_thr, drop_key, drop_scale, s);
     case 64: return fwd_launch<64>(qkv, kbias, kstart, out, lse, B, T, H, drop_thr, drop_key, drop_scale, s);

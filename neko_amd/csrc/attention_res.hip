@@ -1,0 +1,569 @@
+// Head-resident attention for hd = 32, T <= 1024: one workgroup owns one (batch, head) and keeps the head's whole
+// K and V (forward, dQ) or Q and dO (dK/dV) in LDS -- 2 x T x 64 B = 128 KB at T = 1024 of the 160 KB a gfx950 CU has.
+// Same arithmetic, masks (reference-literal finite -1e4 semantics, trajectory_gpt2.py:163-188,663-679), dropout
+// indexing and output layout as the streaming kernels in attention.hip; what changes is the schedule:
+//
+//   * the streaming kernels restage a 64-key tile per iteration behind two block barriers plus a block-wide OR
+//     (three more barriers); at hd = 32 a wave has only ~250 VALU + 8 MFMA instructions of work per tile, so the
+//     barriers and the 4.5x re-read of every K/V tile by the query tiles above it dominated (wave-parked 34 % +
+//     issue-stalled 20 % of wave cycles in the first PMC pass).  Here there is ONE barrier per workgroup: after the
+//     images are staged every wave runs its own key loop with no further synchronisation.
+//   * causal balance: the 32-row blocks of the head are handed out heaviest first from an LDS counter (longest-
+//     processing-time-first), so any wave count balances: 16 waves per workgroup (4 per SIMD, <= 128 VGPRs) in the
+//     forward, 12 (3 per SIMD, <= 168 VGPRs: the backward bodies spill at 128) in dQ and dK/dV.
+//   * the images are natural [row][32] bf16 with 64-byte rows and the 16-byte piece index XOR (row>>2)&3: conflict-
+//     free for both the ds_read_b128 row fragments (S = K.Q^T operands) and the ds_read_b64_tr_b16 column fragments
+//     (the K^T / V^T / Q^T / dO^T operands), so no transposed copy is built.
+//   * workgroup ids are paired so that heads 2j and 2j+1 of one batch row (the two halves of every 128-byte line of
+//     the [B*T, 3d] qkv matrix) run on the same XCD.
+#include "neko_kernels.h"
+
+namespace {
+
+constexpr float MASK_VAL = -10000.0f;
+constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+__device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// image: [rows][32 bf16], 64-byte rows; 16-byte piece p of row r is stored at piece p ^ ((r>>2)&3)
+__device__ __forceinline__ int img_off(int row, int piece) { return row * 64 + ((piece ^ ((row >> 2) & 3)) << 4); }
+
+// MFMA operand with the image ROWS as its 32 rows/columns: row (rowbase + lane%32), head-dim slots ks*16 + 8*(lane/32) + 0..7
+__device__ __forceinline__ bf16x8_v frag_rows(const char* img, int rowbase, int ks, int lane) {
+  const uint4 v = *reinterpret_cast<const uint4*>(img + img_off(rowbase + (lane & 31), ks * 2 + (lane >> 5)));
+  return __builtin_bit_cast(bf16x8_v, v);
+}
+// MFMA operand with the image COLUMNS (head dim) as its 32 rows: contraction slot j = image row
+// rowbase + 16*s + 8*(j>>2) + 4*(lane/32) + (j&3) -- the order a 32x32 accumulator leaves in a lane (frag_from_acc).
+// rowbase must be a multiple of 32.  Each 16-lane group reads a [4 rows][16 columns] block transposed.
+__device__ __forceinline__ bf16x8_v frag_cols(const char* img, int rowbase, int s, int lane) {
+  const int g = lane >> 4, c16 = lane & 15;
+  const int col = 16 * (g & 1) + 4 * (c16 & 3);
+  const int r_lo = 16 * s + 4 * (g >> 1) + (c16 >> 2), r_hi = r_lo + 8;
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  const char* base = img + rowbase * 64 + ((col & 7) << 1);
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + r_lo * 64 + (((col >> 3) ^ ((r_lo >> 2) & 3)) << 4)));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + r_hi * 64 + (((col >> 3) ^ ((r_hi >> 2) & 3)) << 4)));
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  s16x8 r;
+  r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+  r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+  return __builtin_bit_cast(bf16x8_v, r);
+}
+// registers 8*s2 .. 8*s2+7 of a 32x32 accumulator as a bf16 operand (s2 = 0, 1)
+__device__ __forceinline__ bf16x8_v frag_from_acc(const f32x16& a, int s2) {
+  const int o = 8 * s2;
+  const uint4 r = make_uint4(pack_bf16x2(a[o + 0], a[o + 1]), pack_bf16x2(a[o + 2], a[o + 3]),
+                             pack_bf16x2(a[o + 4], a[o + 5]), pack_bf16x2(a[o + 6], a[o + 7]));
+  return __builtin_bit_cast(bf16x8_v, r);
+}
+// own-row operand straight from HBM (row pointer, head-dim slots ks*16 + 8*(lane/32)..+7)
+__device__ __forceinline__ void row_frags(const bf16_t* __restrict__ rowptr, bool valid, int lane, bf16x8_v (&f)[2]) {
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (valid) v = *reinterpret_cast<const uint4*>(rowptr + ks * 16 + (lane >> 5) * 8);
+    f[ks] = __builtin_bit_cast(bf16x8_v, v);
+  }
+}
+__device__ __forceinline__ uint32_t quad_bcast(uint32_t x, int i) {   // value of lane (lane & ~3) + i, i literal 0..3
+  switch (i) {
+    case 0: return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x00, 0xf, 0xf, true);
+    case 1: return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x55, 0xf, 0xf, true);
+    case 2: return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0xAA, 0xf, 0xf, true);
+    default: return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0xFF, 0xf, 0xf, true);
+  }
+}
+// workgroup id -> (batch*H + head): ids n and n+8 run on the same XCD and get heads 2p and 2p+1
+__device__ __forceinline__ int pair_remap(int n, int total) {
+  const int full = total & ~15;
+  if (n >= full) return n;
+  return 2 * ((n >> 4) * 8 + (n & 7)) + ((n >> 3) & 1);
+}
+
+// next work item of the workgroup's queue (wave-uniform); the counter lives in LDS and is zeroed before the staging barrier
+__device__ __forceinline__ int next_item(int* counter, int lane) {
+  int v = 0;
+  if (lane == 0) v = atomicAdd(counter, 1);
+  return __builtin_amdgcn_readfirstlane(v);
+}
+
+// stage two [T][32] bf16 matrices (row strides lda / ldb elements) into swizzled images, rows >= T zero
+__device__ __forceinline__ void stage_pair(const bf16_t* __restrict__ a, long lda, const bf16_t* __restrict__ b, long ldb,
+                                           char* imgA, char* imgB, int T, int Tp, int tid, int nthr) {
+  const int total = Tp * 4;
+  for (int c0 = 0; c0 < total; c0 += nthr * 4) {
+    uint4 ra[4], rb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = c0 + i * nthr + tid, row = c >> 2, p = c & 3;
+      ra[i] = make_uint4(0, 0, 0, 0);
+      rb[i] = make_uint4(0, 0, 0, 0);
+      if (c < total && row < T) {
+        ra[i] = *reinterpret_cast<const uint4*>(a + (long)row * lda + p * 8);
+        rb[i] = *reinterpret_cast<const uint4*>(b + (long)row * ldb + p * 8);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = c0 + i * nthr + tid, row = c >> 2, p = c & 3;
+      if (c < total) {
+        *reinterpret_cast<uint4*>(imgA + img_off(row, p)) = ra[i];
+        *reinterpret_cast<uint4*>(imgB + img_off(row, p)) = rb[i];
+      }
+    }
+  }
+}
+// bit j: 32-position block j holds a position with a non-zero key bias (a padded key == a masked query row)
+__device__ __forceinline__ uint32_t pad_mask_of(const float* __restrict__ kb, int T, int nblk, int lane) {
+  uint32_t m = 0;
+  for (int j = 0; j < nblk; j += 2) {
+    const int i = j * 32 + lane;
+    const float v = (i < T) ? kb[i] : 0.f;
+    const unsigned long long bal = __builtin_amdgcn_ballot_w64(v != 0.f);
+    if ((uint32_t)bal) m |= 1u << j;
+    if ((uint32_t)(bal >> 32)) m |= 2u << j;
+  }
+  return m;
+}
+
+// =====================================================================================================
+// forward
+// =====================================================================================================
+template <bool DROP>
+__global__ __launch_bounds__(1024) void attn_fwd_res_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ kbias,
+                                                            const int* __restrict__ kstart, bf16_t* __restrict__ out,
+                                                            float* __restrict__ lse, int B, int T, int H, float scale,
+                                                            uint32_t drop_thr, uint32_t drop_key, float drop_scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int Tp = (T + 31) & ~31, nblk = Tp >> 5;
+  char* imgK = smem;
+  char* imgV = smem + Tp * 64;
+  float* ldsKb = reinterpret_cast<float*>(smem + Tp * 128);
+  int* queue = reinterpret_cast<int*>(ldsKb + Tp);
+
+  const int tid = threadIdx.x, lane = tid & 63, nthr = blockDim.x;
+  if (tid == 0) *queue = 0;
+  const int hb = pair_remap(blockIdx.x, B * H);
+  const int b = hb / H, h = hb % H;
+  const int d = H * 32;
+  const long ld = 3L * d;
+  const bf16_t* qbase = qkv + (long)b * T * ld + h * 32;
+  const float* kb = kbias + (long)b * T;
+
+  stage_pair(qbase + d, ld, qbase + 2 * d, ld, imgK, imgV, T, Tp, tid, nthr);
+  for (int i = tid; i < Tp; i += nthr) ldsKb[i] = (i < T) ? kb[i] * LOG2E : 0.f;
+  const uint32_t padmask = pad_mask_of(kb, T, nblk, lane);
+  const int kb_first = kstart ? (kstart[b] >> 5) : 0;
+  __syncthreads();
+
+  const float scale2 = scale * LOG2E;
+#pragma unroll 1
+  for (int item = next_item(queue, lane); item < nblk; item = next_item(queue, lane)) {
+    const int qb = nblk - 1 - item;                    // late query blocks see the most keys: heaviest first
+    const int q = qb * 32 + (lane & 31);
+    const bool qvalid = q < T;
+    bf16x8_v qf[2];
+    row_frags(qbase + (long)q * ld, qvalid, lane, qf);
+    // a wave that holds a masked (padded) query row visits every key: the reference's finite masks let such a row see
+    // them; for every other row the keys beyond its diagonal contribute exp(-1e4 - m) == 0 in fp32
+    const bool wave_full = (padmask >> qb) & 1;
+    const int kb_beg = wave_full ? 0 : min(kb_first, qb);
+    const int kb_end = wave_full ? nblk : qb + 1;
+
+    f32x16 o;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+#pragma unroll 1
+    for (int kbk = kb_beg; kbk < kb_end; ++kbk) {
+      const int k0 = kbk * 32;
+      f32x16 st;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(imgK, k0, ks, lane), qf[ks], st, 0, 0, 0);
+      const bool interior = (kbk < qb) && !((padmask >> kbk) & 1) && (k0 + 32 <= T);
+      if (!interior) {
+        const int lim_causal = q - k0 - 4 * (lane >> 5);        // key <= q  <=>  c(r) <= lim_causal
+        const int lim_len = T - 1 - k0 - 4 * (lane >> 5);       // key <  T  <=>  c(r) <= lim_len
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int c = (r & 3) + 8 * (r >> 2);
+          float v = (c <= lim_causal) ? st[r] * scale2 : MASK_VAL * LOG2E;
+          v += ldsKb[k0 + c + 4 * (lane >> 5)];
+          st[r] = (c <= lim_len) ? v : -INFINITY;
+        }
+      }
+      float mx = fmaxf(st[0], st[1]);
+#pragma unroll
+      for (int r = 2; r < 16; ++r) mx = fmaxf(mx, st[r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float sc = interior ? scale2 : 1.0f;      // interior scores are still unscaled
+      // lazy rescale (see attention.hip): the running maximum only moves when some row's maximum grew by more than 2^8
+      const float cand = mx * sc;
+      if (__builtin_amdgcn_ballot_w64(cand > m_run + 8.0f) != 0) {
+        const float m_new = fmaxf(m_run, cand);
+        const float alpha = exp2_fast(m_run - m_new);   // 2^(-inf) = 0 on the first tile
+        l_run *= alpha;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] *= alpha;
+        m_run = m_new;
+      }
+      float ps0 = 0.f, ps1 = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        st[r] = exp2_fast(fmaf(st[r], sc, -m_run));
+        st[r + 1] = exp2_fast(fmaf(st[r + 1], sc, -m_run));
+        ps0 += st[r];
+        ps1 += st[r + 1];
+      }
+      l_run += ps0 + ps1;
+      if (DROP) {   // attn_dropout on the probabilities (trajectory_gpt2.py:179): the normaliser stays undropped
+        const uint32_t g0 = ((uint32_t)(b * H + h) * (uint32_t)T + (uint32_t)q) * (uint32_t)((T + 3) >> 2) +
+                            (uint32_t)((k0 + 4 * (lane >> 5)) >> 2);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {          // registers 4j..4j+3 = keys +8j .. +8j+3: one word
+          const uint32_t w = drop_word(g0 + 2 * j, drop_key);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) st[4 * j + e] = drop_byte_keep(w, e, drop_thr) ? st[4 * j + e] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(imgV, k0, s2, lane), frag_from_acc(st, s2), o, 0, 0, 0);
+    }
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    if (qvalid) {
+      const float inv = (DROP ? drop_scale : 1.0f) / l_tot;
+      bf16_t* orow = out + ((long)b * T + q) * d + h * 32;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        uint2 pk;
+        pk.x = pack_bf16x2(o[4 * g + 0] * inv, o[4 * g + 1] * inv);
+        pk.y = pack_bf16x2(o[4 * g + 2] * inv, o[4 * g + 3] * inv);
+        *reinterpret_cast<uint2*>(orow + 8 * g + 4 * (lane >> 5)) = pk;
+      }
+      if (lane < 32) lse[((long)b * H + h) * T + q] = m_run * LN2 + __logf(l_tot);
+    }
+  }
+}
+
+// =====================================================================================================
+// backward dQ: lanes own queries (same geometry as forward); images K and V
+// =====================================================================================================
+template <bool DROP>
+__global__ __launch_bounds__(768) void attn_dq_res_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+                                                           const float* __restrict__ kbias, const int* __restrict__ kstart,
+                                                           const float* __restrict__ lse, const float* __restrict__ Dv,
+                                                           bf16_t* __restrict__ dqkv, int B, int T, int H, float scale,
+                                                           uint32_t drop_thr, uint32_t drop_key, float drop_scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int Tp = (T + 31) & ~31, nblk = Tp >> 5;
+  char* imgK = smem;
+  char* imgV = smem + Tp * 64;
+  float* ldsKb = reinterpret_cast<float*>(smem + Tp * 128);
+  int* queue = reinterpret_cast<int*>(ldsKb + Tp);
+
+  const int tid = threadIdx.x, lane = tid & 63, nthr = blockDim.x;
+  if (tid == 0) *queue = 0;
+  const int hb = pair_remap(blockIdx.x, B * H);
+  const int b = hb / H, h = hb % H;
+  const int d = H * 32;
+  const long ld = 3L * d;
+  const bf16_t* qbase = qkv + (long)b * T * ld + h * 32;
+  const float* kb = kbias + (long)b * T;
+
+  stage_pair(qbase + d, ld, qbase + 2 * d, ld, imgK, imgV, T, Tp, tid, nthr);
+  for (int i = tid; i < Tp; i += nthr) ldsKb[i] = (i < T) ? kb[i] * LOG2E : 0.f;
+  const uint32_t padmask = pad_mask_of(kb, T, nblk, lane);
+  const int kb_first = kstart ? (kstart[b] >> 5) : 0;
+  __syncthreads();
+
+  const float scale2 = scale * LOG2E;
+#pragma unroll 1
+  for (int item = next_item(queue, lane); item < nblk; item = next_item(queue, lane)) {
+    const int qb = nblk - 1 - item;                    // late query blocks see the most keys: heaviest first
+    const int q = qb * 32 + (lane & 31);
+    const bool qvalid = q < T;
+    bf16x8_v qf[2], dof[2];
+    row_frags(qbase + (long)q * ld, qvalid, lane, qf);
+    row_frags(dout + ((long)b * T + q) * d + h * 32, qvalid, lane, dof);
+    const float my_lse = (qvalid ? lse[((long)b * H + h) * T + q] : 0.f) * LOG2E;
+    const float my_D = qvalid ? Dv[((long)b * H + h) * T + q] : 0.f;
+    const bool wave_full = (padmask >> qb) & 1;
+    const int kb_beg = wave_full ? 0 : min(kb_first, qb);
+    const int kb_end = wave_full ? nblk : qb + 1;
+
+    f32x16 dq;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dq[r] = 0.f;
+
+#pragma unroll 1
+    for (int kbk = kb_beg; kbk < kb_end; ++kbk) {
+      const int k0 = kbk * 32;
+      f32x16 st, dpt;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { st[r] = 0.f; dpt[r] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(imgK, k0, ks, lane), qf[ks], st, 0, 0, 0);
+        dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(imgV, k0, ks, lane), dof[ks], dpt, 0, 0, 0);
+      }
+      // dS^T = P^T o (keep*dP^T - D/s); zero where the score was REPLACED by the causal constant
+      const uint32_t g0 = ((uint32_t)(b * H + h) * (uint32_t)T + (uint32_t)q) * (uint32_t)((T + 3) >> 2) +
+                          (uint32_t)((k0 + 4 * (lane >> 5)) >> 2);
+      const bool interior = (kbk < qb) && !((padmask >> kbk) & 1) && (k0 + 32 <= T);
+      if (interior) {
+        const float nlse = -my_lse;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const uint32_t w = DROP ? drop_word(g0 + 2 * j, drop_key) : 0u;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * j + e;
+            const float pv = exp2_fast(fmaf(st[r], scale2, nlse));
+            float dpe = dpt[r];
+            if (DROP) dpe = drop_byte_keep(w, e, drop_thr) ? dpe : 0.f;
+            st[r] = pv * (dpe - my_D);
+          }
+        }
+      } else {
+        const int lim_causal = q - k0 - 4 * (lane >> 5);
+        const int lim_len = T - 1 - k0 - 4 * (lane >> 5);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const uint32_t w = DROP ? drop_word(g0 + 2 * j, drop_key) : 0u;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * j + e;
+            const int c = (r & 3) + 8 * (r >> 2);
+            const bool causal_ok = c <= lim_causal;
+            const float sv = ldsKb[k0 + c + 4 * (lane >> 5)] + (causal_ok ? st[r] * scale2 : MASK_VAL * LOG2E);
+            const float pv = exp2_fast((c <= lim_len) ? sv - my_lse : -INFINITY);      // select, not a branch: 2^-inf = 0
+            float dpe = dpt[r];
+            if (DROP) dpe = drop_byte_keep(w, e, drop_thr) ? dpe : 0.f;
+            st[r] = causal_ok ? pv * (dpe - my_D) : 0.f;
+          }
+        }
+      }
+      // dQ^T += K^T . dS^T
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+        dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(imgK, k0, s2, lane), frag_from_acc(st, s2), dq, 0, 0, 0);
+    }
+
+    // dS was formed as P o (keep*dP - D/s): the dropout survivor scale s multiplies the result once, here
+    const float qs = scale * (DROP ? drop_scale : 1.0f);
+    if (qvalid) {
+      bf16_t* orow = dqkv + ((long)b * T + q) * ld + h * 32;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        uint2 pk;
+        pk.x = pack_bf16x2(dq[4 * g + 0] * qs, dq[4 * g + 1] * qs);
+        pk.y = pack_bf16x2(dq[4 * g + 2] * qs, dq[4 * g + 3] * qs);
+        *reinterpret_cast<uint2*>(orow + 8 * g + 4 * (lane >> 5)) = pk;
+      }
+    }
+  }
+}
+
+// =====================================================================================================
+// backward dK/dV: lanes own keys; images Q and dO, per-query lse and D in LDS
+// =====================================================================================================
+template <bool DROP>
+__global__ __launch_bounds__(768) void attn_dkv_res_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+                                                            const float* __restrict__ kbias, const float* __restrict__ lse,
+                                                            const float* __restrict__ Dv, bf16_t* __restrict__ dqkv, int B,
+                                                            int T, int H, float scale, uint32_t drop_thr,
+                                                            uint32_t drop_key, float drop_scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int Tp = (T + 31) & ~31, nblk = Tp >> 5;
+  char* imgQ = smem;
+  char* imgdO = smem + Tp * 64;
+  float* ldsLse = reinterpret_cast<float*>(smem + Tp * 128);
+  float* ldsD = ldsLse + Tp;
+  int* queue = reinterpret_cast<int*>(ldsD + Tp);
+
+  const int tid = threadIdx.x, lane = tid & 63, nthr = blockDim.x;
+  if (tid == 0) *queue = 0;
+  const int hb = pair_remap(blockIdx.x, B * H);
+  const int b = hb / H, h = hb % H;
+  const int d = H * 32;
+  const long ld = 3L * d;
+  const bf16_t* qbase = qkv + (long)b * T * ld + h * 32;
+  const bf16_t* dobase = dout + (long)b * T * d + h * 32;
+  const float* kb = kbias + (long)b * T;
+  const float* lse_b = lse + ((long)b * H + h) * T;
+  const float* D_b = Dv + ((long)b * H + h) * T;
+
+  stage_pair(qbase, ld, dobase, (long)d, imgQ, imgdO, T, Tp, tid, nthr);
+  for (int i = tid; i < Tp; i += nthr) {
+    ldsLse[i] = (i < T) ? lse_b[i] * LOG2E : 0.f;
+    ldsD[i] = (i < T) ? D_b[i] : 0.f;
+  }
+  const uint32_t padmask = pad_mask_of(kb, T, nblk, lane);   // bit j: query block j holds a masked (padded) row
+  __syncthreads();
+
+  const float scale2 = scale * LOG2E;
+  const uint32_t T4 = (uint32_t)((T + 3) >> 2);
+#pragma unroll 1
+  for (int kbw = next_item(queue, lane); kbw < nblk; kbw = next_item(queue, lane)) {   // early key blocks are seen by
+    const int kw0 = kbw * 32;                                                          // the most queries: heaviest first
+    const int key = kw0 + (lane & 31);
+    const bool kvalid = key < T;
+    const float my_kb = (kvalid ? kb[key] : 0.f) * LOG2E;
+    bf16x8_v kf[2], vf[2];
+    row_frags(qbase + d + (long)key * ld, kvalid, lane, kf);
+    row_frags(qbase + 2 * d + (long)key * ld, kvalid, lane, vf);
+    const bool keys_plain = (kw0 + 31 < T) && !((padmask >> kbw) & 1);
+
+    f32x16 dk, dv;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk[r] = 0.f; dv[r] = 0.f; }
+    const int ksh = 8 * (lane & 3);
+
+#pragma unroll 1
+    for (int qb = 0; qb < nblk; ++qb) {
+      // wave-uniform skip: no query of the block sees a key of this wave causally and none is a masked row
+      if (qb < kbw && !((padmask >> qb) & 1)) continue;
+      const int q0 = qb * 32;
+      f32x16 st, dpt;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { st[r] = 0.f; dpt[r] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(imgQ, q0, ks, lane), kf[ks], st, 0, 0, 0);
+        dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(imgdO, q0, ks, lane), vf[ks], dpt, 0, 0, 0);
+      }
+      // dropout words: rows of this sub-tile are registers, the 4 lanes of a quad own the 4 keys of one group -> lane
+      // (key & 3) = i hashes rows 4j + i and the quad shares the 16 words by DPP
+      uint32_t mine[4] = {0u, 0u, 0u, 0u};
+      if (DROP) {
+        const uint32_t gq = ((uint32_t)(b * H + h) * (uint32_t)T + (uint32_t)(q0 + 4 * (lane >> 5) + (lane & 3))) * T4 +
+                            (uint32_t)(key >> 2);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mine[j] = drop_word(gq + (uint32_t)(8 * j) * T4, drop_key);    // row c = (lane&3) + 8j
+      }
+      const float* lq = ldsLse + q0 + 4 * (lane >> 5);
+      const float* dq_ = ldsD + q0 + 4 * (lane >> 5);
+      // wave-uniform fast path: every query of the block sees every key of this wave, no key is padded or invalid
+      const bool interior = (qb > kbw) && (q0 + 31 < T) && keys_plain;
+      if (interior) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int c = (r & 3) + 8 * (r >> 2);
+          const float lse_q = lq[c], d_q = dq_[c];
+          const float pv = exp2_fast(fmaf(st[r], scale2, -lse_q));
+          float pd = pv, dpe = dpt[r];
+          if (DROP) {
+            const bool keep = __builtin_amdgcn_ubfe(quad_bcast(mine[r >> 2], r & 3), ksh, 8) >= drop_thr;
+            pd = keep ? pv : 0.f;
+            dpe = keep ? dpe : 0.f;
+          }
+          st[r] = pd;
+          dpt[r] = pv * (dpe - d_q);
+        }
+      } else {
+        const int lim_causal = q0 + 4 * (lane >> 5) - key;    // key <= query  <=>  -c(r) <= lim_causal
+        const int lim_len = T - 1 - q0 - 4 * (lane >> 5);     // query < T     <=>   c(r) <= lim_len
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int c = (r & 3) + 8 * (r >> 2);
+          const bool causal_ok = (-c) <= lim_causal;
+          const float sv = (causal_ok ? st[r] * scale2 : MASK_VAL * LOG2E) + my_kb;
+          const float lse_q = lq[c], d_q = dq_[c];      // unconditional: a load inside ?: compiles to a branch
+          const float pv = exp2_fast((c <= lim_len && kvalid) ? sv - lse_q : -INFINITY);        // select: 2^-inf = 0
+          float pd = pv, dpe = dpt[r];
+          if (DROP) {
+            const bool keep = __builtin_amdgcn_ubfe(quad_bcast(mine[r >> 2], r & 3), ksh, 8) >= drop_thr;   // word of row r
+            pd = keep ? pv : 0.f;
+            dpe = keep ? dpe : 0.f;
+          }
+          st[r] = pd;                                              // dropped P (for dV)
+          dpt[r] = causal_ok ? pv * (dpe - d_q) : 0.f;             // dS        (for dK)
+        }
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        dv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(imgdO, q0, s2, lane), frag_from_acc(st, s2), dv, 0, 0, 0);
+        dk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(imgQ, q0, s2, lane), frag_from_acc(dpt, s2), dk, 0, 0, 0);
+      }
+    }
+
+    // P and dP were masked but not scaled in the loop (D holds D/s): the survivor scale s is applied once, here
+    const float vsc = DROP ? drop_scale : 1.0f, ksc = scale * vsc;
+    if (kvalid) {
+      bf16_t* krow = dqkv + ((long)b * T + key) * ld + d + h * 32;
+      bf16_t* vrow = krow + d;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        uint2 pk;
+        pk.x = pack_bf16x2(dk[4 * g + 0] * ksc, dk[4 * g + 1] * ksc);
+        pk.y = pack_bf16x2(dk[4 * g + 2] * ksc, dk[4 * g + 3] * ksc);
+        *reinterpret_cast<uint2*>(krow + 8 * g + 4 * (lane >> 5)) = pk;
+        pk.x = pack_bf16x2(dv[4 * g + 0] * vsc, dv[4 * g + 1] * vsc);
+        pk.y = pack_bf16x2(dv[4 * g + 2] * vsc, dv[4 * g + 3] * vsc);
+        *reinterpret_cast<uint2*>(vrow + 8 * g + 4 * (lane >> 5)) = pk;
+      }
+    }
+  }
+}
+
+template <typename K>
+int allow_lds(K kernel, size_t bytes) {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) ==
+                 hipSuccess
+             ? NEKO_OK
+             : NEKO_ERR_LAUNCH;
+}
+
+}  // namespace
+
+bool neko_attn_res_applicable(int T, int hd) { return hd == 32 && T >= 1 && T <= 1024; }
+
+int neko_attn_fwd_res_impl(const bf16_t* qkv, const float* kbias, const int* kstart, bf16_t* out, float* lse, int B, int T,
+                           int H, int drop_thr, unsigned drop_key, float drop_scale, hipStream_t s) {
+  const int Tp = (T + 31) & ~31, nblk = Tp / 32, nw = min(16, (nblk + 1) / 2);
+  const size_t lds = (size_t)Tp * 128 + (size_t)Tp * 4 + 16;
+  const float scale = 1.0f / sqrtf(32.0f);
+  static const int once = allow_lds(attn_fwd_res_kernel<true>, 160 * 1024) | allow_lds(attn_fwd_res_kernel<false>, 160 * 1024);
+  if (once != NEKO_OK) return once;
+  if (drop_thr)
+    hipLaunchKernelGGL((attn_fwd_res_kernel<true>), dim3(B * H), dim3(64 * nw), lds, s, qkv, kbias, kstart, out, lse, B, T, H,
+                       scale, (uint32_t)drop_thr, drop_key, drop_scale);
+  else
+    hipLaunchKernelGGL((attn_fwd_res_kernel<false>), dim3(B * H), dim3(64 * nw), lds, s, qkv, kbias, kstart, out, lse, B, T, H,
+                       scale, 0u, drop_key, drop_scale);
+  NEKO_CHECK_LAUNCH();
+  return NEKO_OK;
+}
+
+// D (already divided by the survivor scale) comes from attn_bwd_prep_kernel, as for the streaming kernels
+int neko_attn_bwd_res_impl(const bf16_t* qkv, const bf16_t* dout, const float* kbias, const int* kstart, const float* lse,
+                           const float* D, bf16_t* dqkv, int B, int T, int H, int drop_thr, unsigned drop_key,
+                           float drop_scale, hipStream_t s) {
+  const int Tp = (T + 31) & ~31, nblk = Tp / 32, nw = min(12, (nblk + 1) / 2);
+  const size_t lds_q = (size_t)Tp * 128 + (size_t)Tp * 4 + 16, lds_kv = (size_t)Tp * 128 + (size_t)Tp * 8 + 16;
+  const float scale = 1.0f / sqrtf(32.0f);
+  static const int once = allow_lds(attn_dq_res_kernel<true>, 160 * 1024) | allow_lds(attn_dq_res_kernel<false>, 160 * 1024) |
+                          allow_lds(attn_dkv_res_kernel<true>, 160 * 1024) | allow_lds(attn_dkv_res_kernel<false>, 160 * 1024);
+  if (once != NEKO_OK) return once;
+  if (drop_thr) {
+    hipLaunchKernelGGL((attn_dkv_res_kernel<true>), dim3(B * H), dim3(64 * nw), lds_kv, s, qkv, dout, kbias, lse, D, dqkv, B, T,
+                       H, scale, (uint32_t)drop_thr, drop_key, drop_scale);
+    NEKO_CHECK_LAUNCH();
+    hipLaunchKernelGGL((attn_dq_res_kernel<true>), dim3(B * H), dim3(64 * nw), lds_q, s, qkv, dout, kbias, kstart, lse, D, dqkv,
+                       B, T, H, scale, (uint32_t)drop_thr, drop_key, drop_scale);
+  } else {
+    hipLaunchKernelGGL((attn_dkv_res_kernel<false>), dim3(B * H), dim3(64 * nw), lds_kv, s, qkv, dout, kbias, lse, D, dqkv, B,
+                       T, H, scale, 0u, drop_key, drop_scale);
+    NEKO_CHECK_LAUNCH();
+    hipLaunchKernelGGL((attn_dq_res_kernel<false>), dim3(B * H), dim3(64 * nw), lds_q, s, qkv, dout, kbias, kstart, lse, D, dqkv,
+                       B, T, H, scale, 0u, drop_key, drop_scale);
+  }
+  NEKO_CHECK_LAUNCH();
+  return NEKO_OK;
+}

@@ -48,6 +48,7 @@ int neko_attn_fwd(const uint16_t* qkv, const float* kbias, const int* kstart, ui
                   int H, int hd, int drop_thr, unsigned drop_key, float drop_scale, void* stream) {
   return neko_attn_fwd_impl(qkv, kbias, kstart, out, lse, B, T, H, hd, drop_thr, drop_key, drop_scale, S(stream));
 }
+int neko_attn_set_path(int mode) { return neko_attn_set_path_impl(mode); }
 int neko_attn_bwd(const uint16_t* qkv, const uint16_t* out, const uint16_t* dout, const float* kbias,
                   const int* kstart, const float* lse, float* D, int* qflags, uint16_t* dqkv, int B, int T, int H,
                   int hd, int drop_thr, unsigned drop_key, float drop_scale, void* stream) {

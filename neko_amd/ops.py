@@ -159,6 +159,12 @@ def mask_bias(mask: torch.Tensor):
     return kb, ks
 
 
+def attn_set_path(mode: int) -> int:
+    """0 = automatic (head-resident kernels when hd = 32 and T <= 1024), 1 = always the streaming kernels; returns the
+    previous mode (neko_attn_set_path)."""
+    return int(_lib.load().neko_attn_set_path(int(mode)))
+
+
 def attn_fwd(qkv, kbias, kstart, B, T, H, hd, drop=None):
     _chk(qkv, BF16, "qkv")
     out = torch.empty(B * T, H * hd, dtype=BF16, device=qkv.device)

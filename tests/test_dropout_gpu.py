@@ -94,9 +94,18 @@ def test_gemm_epilogue_and_ln_bwd_masks():
     assert torch.equal(dx16.cpu(), ref16)
 
 
-@pytest.mark.parametrize("B,T,H,hd", [(2, 96, 2, 32), (1, 200, 2, 64)])
-def test_attention_dropout_fwd_bwd(B, T, H, hd):
+@pytest.mark.parametrize("path", ["auto", "streaming"])
+@pytest.mark.parametrize("B,T,H,hd", [(2, 96, 2, 32), (1, 200, 2, 64), (2, 301, 3, 32)])
+def test_attention_dropout_fwd_bwd(B, T, H, hd, path):
     from neko_amd import ops
+    prev = ops.attn_set_path(1 if path == "streaming" else 0)
+    try:
+        _attention_dropout_case(ops, B, T, H, hd)
+    finally:
+        ops.attn_set_path(prev)
+
+
+def _attention_dropout_case(ops, B, T, H, hd):
     g = torch.Generator().manual_seed(T)
     d = H * hd
     qkv = rb(torch.randn(B, T, 3 * d, generator=g))

@@ -184,10 +184,23 @@ def _masks(B, T, kind):
     return m
 
 
+@pytest.fixture(params=["auto", "streaming"])
+def attn_path(request, ops):
+    """Both attention schedules (head-resident for hd = 32 / T <= 1024, streaming for everything) against the oracle."""
+    prev = ops.attn_set_path(1 if request.param == "streaming" else 0)
+    yield request.param
+    ops.attn_set_path(prev)
+
+
 @pytest.mark.parametrize("mask_kind", ["none", "left", "right", "holes"])
 @pytest.mark.parametrize("B,T,H,hd", [(2, 40, 2, 32), (3, 200, 4, 32), (2, 333, 2, 64), (1, 130, 2, 128),
-                                      (2, 256, 3, 32)])
-def test_attention_fwd_bwd(ops, B, T, H, hd, mask_kind):
+                                      (2, 256, 3, 32), (1, 1, 2, 32), (2, 31, 1, 32), (1, 1024, 2, 32),
+                                      (2, 1000, 3, 32), (17, 97, 3, 32)])
+def test_attention_fwd_bwd(ops, attn_path, B, T, H, hd, mask_kind):
+    if attn_path == "streaming" and hd == 32 and T >= 1000 and mask_kind in ("right", "holes"):
+        pytest.skip("large streaming cases are covered by the 'none' and 'left' masks")
+    if T < 16 and mask_kind != "none":
+        pytest.skip("mask pattern needs T >= 16")
     g = torch.Generator().manual_seed(B * 1000 + T + hd)
     d = H * hd
     qkv = rb(torch.randn(B, T, 3 * d, generator=g))

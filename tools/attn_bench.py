@@ -22,7 +22,9 @@ def main():
     ap.add_argument("--pad", type=int, default=0, help="left padding of every sequence")
     ap.add_argument("--only", default="")
     ap.add_argument("--drop", type=float, default=0.0, help="attention dropout probability")
+    ap.add_argument("--path", type=int, default=0, help="0 auto (head-resident when applicable), 1 streaming")
     a = ap.parse_args()
+    ops.attn_set_path(a.path)
     B, T, H, hd = a.B, a.T, a.H, a.hd
     d = H * hd
     dev = "cuda"
