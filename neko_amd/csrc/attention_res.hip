@@ -87,6 +87,24 @@ __device__ __forceinline__ int next_item(int* counter, int lane) {
   return __builtin_amdgcn_readfirstlane(v);
 }
 
+// item -> 32-row block for the kernels whose lanes own queries: blocks in `heavy` (they hold a masked query row and
+// visit every key) first, then the remaining blocks latest (longest causal range) first.  Wave-uniform scalar work.
+__device__ __forceinline__ int block_of_item(int item, uint32_t heavy, int nblk) {
+  const int nh = __popc(heavy);
+  if (item < nh) {
+    uint32_t m = heavy;
+    for (int i = 0; i < item; ++i) m &= m - 1;
+    return __ffs(m) - 1;
+  }
+  uint32_t m = ~heavy & (nblk >= 32 ? 0xffffffffu : ((1u << nblk) - 1u));
+  for (int i = 0; i < item - nh; ++i) m &= ~(1u << (31 - __clz(m)));
+  return 31 - __clz(m);
+}
+__device__ __forceinline__ bool frag_nonzero(const bf16x8_v& f) {
+  const uint4 u = __builtin_bit_cast(uint4, f);
+  return (u.x | u.y | u.z | u.w) != 0u;
+}
+
 // stage two [T][32] bf16 matrices (row strides lda / ldb elements) into swizzled images, rows >= T zero
 __device__ __forceinline__ void stage_pair(const bf16_t* __restrict__ a, long lda, const bf16_t* __restrict__ b, long ldb,
                                            char* imgA, char* imgB, int T, int Tp, int tid, int nthr) {
@@ -159,7 +177,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_res_kernel(const bf16_t* __rest
   const float scale2 = scale * LOG2E;
 #pragma unroll 1
   for (int item = next_item(queue, lane); item < nblk; item = next_item(queue, lane)) {
-    const int qb = nblk - 1 - item;                    // late query blocks see the most keys: heaviest first
+    const int qb = block_of_item(item, padmask, nblk);   // heaviest first
     const int q = qb * 32 + (lane & 31);
     const bool qvalid = q < T;
     bf16x8_v qf[2];
@@ -285,7 +303,7 @@ __global__ __launch_bounds__(768) void attn_dq_res_kernel(const bf16_t* __restri
   const float scale2 = scale * LOG2E;
 #pragma unroll 1
   for (int item = next_item(queue, lane); item < nblk; item = next_item(queue, lane)) {
-    const int qb = nblk - 1 - item;                    // late query blocks see the most keys: heaviest first
+    const int qb = block_of_item(item, padmask, nblk);   // heaviest first
     const int q = qb * 32 + (lane & 31);
     const bool qvalid = q < T;
     bf16x8_v qf[2], dof[2];
@@ -293,7 +311,10 @@ __global__ __launch_bounds__(768) void attn_dq_res_kernel(const bf16_t* __restri
     row_frags(dout + ((long)b * T + q) * d + h * 32, qvalid, lane, dof);
     const float my_lse = (qvalid ? lse[((long)b * H + h) * T + q] : 0.f) * LOG2E;
     const float my_D = qvalid ? Dv[((long)b * H + h) * T + q] : 0.f;
-    const bool wave_full = (padmask >> qb) & 1;
+    // a masked query row whose dO is exactly zero (the training case: no loss reaches a padded position) has dP = D = 0,
+    // hence dS = 0 for every key: the keys beyond the diagonal are then needed by no row of the block
+    const bool live_masked = __builtin_amdgcn_ballot_w64(qvalid && ldsKb[q] != 0.f && (frag_nonzero(dof[0]) || frag_nonzero(dof[1]))) != 0;
+    const bool wave_full = ((padmask >> qb) & 1) && live_masked;
     const int kb_beg = wave_full ? 0 : min(kb_first, qb);
     const int kb_end = wave_full ? nblk : qb + 1;
 
@@ -406,6 +427,17 @@ __global__ __launch_bounds__(768) void attn_dkv_res_kernel(const bf16_t* __restr
   }
   const uint32_t padmask = pad_mask_of(kb, T, nblk, lane);   // bit j: query block j holds a masked (padded) row
   __syncthreads();
+  // bit j of qactive: query block j holds a masked row whose dO is not exactly zero.  Only such rows reach keys beyond
+  // their diagonal (dO == 0 gives dP = D = 0, so P^T.dO and dS vanish): in training no loss reaches a padded position
+  // and the early blocks are visited by the causal range only.
+  uint32_t qactive = 0;
+  for (uint32_t m = padmask; m; m &= m - 1) {
+    const int j = __ffs(m) - 1, row = j * 32 + (lane & 31);
+    const uint4 u0 = *reinterpret_cast<const uint4*>(imgdO + img_off(row, (lane >> 5) * 2));
+    const uint4 u1 = *reinterpret_cast<const uint4*>(imgdO + img_off(row, (lane >> 5) * 2 + 1));
+    const bool nz = ((u0.x | u0.y | u0.z | u0.w | u1.x | u1.y | u1.z | u1.w) != 0u) && row < T && kb[row] != 0.f;
+    if (__builtin_amdgcn_ballot_w64(nz) != 0) qactive |= 1u << j;
+  }
 
   const float scale2 = scale * LOG2E;
   const uint32_t T4 = (uint32_t)((T + 3) >> 2);
@@ -428,7 +460,7 @@ __global__ __launch_bounds__(768) void attn_dkv_res_kernel(const bf16_t* __restr
 #pragma unroll 1
     for (int qb = 0; qb < nblk; ++qb) {
       // wave-uniform skip: no query of the block sees a key of this wave causally and none is a masked row
-      if (qb < kbw && !((padmask >> qb) & 1)) continue;
+      if (qb < kbw && !((qactive >> qb) & 1)) continue;
       const int q0 = qb * 32;
       f32x16 st, dpt;
 #pragma unroll

@@ -226,6 +226,29 @@ def test_attention_fwd_bwd(ops, attn_path, B, T, H, hd, mask_kind):
     close(dqkv.view(B, T, 3 * d), leaf.grad, 2 ** -6, 1e-2 * gs, "attn dqkv")
 
 
+@pytest.mark.parametrize("B,T,H", [(3, 200, 2), (2, 1024, 2), (5, 97, 3)])
+def test_attention_bwd_zero_grad_on_masked_rows(ops, B, T, H):
+    """Training case: dO is exactly zero on padded query rows.  The head-resident backward then skips the keys beyond the
+    diagonal for those rows (their dS vanishes); the result must still match the oracle on every row."""
+    hd, d = 32, H * 32
+    g = torch.Generator().manual_seed(T + H)
+    qkv = rb(torch.randn(B, T, 3 * d, generator=g))
+    mask = _masks(B, T, "left")
+    mask[B - 1, T // 2] = 0                                    # one hole too
+    do = rb(torch.randn(B, T, d, generator=g)) * mask[:, :, None]
+    leaf = qkv.clone().requires_grad_(True)
+    q, k, v = leaf.split(d, dim=2)
+    sh = lambda t: t.view(B, T, H, hd).permute(0, 2, 1, 3)
+    o_ref = O.attention_core(sh(q), sh(k), sh(v), mask).permute(0, 2, 1, 3).reshape(B, T, d)
+    o_ref.backward(do)
+    kb, ks = ops.mask_bias(mask.to(DEV))
+    qkv_d = bf(qkv.view(B * T, 3 * d))
+    out, lse = ops.attn_fwd(qkv_d, kb, ks, B, T, H, hd)
+    dqkv = ops.attn_bwd(qkv_d, out, bf(do.view(B * T, d)), kb, ks, lse, B, T, H, hd)
+    gs = float(leaf.grad.abs().max())
+    close(dqkv.view(B, T, 3 * d), leaf.grad, 2 ** -6, 1e-2 * gs, "attn dqkv (zero dO on masked rows)")
+
+
 # ----------------------------------------------------------------------------------------------------
 # cross entropy
 # ----------------------------------------------------------------------------------------------------
