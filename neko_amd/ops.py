@@ -70,7 +70,7 @@ def pick_splitk(M: int, N: int, K: int, target_blocks: int = 256) -> tuple:
     if K < 4096:
         return 1, 0
     tiles = ((M + 255) // 256) * ((N + 255) // 256)
-    if tiles >= 2 * target_blocks:
+    if tiles >= 4 * target_blocks:            # >= 4 rounds: the partial last round costs less than the reduce pass
         return 1, 0
     best_t, best = None, (1, 0)
     for sk in range(1, 33):

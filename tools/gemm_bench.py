@@ -31,7 +31,7 @@ SHAPES = [
     ("lm logits NT", 4096, V, D, False, False, "f32,ldc=%d" % VP),
     ("lm logit16 NT", 4096, VP, D, False, False, "bf16,ldc=%d" % VP),
     ("lm dH     NN", M, D, VP, False, True, "f32"),
-    ("lm dW     TN", VP, D, M, True, True, "acc"),
+    ("lm dW     TN", VP, D, M, True, True, "splitk"),
     ("rl k768   NN", M, 1024, 768, False, True, "bf16"),
     ("rl k768   NT", M, 1024, 768, False, False, "bf16"),
     ("rl k4096  NN", M, 1024, 4096, False, True, "bf16"),
