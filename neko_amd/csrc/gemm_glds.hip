@@ -26,6 +26,21 @@
 #define NEKO_GEMM_DIAG 0   // ablations for tools/gemm_bench.py: 1 no in-loop DMA, 4 no epilogue
 #endif
 
+#if NEKO_GEMM_DIAG == 9
+// phase trace (diagnostic builds only): per block 4 x s_memrealtime (100 MHz) = start, first tile landed, k-loop done,
+// epilogue done; buffer set with neko_gemm_diag_trace()
+__device__ unsigned long long* g_neko_gemm_trace = nullptr;
+extern "C" int neko_gemm_diag_trace(void* buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_neko_gemm_trace), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
+}
+#define NEKO_TRACE(slot)                                                                                       \
+  do {                                                                                                         \
+    if (g_neko_gemm_trace && threadIdx.x == 0) g_neko_gemm_trace[(long)blockIdx.x * 4 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#else
+#define NEKO_TRACE(slot) do { } while (0)
+#endif
+
 namespace {
 
 constexpr int BK = 32;
@@ -499,6 +514,7 @@ __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void gemm_glds_kernel(Gem
     else stage_ks<BN, C::NW>(p.B, p.ldb, n0, p.N, k0, lb, wave, lane);
   };
 
+  NEKO_TRACE(0);
   // prologue: NSTAGE-1 tiles in flight
 #pragma unroll
   for (int t = 0; t < NSTAGE - 1; ++t)
@@ -560,6 +576,9 @@ __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void gemm_glds_kernel(Gem
   const int nmain = max(0, nkt - (NSTAGE - 1));
   for (int kt = 0; kt < nmain; ++kt) {
     wait_dma_and_barrier<(NSTAGE - 2) * GLDS_PER_STAGE>();
+#if NEKO_GEMM_DIAG == 9
+    if (kt == 0) NEKO_TRACE(1);
+#endif
     body(kt, std::true_type{});
   }
   // drain: no tile left to request
@@ -571,6 +590,14 @@ __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void gemm_glds_kernel(Gem
     body(kt, std::false_type{});
   }
   __syncthreads();   // all waves done with the ring before the slabs overwrite it
+  NEKO_TRACE(2);
+#if NEKO_GEMM_DIAG == 9
+  if (!try_epilogue_fast<C>(p, acc, smem, m0, n0, wm, wn, wave, lane)) epilogue<C>(p, acc, smem, m0, n0, wm, wn, wave, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  NEKO_TRACE(3);
+  return;
+#endif
   if (try_epilogue_fast<C>(p, acc, smem, m0, n0, wm, wn, wave, lane)) return;
   epilogue<C>(p, acc, smem, m0, n0, wm, wn, wave, lane);
 }
