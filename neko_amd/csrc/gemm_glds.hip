@@ -157,11 +157,17 @@ __device__ __forceinline__ void wait_dma_and_barrier() {
 // XCD then share <= 8 A panels and a few B panels: with B small (activations x weight) A streams once as before;
 // with A small and B huge (LM-head logits: 4096 rows x 52k vocabulary columns) the embedding table streams once
 // per 8 row panels instead of once per row panel.
+// Split-K launches are ONE flat grid of tiles x slices with the slice as the slow index of the logical id: the
+// contiguous logical range an XCD gets from xcd_remap then lies inside one or two k-slices, whose tiles share their A and
+// B panels pairwise.  (As a 2-D grid the tiles of a slice were dealt round-robin over all eight XCDs and every L2 fetched
+// nearly every panel of every slice: the fc / proj weight gradients moved 730 MB over the fabric for 250 MB of operands.)
 template <int BM, int BN>
-__device__ __forceinline__ void tile_coords(const GemmArgs& p, int& tm, int& tn) {
+__device__ __forceinline__ void tile_coords(const GemmArgs& p, int& tm, int& tn, int& slice) {
   constexpr int GROUP_M = 8;
   const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
-  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  int bid = xcd_remap(blockIdx.x, gridDim.x);
+  slice = bid / (nbm * nbn);
+  bid -= slice * (nbm * nbn);
   const int per_group = GROUP_M * nbn;
   const int g = bid / per_group, local = bid - g * per_group;
   const int gsz = min(GROUP_M, nbm - g * GROUP_M);
@@ -301,7 +307,7 @@ __device__ __forceinline__ void epilogue_fast(const GemmArgs& p, f32x16 (&acc)[C
 // dispatch: feature mask of this launch -> a compiled fast epilogue, or false (caller runs the generic one)
 template <class C>
 __device__ __forceinline__ bool try_epilogue_fast(const GemmArgs& p, f32x16 (&acc)[C::TM][C::TN], char* smem, int m0,
-                                                  int n0, int wm, int wn, int wave, int lane) {
+                                                  int n0, int wm, int wn, int wave, int lane, int slice) {
 #if NEKO_GEMM_DIAG == 4
   if (p.M != 12345) return true;      // ablation: no epilogue at all
 #endif
@@ -319,9 +325,9 @@ __device__ __forceinline__ bool try_epilogue_fast(const GemmArgs& p, f32x16 (&ac
   const bool to_ws = p.splitk > 1 && p.splitk_ws;
   if (p.splitk > 1 && !to_ws) return false;                                   // atomic split-K: generic path
   if (m0 + C::BM > p.M || n0 + C::BN > p.N) return false;                     // edge tile
-  float* Cf_out = to_ws ? p.splitk_ws + (long)blockIdx.y * p.M * p.N : p.Cf;
+  float* Cf_out = to_ws ? p.splitk_ws + (long)slice * p.M * p.N : p.Cf;
   const long ldcf_out = to_ws ? p.N : p.ldcf;
-  const bool lead = !to_ws || blockIdx.y == 0;                                // bias/resid only once over split-K slices
+  const bool lead = !to_ws || slice == 0;                                // bias/resid only once over split-K slices
   if (to_ws && (p.bias || p.resid || p.act || p.Cb || p.drop_thr)) return false;
   if (((ldcf_out | p.ldr | p.ldcb | p.ldact | p.ldpre) & 3) || (p.N & 3)) return false;
   unsigned f = 0;
@@ -356,7 +362,7 @@ __device__ __forceinline__ bool try_epilogue_fast(const GemmArgs& p, f32x16 (&ac
 // ---- epilogue (shared by both kernels): the caller has passed a block barrier after the last ring read -------
 template <class C>
 __device__ __forceinline__ void epilogue(const GemmArgs& p, f32x16 (&acc)[C::TM][C::TN], char* smem, int m0, int n0,
-                                         int wm, int wn, int wave, int lane) {
+                                         int wm, int wn, int wave, int lane, int slice) {
   constexpr int TM = C::TM, TN = C::TN;
 #if NEKO_GEMM_DIAG == 4
   if (p.M != 12345) return;      // ablation: no epilogue at all
@@ -370,10 +376,10 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, f32x16 (&acc)[C::TM]
   const float alpha = p.alpha_dev ? p.alpha * (*p.alpha_dev) : p.alpha;
   const bool to_ws = p.splitk > 1 && p.splitk_ws;   // split-K slices go to a workspace, reduced in fixed order afterwards
   const bool atomic = p.splitk > 1 && !to_ws;
-  float* const Cf_out = to_ws ? p.splitk_ws + (long)blockIdx.y * p.M * p.N : p.Cf;
+  float* const Cf_out = to_ws ? p.splitk_ws + (long)slice * p.M * p.N : p.Cf;
   const long ldcf_out = to_ws ? p.N : p.ldcf;
   const int acc_out = to_ws ? 0 : p.accumulate;
-  const bool lead = !atomic || blockIdx.y == 0;
+  const bool lead = !atomic || slice == 0;
   const int cchunk = lane % CPR;
   const int col = n0 + wn * SW + cchunk * 4;
   const bool col_ok = col < p.N;
@@ -485,13 +491,13 @@ __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void gemm_glds_kernel(Gem
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / C::WN, wn = wave % C::WN;
-  int tm, tn;
-  tile_coords<BM, BN>(p, tm, tn);
+  int tm, tn, slice;
+  tile_coords<BM, BN>(p, tm, tn, slice);
   const int m0 = tm * BM, n0 = tn * BN;
 
   int kbeg = 0, kend = p.K;
   if (p.splitk > 1) {
-    kbeg = blockIdx.y * p.k_per_split;
+    kbeg = slice * p.k_per_split;
     kend = min(p.K, kbeg + p.k_per_split);
   }
   const int nkt = (kend - kbeg) / BK;
@@ -592,14 +598,14 @@ __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void gemm_glds_kernel(Gem
   __syncthreads();   // all waves done with the ring before the slabs overwrite it
   NEKO_TRACE(2);
 #if NEKO_GEMM_DIAG == 9
-  if (!try_epilogue_fast<C>(p, acc, smem, m0, n0, wm, wn, wave, lane)) epilogue<C>(p, acc, smem, m0, n0, wm, wn, wave, lane);
+  if (!try_epilogue_fast<C>(p, acc, smem, m0, n0, wm, wn, wave, lane, slice)) epilogue<C>(p, acc, smem, m0, n0, wm, wn, wave, lane, slice);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   NEKO_TRACE(3);
   return;
 #endif
-  if (try_epilogue_fast<C>(p, acc, smem, m0, n0, wm, wn, wave, lane)) return;
-  epilogue<C>(p, acc, smem, m0, n0, wm, wn, wave, lane);
+  if (try_epilogue_fast<C>(p, acc, smem, m0, n0, wm, wn, wave, lane, slice)) return;
+  epilogue<C>(p, acc, smem, m0, n0, wm, wn, wave, lane, slice);
 }
 
 // 128x128: 4 waves x (64x64), 3 blocks/CU (3-stage) or 2 (4-stage)      -- short K / ragged or small outputs
@@ -613,7 +619,7 @@ using C256x256 = Cfg<2, 4, 4, 2, 4>;
 template <bool A_KC, bool B_KC, class C>
 int launch_cfg(const GemmArgs& a, hipStream_t s) {
   const int nbm = (a.M + C::BM - 1) / C::BM, nbn = (a.N + C::BN - 1) / C::BN;
-  dim3 grid(nbm * nbn, a.splitk > 1 ? a.splitk : 1);
+  dim3 grid(nbm * nbn * (a.splitk > 1 ? a.splitk : 1));
   hipLaunchKernelGGL((gemm_glds_kernel<A_KC, B_KC, C>), grid, dim3(C::NT), 0, s, a);
   NEKO_CHECK_LAUNCH();
   return NEKO_OK;
