@@ -721,6 +721,7 @@ int launch(const GemmArgs& a, hipStream_t s) {
     const bool big_out = (long)a.M * a.N >= (long)256 * 256 * 64;      // enough 256x256 tiles to matter
     if (a.splitk > 1 || (klen >= 4096 && (long)a.M * a.N >= (long)256 * 256 * 8)) cfg = 3;
     else if (A_KC && !B_KC && a.N >= 2048 && big_out) cfg = 3;
+    else if (A_KC && !B_KC && klen >= 2048 && big_out && a.N % 256 == 0) cfg = 3;    // forward MLP projection (K = 3072, N = 768): +12 % over 128x128
     else if (A_KC && B_KC && klen >= 2048 && big_out && a.N % 128 == 0) cfg = 2;
     else if (A_KC && B_KC && a.N >= 2048 && big_out) cfg = 3;       // K = 768 dgrad through the MLP, LM-head logits
     else if (A_KC && B_KC && big_out && a.N % 128 == 0) cfg = 2;    // K = 768, N = 768 dgrad (attention out)
