@@ -56,6 +56,9 @@ class GradReducer:
                 self._reduce(g)
 
     def _reduce(self, gname: str) -> None:
+        if self.flat.grad.is_cuda:
+            from .engine import SideStream
+            SideStream.join(self.flat.grad.device)      # weight gradients are produced on the side stream
         a, b = self.flat.group_ranges[gname]
         for s in range(a, b, self.bucket_elems):
             e = min(b, s + self.bucket_elems)

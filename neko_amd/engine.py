@@ -11,6 +11,7 @@ statistics, softmax, logits, loss and all gradients of parameters are fp32; MFMA
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass, field
 from typing import Callable, List, Optional
 
@@ -79,6 +80,49 @@ class StackCtx:
     xf: torch.Tensor = None          # residual stream entering ln_f
     meanf: torch.Tensor = None
     rstdf: torch.Tensor = None
+
+
+class SideStream:
+    """Weight / bias gradients on a second HIP stream.  They hang off the backward chain (nothing downstream reads them
+    until the all-reduce / optimiser), while the chain itself is a sequence of launches whose last round rarely fills
+    the chip: the dgrads with N = 768 are 768 tiles on 512 slots (1.5 rounds), forward-shaped qkv 4.5 rounds, the
+    weight gradients themselves 252 blocks.  On their own queue the gradient kernels fill those tails.
+    fork(fn, *temps): fn's launches run on the side stream after everything enqueued so far on the current stream;
+    `temps` are tensors that may be freed before join() (their blocks must not be recycled under the side kernels).
+    join(): the current stream waits for the side stream.  NEKO_WGRAD_STREAM=0 keeps everything on one stream."""
+    enabled = os.environ.get("NEKO_WGRAD_STREAM", "1") != "0"
+    _streams: dict = {}
+    _dirty: dict = {}
+
+    @classmethod
+    def _get(cls, dev) -> "torch.cuda.Stream":
+        key = torch.device(dev).index if torch.device(dev).index is not None else torch.cuda.current_device()
+        if key not in cls._streams:
+            cls._streams[key] = torch.cuda.Stream(device=key)
+        return cls._streams[key]
+
+    @classmethod
+    def fork(cls, fn: Callable[[], None], *temps: torch.Tensor) -> None:
+        dev = temps[0].device if temps else torch.device("cuda", torch.cuda.current_device())
+        if not cls.enabled or dev.type != "cuda":
+            fn()
+            return
+        side = cls._get(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            fn()
+        for t in temps:
+            t.record_stream(side)
+        cls._dirty[side.device.index] = True
+
+    @classmethod
+    def join(cls, dev=None) -> None:
+        if not cls.enabled or not torch.cuda.is_available():
+            return
+        key = torch.device(dev).index if (dev is not None and torch.device(dev).index is not None) else torch.cuda.current_device()
+        if cls._dirty.get(key):
+            torch.cuda.current_stream(key).wait_stream(cls._streams[key])
+            cls._dirty[key] = False
 
 
 def _wgrad(A: torch.Tensor, Bm: torch.Tensor, Mout: int, N: int, K: int, out: torch.Tensor,
@@ -166,12 +210,12 @@ def stack_backward(P: StackParams, ctx: StackCtx, dhf: torch.Tensor,
         # ---- MLP: x2 = x1 + gelu(a2 Wfc + bfc) Wpr + bpr ------------------------------------------
         d_pre = torch.empty(M, 4 * d, dtype=BF16, device=dev)
         ops.gemm(g16, lp.w_pr, M, 4 * d, d, ldb=d, act=2, act_in=c.pre, out_bf16=d_pre)       # dgrad * gelu'
-        _wgrad(c.h, g16, 4 * d, d, M, lp.g_w_pr)
-        ops.colsum_bf16(g16, M, d, lp.g_b_pr)
+        SideStream.fork(lambda c=c, lp=lp, g16=g16: (_wgrad(c.h, g16, 4 * d, d, M, lp.g_w_pr),
+                                                    ops.colsum_bf16(g16, M, d, lp.g_b_pr)), g16)
         d_a2 = torch.empty(M, d, dtype=F32, device=dev)
         ops.gemm(d_pre, lp.w_fc, M, d, 4 * d, ldb=4 * d, out_f32=d_a2)
-        _wgrad(c.a2, d_pre, d, 4 * d, M, lp.g_w_fc)
-        ops.colsum_bf16(d_pre, M, 4 * d, lp.g_b_fc)
+        SideStream.fork(lambda c=c, lp=lp, d_pre=d_pre: (_wgrad(c.a2, d_pre, d, 4 * d, M, lp.g_w_fc),
+                                                        ops.colsum_bf16(d_pre, M, 4 * d, lp.g_b_fc)), d_pre)
         g1 = torch.empty(M, d, dtype=F32, device=dev)
         g1_16 = torch.empty(M, d, dtype=BF16, device=dev)
         ops.layernorm_bwd(d_a2, c.x1, lp.ln2_w, c.mean2, c.rstd2, lp.g_ln2_w, lp.g_ln2_b, g_in=g, dx=g1, dx16=g1_16,
@@ -179,13 +223,13 @@ def stack_backward(P: StackParams, ctx: StackCtx, dhf: torch.Tensor,
         # ---- attention: x1 = x + attn(a1 Wqkv + bqkv) Wo + bo -----------------------------------------
         d_o = torch.empty(M, d, dtype=BF16, device=dev)
         ops.gemm(g1_16, lp.w_o, M, d, d, ldb=d, out_bf16=d_o)
-        _wgrad(c.o, g1_16, d, d, M, lp.g_w_o)
-        ops.colsum_bf16(g1_16, M, d, lp.g_b_o)
+        SideStream.fork(lambda c=c, lp=lp, g1_16=g1_16: (_wgrad(c.o, g1_16, d, d, M, lp.g_w_o),
+                                                          ops.colsum_bf16(g1_16, M, d, lp.g_b_o)), g1_16)
         dqkv = ops.attn_bwd(c.qkv, c.o, d_o, ctx.kbias, ctx.kstart, c.lse, B, T, H, hd, drop=dr.attn[i] if dr else None)
         d_a1 = torch.empty(M, d, dtype=F32, device=dev)
         ops.gemm(dqkv, lp.w_qkv, M, d, 3 * d, ldb=3 * d, out_f32=d_a1)
-        _wgrad(c.a1, dqkv, d, 3 * d, M, lp.g_w_qkv)
-        ops.colsum_bf16(dqkv, M, 3 * d, lp.g_b_qkv)
+        SideStream.fork(lambda c=c, lp=lp, dqkv=dqkv: (_wgrad(c.a1, dqkv, d, 3 * d, M, lp.g_w_qkv),
+                                                      ops.colsum_bf16(dqkv, M, 3 * d, lp.g_b_qkv)), dqkv)
         g0 = torch.empty(M, d, dtype=F32, device=dev)
         g0_16 = torch.empty(M, d, dtype=BF16, device=dev) if i > 0 else None
         ops.layernorm_bwd(d_a1, c.x, lp.ln1_w, c.mean1, c.rstd1, lp.g_ln1_w, lp.g_ln1_b, g_in=g1, dx=g0, dx16=g0_16,
@@ -193,6 +237,7 @@ def stack_backward(P: StackParams, ctx: StackCtx, dhf: torch.Tensor,
         g, g16 = g0, g0_16
         if on_layer_done:
             on_layer_done(i)
+    SideStream.join(dev)          # every parameter gradient of the stack is ordered before what follows on this stream
     if dr is not None and dr.embd is not None:
         g = ops.dropout_f32(g, dr.embd)                       # backward of the embedding dropout: same mask
     return g
@@ -425,5 +470,7 @@ def lm_head_backward(Hp: HeadParams, hf16: torch.Tensor, dlogits: torch.Tensor, 
     dhf = torch.empty(M, d, dtype=F32, device=hf16.device)
     sk, kps = ops.pick_splitk(M, d, Hp.Vpad)          # few output tiles, K = vocabulary: fill the CUs
     ops.gemm(dlogits, Hp.w, M, d, Hp.Vpad, b_kstrided=True, ldb=d, out_f32=dhf, alpha_dev=go, splitk=sk, k_per_split=kps)
-    _wgrad(dlogits, hf16, Hp.Vpad, d, M, Hp.g_w, alpha_dev=go)
+    # dW on the side stream: it overlaps the start of the stack's backward (joined at the end of stack_backward, or by
+    # the data-parallel reducer before it reads the range)
+    SideStream.fork(lambda: _wgrad(dlogits, hf16, Hp.Vpad, d, M, Hp.g_w, alpha_dev=go), dlogits, hf16, go)
     return dhf

@@ -217,6 +217,7 @@ class _PolicyCoreFn(torch.autograd.Function):
                 dp.group_ready("lnf" if i == len(policy.transformer.h) else f"layer{i}")
 
         gx = engine.stack_backward(policy.transformer._stack_params(), ctx.sctx, dhf, on_layer_done=layer_done)
+        engine.SideStream.join(gx.device)       # (stack_backward joins too: explicit for the LM-head dW launched before it)
         f.attach_grads(names)
         ctx.sctx = ctx.hf16 = ctx.dlogits = None
         return (None, gx.view(B, T, d)) + (None,) * (len(ctx.needs_input_grad) - 2)
