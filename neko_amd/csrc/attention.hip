@@ -683,12 +683,12 @@ int bwd_launch(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const f
                const float* lse, float* D, int* qflags, bf16_t* dqkv, int B, int T, int H, int thr, unsigned key,
                float dscale, hipStream_t s) {
   const float scale = 1.0f / sqrtf((float)HD);
+  if (neko_attn_path_mode() == 0 && neko_attn_res_applicable(T, HD))
+    return neko_attn_bwd_res_impl(qkv, out, dout, kbias, kstart, lse, dqkv, B, T, H, thr, key, dscale, s);
   const long total = (long)B * T * H;
   hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, out, dout, kbias, D,
                      qflags, B, T, H, HD, thr ? 1.0f / dscale : 1.0f);
   NEKO_CHECK_LAUNCH();
-  if (neko_attn_path_mode() == 0 && neko_attn_res_applicable(T, HD))
-    return neko_attn_bwd_res_impl(qkv, dout, kbias, kstart, lse, D, dqkv, B, T, H, thr, key, dscale, s);
   dim3 grid((T + 127) / 128, H, B);
   if (thr) {
     hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, true>), grid, dim3(NT), 0, s, qkv, dout, kbias, kstart, lse, D, dqkv, B, T,

@@ -105,6 +105,18 @@ __device__ __forceinline__ bool frag_nonzero(const bf16x8_v& f) {
   return (u.x | u.y | u.z | u.w) != 0u;
 }
 
+// sum over the 8 bf16 pairs of two 16-byte pieces
+__device__ __forceinline__ float dot8_bf16(const uint4& a, const uint4& b) {
+  const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
+  float acc = 0.f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    acc = fmaf(__uint_as_float(aw[e] << 16), __uint_as_float(bw[e] << 16), acc);
+    acc = fmaf(__uint_as_float(aw[e] & 0xffff0000u), __uint_as_float(bw[e] & 0xffff0000u), acc);
+  }
+  return acc;
+}
+
 // stage two [T][32] bf16 matrices (row strides lda / ldb elements) into swizzled images, rows >= T zero
 __device__ __forceinline__ void stage_pair(const bf16_t* __restrict__ a, long lda, const bf16_t* __restrict__ b, long ldb,
                                            char* imgA, char* imgB, int T, int Tp, int tid, int nthr) {
@@ -275,7 +287,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_res_kernel(const bf16_t* __rest
 template <bool DROP>
 __global__ __launch_bounds__(768) void attn_dq_res_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                            const float* __restrict__ kbias, const int* __restrict__ kstart,
-                                                           const float* __restrict__ lse, const float* __restrict__ Dv,
+                                                           const float* __restrict__ lse, const bf16_t* __restrict__ outp,
                                                            bf16_t* __restrict__ dqkv, int B, int T, int H, float scale,
                                                            uint32_t drop_thr, uint32_t drop_key, float drop_scale) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -310,7 +322,14 @@ __global__ __launch_bounds__(768) void attn_dq_res_kernel(const bf16_t* __restri
     row_frags(qbase + (long)q * ld, qvalid, lane, qf);
     row_frags(dout + ((long)b * T + q) * d + h * 32, qvalid, lane, dof);
     const float my_lse = (qvalid ? lse[((long)b * H + h) * T + q] : 0.f) * LOG2E;
-    const float my_D = qvalid ? Dv[((long)b * H + h) * T + q] : 0.f;
+    // D = sum_hd dO.O of the own row (divided by the dropout survivor scale, which is folded out of dS): the lane pair
+    // (l, l^32) holds the two halves of the row -- the separate D pass of the streaming kernels is not needed here
+    bf16x8_v of[2];
+    row_frags(outp + ((long)b * T + q) * d + h * 32, qvalid, lane, of);
+    float my_D = dot8_bf16(__builtin_bit_cast(uint4, dof[0]), __builtin_bit_cast(uint4, of[0])) +
+                 dot8_bf16(__builtin_bit_cast(uint4, dof[1]), __builtin_bit_cast(uint4, of[1]));
+    my_D += __shfl_xor(my_D, 32, 64);
+    if (DROP) my_D *= 1.0f / drop_scale;
     // a masked query row whose dO is exactly zero (the training case: no loss reaches a padded position) has dP = D = 0,
     // hence dS = 0 for every key: the keys beyond the diagonal are then needed by no row of the block
     const bool live_masked = __builtin_amdgcn_ballot_w64(qvalid && ldsKb[q] != 0.f && (frag_nonzero(dof[0]) || frag_nonzero(dof[1]))) != 0;
@@ -397,7 +416,7 @@ __global__ __launch_bounds__(768) void attn_dq_res_kernel(const bf16_t* __restri
 template <bool DROP>
 __global__ __launch_bounds__(768) void attn_dkv_res_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                             const float* __restrict__ kbias, const float* __restrict__ lse,
-                                                            const float* __restrict__ Dv, bf16_t* __restrict__ dqkv, int B,
+                                                            const bf16_t* __restrict__ outp, bf16_t* __restrict__ dqkv, int B,
                                                             int T, int H, float scale, uint32_t drop_thr,
                                                             uint32_t drop_key, float drop_scale) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -418,12 +437,24 @@ __global__ __launch_bounds__(768) void attn_dkv_res_kernel(const bf16_t* __restr
   const bf16_t* dobase = dout + (long)b * T * d + h * 32;
   const float* kb = kbias + (long)b * T;
   const float* lse_b = lse + ((long)b * H + h) * T;
-  const float* D_b = Dv + ((long)b * H + h) * T;
+  const bf16_t* obase = outp + (long)b * T * d + h * 32;
 
   stage_pair(qbase, ld, dobase, (long)d, imgQ, imgdO, T, Tp, tid, nthr);
-  for (int i = tid; i < Tp; i += nthr) {
-    ldsLse[i] = (i < T) ? lse_b[i] * LOG2E : 0.f;
-    ldsD[i] = (i < T) ? D_b[i] : 0.f;
+  for (int i = tid; i < Tp; i += nthr) ldsLse[i] = (i < T) ? lse_b[i] * LOG2E : 0.f;
+  // D[q] = sum_hd dO.O / s for every query of the head (the streaming kernels take it from a separate pass): four
+  // consecutive lanes hold the four 16-byte pieces of a row
+  {
+    const float inv_s = DROP ? 1.0f / drop_scale : 1.0f;
+    for (int c0 = 0; c0 < Tp * 4; c0 += nthr) {          // nthr is a multiple of 64: the quad stays together
+      const int c = c0 + tid, row = c >> 2, pc = c & 3;
+      float part = 0.f;
+      if (c < Tp * 4 && row < T)
+        part = dot8_bf16(*reinterpret_cast<const uint4*>(dobase + (long)row * d + pc * 8),
+                         *reinterpret_cast<const uint4*>(obase + (long)row * d + pc * 8));
+      part += __shfl_xor(part, 1, 64);
+      part += __shfl_xor(part, 2, 64);
+      if (c < Tp * 4 && pc == 0) ldsD[row] = part * inv_s;
+    }
   }
   const uint32_t padmask = pad_mask_of(kb, T, nblk, lane);   // bit j: query block j holds a masked (padded) row
   __syncthreads();
@@ -573,9 +604,9 @@ int neko_attn_fwd_res_impl(const bf16_t* qkv, const float* kbias, const int* kst
   return NEKO_OK;
 }
 
-// D (already divided by the survivor scale) comes from attn_bwd_prep_kernel, as for the streaming kernels
-int neko_attn_bwd_res_impl(const bf16_t* qkv, const bf16_t* dout, const float* kbias, const int* kstart, const float* lse,
-                           const float* D, bf16_t* dqkv, int B, int T, int H, int drop_thr, unsigned drop_key,
+// D = sum dO.O is formed inside both kernels (the D / qflags workspace of the streaming path is not touched)
+int neko_attn_bwd_res_impl(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const float* kbias, const int* kstart,
+                           const float* lse, bf16_t* dqkv, int B, int T, int H, int drop_thr, unsigned drop_key,
                            float drop_scale, hipStream_t s) {
   const int Tp = (T + 31) & ~31, nblk = Tp / 32, nw = min(12, (nblk + 1) / 2);
   const size_t lds_q = (size_t)Tp * 128 + (size_t)Tp * 4 + 16, lds_kv = (size_t)Tp * 128 + (size_t)Tp * 8 + 16;
@@ -584,16 +615,16 @@ int neko_attn_bwd_res_impl(const bf16_t* qkv, const bf16_t* dout, const float* k
                           allow_lds(attn_dkv_res_kernel<true>, 160 * 1024) | allow_lds(attn_dkv_res_kernel<false>, 160 * 1024);
   if (once != NEKO_OK) return once;
   if (drop_thr) {
-    hipLaunchKernelGGL((attn_dkv_res_kernel<true>), dim3(B * H), dim3(64 * nw), lds_kv, s, qkv, dout, kbias, lse, D, dqkv, B, T,
+    hipLaunchKernelGGL((attn_dkv_res_kernel<true>), dim3(B * H), dim3(64 * nw), lds_kv, s, qkv, dout, kbias, lse, out, dqkv, B, T,
                        H, scale, (uint32_t)drop_thr, drop_key, drop_scale);
     NEKO_CHECK_LAUNCH();
-    hipLaunchKernelGGL((attn_dq_res_kernel<true>), dim3(B * H), dim3(64 * nw), lds_q, s, qkv, dout, kbias, kstart, lse, D, dqkv,
+    hipLaunchKernelGGL((attn_dq_res_kernel<true>), dim3(B * H), dim3(64 * nw), lds_q, s, qkv, dout, kbias, kstart, lse, out, dqkv,
                        B, T, H, scale, (uint32_t)drop_thr, drop_key, drop_scale);
   } else {
-    hipLaunchKernelGGL((attn_dkv_res_kernel<false>), dim3(B * H), dim3(64 * nw), lds_kv, s, qkv, dout, kbias, lse, D, dqkv, B,
+    hipLaunchKernelGGL((attn_dkv_res_kernel<false>), dim3(B * H), dim3(64 * nw), lds_kv, s, qkv, dout, kbias, lse, out, dqkv, B,
                        T, H, scale, 0u, drop_key, drop_scale);
     NEKO_CHECK_LAUNCH();
-    hipLaunchKernelGGL((attn_dq_res_kernel<false>), dim3(B * H), dim3(64 * nw), lds_q, s, qkv, dout, kbias, kstart, lse, D, dqkv,
+    hipLaunchKernelGGL((attn_dq_res_kernel<false>), dim3(B * H), dim3(64 * nw), lds_q, s, qkv, dout, kbias, kstart, lse, out, dqkv,
                        B, T, H, scale, 0u, drop_key, drop_scale);
   }
   NEKO_CHECK_LAUNCH();
