@@ -172,7 +172,10 @@ __global__ __launch_bounds__(CE_NT) void ce_bf16_inplace_kernel(bf16_t* __restri
   const float lse = gm + __logf(gs);
   if (tid == 0 && loss_row) loss_row[row] = lse - z_t;
   if (!want_grad) return;
-  const float lse2 = lse * 1.4426950408889634f;
+  // weight folded into the exponent: w * 2^(z - lse) = 2^(z - lse + log2 w) for w > 0 (w == 0 rows returned above; a
+  // negative weight -- never produced by the policy -- takes the multiply, block-uniform)
+  const bool fold = w > 0.f;
+  const float lse2 = lse * 1.4426950408889634f - (fold ? __log2f(w) : 0.f);
 #pragma unroll
   for (int i = 0; i < CE_MAXCH; ++i) {
     const int c = tid + i * CE_NT;
@@ -184,12 +187,17 @@ __global__ __launch_bounds__(CE_NT) void ce_bf16_inplace_kernel(bf16_t* __restri
       p[2 * e] = __builtin_amdgcn_exp2f(fmaf(__uint_as_float(wv[e] << 16), 1.4426950408889634f, -lse2));
       p[2 * e + 1] = __builtin_amdgcn_exp2f(fmaf(__uint_as_float(wv[e] & 0xffff0000u), 1.4426950408889634f, -lse2));
     }
-    const int c0 = c * 8;
+    if (!fold) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float g = p[e];
-      if (c0 + e == tgt) g -= 1.f;
-      p[e] = g * w;
+      for (int e = 0; e < 8; ++e) p[e] *= w;
+    }
+    const int c0 = c * 8;
+    // the one-hot term lives in exactly one 16-B chunk of the row: a rare (1 in Vpad/8) thread-level branch instead of a
+    // compare + select on every element
+    if (tgt >= c0 && tgt < c0 + 8) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (c0 + e == tgt) p[e] -= w;
     }
     reinterpret_cast<uint4*>(zr)[c] = make_uint4(pack_bf16x2(p[0], p[1]), pack_bf16x2(p[2], p[3]),
                                                  pack_bf16x2(p[4], p[5]), pack_bf16x2(p[6], p[7]));
