@@ -30,6 +30,9 @@ class GradReducer:
         self.handles: List = []
         self.pending: Dict[str, bool] = {}
         self.grad_scale = torch.full((1,), 1.0 / self.world, dtype=torch.float32, device=flat.grad.device)
+        #: False on the accumulating micro-steps of gradient accumulation: nothing is reduced (the flat gradient keeps
+        #: adding up locally) until the last micro-step, whose backward reduces every range once
+        self.sync = True
 
     def broadcast_parameters(self, src: int = 0) -> None:
         """One-time parameter broadcast rank0 -> all (DDP constructor semantics)."""
@@ -43,13 +46,13 @@ class GradReducer:
 
     def group_ready(self, gname: str) -> None:
         """All gradient kernels of flat group `gname` are enqueued: launch its all-reduce(s)."""
-        if self.world == 1 or gname not in self.flat.group_ranges or gname in self.DEFERRED:
+        if self.world == 1 or not self.sync or gname not in self.flat.group_ranges or gname in self.DEFERRED:
             return
         self._reduce(gname)
 
     def flush(self) -> None:
         """After backward: reduce the ranges that are not guaranteed to be touched on every rank."""
-        if self.world == 1:
+        if self.world == 1 or not self.sync:
             return
         for g in self.DEFERRED:
             if g in self.flat.group_ranges:

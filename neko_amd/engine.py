@@ -127,10 +127,12 @@ class SideStream:
 
 def _wgrad(A: torch.Tensor, Bm: torch.Tensor, Mout: int, N: int, K: int, out: torch.Tensor,
            alpha_dev: Optional[torch.Tensor] = None) -> None:
-    """out[Mout,N] += A^T @ B with A stored [K, Mout], B stored [K, N] (both k-strided)."""
+    """out[Mout,N] += A^T @ B with A stored [K, Mout], B stored [K, N] (both k-strided).  Always "+=": a split-K product
+    goes through the slice workspace and the fixed-order reduce adds the existing gradient (a second backward before the
+    optimiser step -- gradient accumulation, trainer.py:176 -- must not overwrite the first)."""
     sk, kps = ops.pick_splitk(Mout, N, K)
     ops.gemm(A, Bm, Mout, N, K, a_kstrided=True, b_kstrided=True, lda=A.stride(0), ldb=Bm.stride(0),
-             out_f32=out, ldcf=out.stride(0), accumulate=(sk == 1), splitk=sk, k_per_split=kps,
+             out_f32=out, ldcf=out.stride(0), accumulate=True, splitk=sk, k_per_split=kps,
              alpha_dev=alpha_dev)
 
 

@@ -104,7 +104,7 @@ class _ImageEmbedFn(torch.autograd.Function):
         # dW[d,768] += g^T @ y ;  dy[P,768] = g @ W
         sk, kps = ops.pick_splitk(d, 768, P)
         ops.gemm(g16, ctx.y16, d, 768, P, a_kstrided=True, b_kstrided=True, lda=d, ldb=768,
-                 out_f32=f.gview(pre + "post_embedding_projection.weight"), ldcf=768, accumulate=(sk == 1),
+                 out_f32=f.gview(pre + "post_embedding_projection.weight"), ldcf=768, accumulate=True,   # also with split-K: one call per image-shape group
                  splitk=sk, k_per_split=kps)
         dy = torch.empty(P, 768, dtype=torch.float32, device=g.device)
         ops.gemm(g16, f.sview(pre + "post_embedding_projection.weight"), P, 768, d, b_kstrided=True, ldb=768,

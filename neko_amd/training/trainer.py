@@ -33,6 +33,11 @@ class Trainer:
         self.exp_name = exp_name
         self.exp_dir = os.path.join(self.args.save_dir, self.exp_name)
         self.steps = 0
+        # gradient accumulation (train.py:37, trainer.py:176 `accelerator.accumulate`): every call of train_step is one
+        # micro-batch whose loss is scaled by 1/k in backward; clip / optimiser / scheduler / zero_grad -- and the
+        # data-parallel all-reduce -- only run on every k-th call
+        self.accum_steps = max(1, int(getattr(args, "gradient_accumulation_steps", 1) or 1))
+        self._micro = 0
         self.start_time = None
         self.is_main = (not torch.distributed.is_initialized()) or torch.distributed.get_rank() == 0
 
@@ -115,13 +120,18 @@ class Trainer:
         batch = self.sample_batch()
         logs["time/sample_batch"] = time.time() - t0
         _, loss = self.model.forward(inputs=batch, compute_loss=True, return_logits=False)
-        loss.backward()
+        self._micro += 1
+        sync = self._micro % self.accum_steps == 0
         if self.dp is not None:
-            self.dp.flush()
-            self.dp.finish()
-        if not self.args.disable_grad_clip:
-            self.optimizer.clip_grad_norm_(self.args.grad_norm_clip)
-        self.optimizer.step()
-        self.scheduler.step()
-        self.optimizer.zero_grad()
+            self.dp.sync = sync                   # no gradient all-reduce on the accumulating micro-steps (DDP no_sync)
+        (loss / self.accum_steps if self.accum_steps > 1 else loss).backward()
+        if sync:
+            if self.dp is not None:
+                self.dp.flush()
+                self.dp.finish()
+            if not self.args.disable_grad_clip:
+                self.optimizer.clip_grad_norm_(self.args.grad_norm_clip)
+            self.optimizer.step()
+            self.scheduler.step()
+            self.optimizer.zero_grad()
         return loss.detach(), logs

@@ -167,6 +167,21 @@ def test_layernorm_fwd_bwd(ops, M, d):
     close(db, br.grad + 1, 1e-4, 1e-3, "ln dbeta")
 
 
+def test_wgrad_splitk_accumulates(ops):
+    """engine._wgrad at a contraction long enough for split-K (workspace slices + fixed-order reduce): the product is ADDED
+    to the gradient buffer, twice in a row (gradient accumulation; two image-shape groups in one backward)."""
+    from neko_amd import engine
+    g = torch.Generator().manual_seed(3)
+    K, Mo, N = 8192, 256, 512
+    A = rb(torch.randn(K, Mo, generator=g) * 0.1)
+    Bm = rb(torch.randn(K, N, generator=g) * 0.1)
+    assert ops.pick_splitk(Mo, N, K)[0] > 1
+    out = torch.ones(Mo, N, device=DEV)
+    engine._wgrad(bf(A), bf(Bm), Mo, N, K, out)
+    engine._wgrad(bf(A), bf(Bm), Mo, N, K, out)
+    close(out, 1.0 + 2.0 * (A.t() @ Bm), 1e-4, 2e-3, "split-K wgrad accumulate")
+
+
 # ----------------------------------------------------------------------------------------------------
 # attention
 # ----------------------------------------------------------------------------------------------------

@@ -230,3 +230,34 @@ def test_g7b_training_trace_1e3():
     print("g7b max rel loss dev", max(rel), "| max rel grad-norm dev", max(reln), "| loss", losses[0], "->", losses[-1])
     assert max(rel) < 1e-3, (max(rel), rel.index(max(rel)))
     assert max(reln) < 6e-2, (max(reln), reln.index(max(reln)))
+
+
+def test_gradient_accumulation_two_micro_batches():
+    """trainer.py:176 (`accelerator.accumulate`): two backward calls with losses scaled by 1/2 before one optimiser step
+    must leave (gA + gB) / 2 in the gradients -- every gradient kernel adds to what is there."""
+    cfg = O.OracleConfig(embed_dim=64, layers=2, heads=2, text_tokens=128, context_len=48)
+    m, sd = make_policy(cfg, 5)
+    m.eval()                                            # deterministic patch positions on both sides
+    g = torch.Generator().manual_seed(11)
+    bA = [{"text": torch.randint(0, 128, (20,), generator=g).tolist()},
+          {"continuous_obs": torch.randn(3, 4, generator=g), "continuous_actions": torch.rand(3, 2, generator=g) * 2 - 1},
+          {"images": torch.floor(torch.rand(1, 3, 32, 32, generator=g) * 256),
+           "discrete_actions": torch.randint(0, 4, (1, 1), generator=g).to(torch.int32)}]
+    bB = [{"text": torch.randint(0, 128, (33,), generator=g).tolist()},
+          {"images": torch.floor(torch.rand(2, 3, 32, 48, generator=g) * 256),
+           "discrete_actions": torch.randint(0, 4, (2, 1), generator=g).to(torch.int32)}]
+    ref = {}
+    for b in (bA, bB):
+        _, _, grads = O.loss_and_grads(sd, cfg, b)
+        for k, v in grads.items():
+            if v is not None:
+                ref[k] = ref.get(k, 0) + 0.5 * v
+    for b in (bA, bB):
+        _, loss = m(to_dev(b), compute_loss=True)
+        (loss / 2).backward()
+    named = dict(m.named_parameters())
+    for k, gref in ref.items():
+        if k.endswith("c_attn.bias"):
+            continue
+        assert named[k].grad is not None, k
+        assert relerr(named[k].grad, gref) < 8e-2, (k, relerr(named[k].grad, gref))
