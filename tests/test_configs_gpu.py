@@ -153,3 +153,44 @@ def test_checkpoint_resume_continues_the_same_trajectory(tmp_path):
     m3, o3 = fresh()
     m3.load_state_dict(ck["model"])
     assert abs(run(m3, o3, 3, 3)[-1] - ref[-1]) > 2e-5 * abs(ref[-1])
+
+
+def test_metric_shape_gradients_add_up():
+    """At the metric shape (768d x 6L x 24H, T = 1024, mixed batch with two image-shape groups, one of them >= 4096
+    patches) every gradient kernel must ADD: two backward passes of loss/2 on the same batch leave the same flat gradient
+    as one backward of the loss.  A scale of exactly 1/2 commutes with every bf16 rounding on the way, so the two results
+    agree to fp32 summation noise.  (Small-shape tests never reach the split-K weight-gradient paths: K >= 4096.)"""
+    from neko_amd.tasks import synthetic as S
+    m = _policy(768, 6, 24, 1024)
+    m.transformer.drop.p = 0.0
+    m.eval()                                            # deterministic patch positions: both passes see the same batch
+    batch = S.metric_mix_batch(16, 77, DEV)
+    f = m._flat
+
+    def grads(parts):
+        for p in m.parameters():
+            p.grad = None
+        f.zero_grad()
+        for _ in range(parts):
+            _, loss = m.forward(inputs=batch, compute_loss=True, return_logits=False)
+            (loss / parts).backward()
+        torch.cuda.synchronize()
+        return f.grad.clone()
+
+    g1 = grads(1)
+    g2 = grads(2)
+    scale = float(g1.abs().max())
+    assert scale > 0
+    # compare range by range so that a small tensor cannot hide behind a large one
+    for name, p in m.named_parameters():
+        if p.grad is None:
+            continue
+        a = f.gview(name)
+        off = a.data_ptr() - f.grad.data_ptr()
+        i0, n = off // 4, a.numel()
+        r1, r2 = g1[i0:i0 + n], g2[i0:i0 + n]
+        den = float(r1.abs().max())
+        if den == 0:
+            continue
+        err = float((r1 - r2).abs().max()) / den
+        assert err < 2e-3, (name, err)
