@@ -177,10 +177,16 @@ def test_metric_shape_gradients_add_up():
         torch.cuda.synchronize()
         return f.grad.clone()
 
+    from neko_amd import engine
     g1 = grads(1)
     g2 = grads(2)
-    scale = float(g1.abs().max())
-    assert scale > 0
+    was = engine.SideStream.enabled
+    engine.SideStream.enabled = False                   # everything on one stream: the reference for the fork / join ordering
+    try:
+        g3 = grads(1)
+    finally:
+        engine.SideStream.enabled = was
+    assert float(g1.abs().max()) > 0
     # compare range by range so that a small tensor cannot hide behind a large one
     for name, p in m.named_parameters():
         if p.grad is None:
@@ -188,9 +194,11 @@ def test_metric_shape_gradients_add_up():
         a = f.gview(name)
         off = a.data_ptr() - f.grad.data_ptr()
         i0, n = off // 4, a.numel()
-        r1, r2 = g1[i0:i0 + n], g2[i0:i0 + n]
+        r1, r2, r3 = g1[i0:i0 + n], g2[i0:i0 + n], g3[i0:i0 + n]
         den = float(r1.abs().max())
         if den == 0:
             continue
-        err = float((r1 - r2).abs().max()) / den
-        assert err < 2e-3, (name, err)
+        assert float((r1 - r2).abs().max()) / den < 2e-3, (name, "two half passes")
+        # same kernels, same order of every fixed-order reduction; only the atomically scattered embedding rows may differ
+        # in their last bits
+        assert float((r1 - r3).abs().max()) / den < 1e-5, (name, "side stream vs one stream")

@@ -427,3 +427,33 @@ def test_patch_pos_add(ops):
     ops.patch_pos_add_bwd(out.to(DEV), hp.to(DEV), wp.to(DEV), dr, dc)
     ref_r = torch.zeros(128, d).index_add_(0, hp.long(), out); ref_c = torch.zeros(128, d).index_add_(0, wp.long(), out)
     close(dr, ref_r, 1e-5, 1e-5, "pos bwd row"); close(dc, ref_c, 1e-5, 1e-5, "pos bwd col")
+
+
+@pytest.mark.parametrize("drop_p", [0.0, 0.1])
+def test_attention_schedules_agree_at_metric_shape(ops, drop_p):
+    """Head-resident and streaming kernels on the bench shape (32 x 1024 x 24 heads of 32, left padding on a third of the
+    batch, dropout as in training): same sums in a different order -> agreement at bf16-rounding level on every row."""
+    B, T, H, hd = 32, 1024, 24, 32
+    d = H * hd
+    g = torch.Generator(device=DEV).manual_seed(5)
+    qkv = torch.randn(B * T, 3 * d, device=DEV, generator=g).to(torch.bfloat16)
+    do = torch.randn(B * T, d, device=DEV, generator=g).to(torch.bfloat16)
+    mask = torch.ones(B, T, device=DEV)
+    for b in range(0, B, 3):
+        mask[b, : 16 + 20 * (b % 5)] = 0
+    do = (do.view(B, T, d) * mask[:, :, None].to(torch.bfloat16)).view(B * T, d).contiguous()   # training: no loss on padded rows
+    kb, ks = ops.mask_bias(mask)
+    drop = ops.Drop(drop_p, 0x2468ACE) if drop_p > 0 else None
+    res = {}
+    for path in (0, 1):
+        prev = ops.attn_set_path(path)
+        try:
+            out, lse = ops.attn_fwd(qkv, kb, ks, B, T, H, hd, drop=drop)
+            dqkv = ops.attn_bwd(qkv, out, do, kb, ks, lse, B, T, H, hd, drop=drop)
+        finally:
+            ops.attn_set_path(prev)
+        res[path] = (out.float(), lse, dqkv.float())
+    so, sg = float(res[1][0].abs().max()), float(res[1][2].abs().max())
+    assert float((res[0][0] - res[1][0]).abs().max()) < 2 ** -7 * so
+    assert float((res[0][1] - res[1][1]).abs().max()) < 1e-4 * float(res[1][1].abs().max())
+    assert float((res[0][2] - res[1][2]).abs().max()) < 2 ** -6 * sg
