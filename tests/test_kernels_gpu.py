@@ -70,6 +70,27 @@ def test_gemm_layouts(ops, layout, M, N, K, safe):
     close(out, ref, 2e-4, 2e-4 * math.sqrt(K), f"gemm {layout} safe={safe}")
 
 
+@pytest.mark.parametrize("layout", ["nt", "nn", "tn"])
+@pytest.mark.parametrize("K", [64, 128, 192, 256, 448, 2112])
+def test_gemm_pipelined_loop_short_and_long_k(ops, layout, K):
+    """Output large enough for the 256x256 tile (4-stage ring: the software-pipelined main loop for k-contiguous operands,
+    the plain loop for the doubly k-strided form) at contractions of 2, 4, 6, 8, 14 and 66 k-tiles: prologue shorter than
+    the ring, main part absent / present, drain of every length."""
+    g = torch.Generator().manual_seed(K)
+    M, N = 2048, 2304
+    A = rb(torch.randn(M, K, generator=g)); Bm = rb(torch.randn(K, N, generator=g) * 0.2)
+    ref = A @ Bm
+    a_ks, b_ks = layout == "tn", layout in ("nn", "tn")
+    A_dev = bf(A.t()) if a_ks else bf(A)
+    B_dev = bf(Bm) if b_ks else bf(Bm.t())
+    out = torch.full((M, N), float("nan"), device=DEV)
+    ops.gemm(A_dev, B_dev, M, N, K, a_kstrided=a_ks, b_kstrided=b_ks, out_f32=out)
+    close(out, ref, 2e-4, 2e-4 * math.sqrt(K), f"gemm 256-tile {layout} K={K}")
+    out16 = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(A_dev, B_dev, M, N, K, a_kstrided=a_ks, b_kstrided=b_ks, out_bf16=out16)
+    close(out16, ref, 2 ** -7, 2e-4 * math.sqrt(K), f"gemm 256-tile bf16 {layout} K={K}")
+
+
 def test_gemm_many_tiles_fast_epilogues(ops):
     """A shape with several hundred 256x256 / 128x128 tiles (more than one round of the chip) through the specialised
     epilogues: forward-like (bias + bf16 / GELU + pre-activation / bias + residual f32) and dgrad-like (both operands
@@ -457,3 +478,31 @@ def test_attention_schedules_agree_at_metric_shape(ops, drop_p):
     assert float((res[0][0] - res[1][0]).abs().max()) < 2 ** -7 * so
     assert float((res[0][1] - res[1][1]).abs().max()) < 1e-4 * float(res[1][1].abs().max())
     assert float((res[0][2] - res[1][2]).abs().max()) < 2 ** -6 * sg
+
+
+def test_lm_head_chunking_is_invisible(ops):
+    """engine.lm_head_loss over 4096-row chunks (the training path at the metric shape) against one chunk holding every row:
+    same loss, same bf16 dlogits, and the same dH / dW from the backward GEMMs (split-K at these sizes)."""
+    from neko_amd import engine
+    g = torch.Generator(device=DEV).manual_seed(9)
+    M, d, V = 9000, 768, 52305
+    Vpad = (V + 127) // 128 * 128
+    w = torch.zeros(Vpad, d, device=DEV)
+    w[:V] = torch.randn(V, d, device=DEV, generator=g) * 0.02
+    hp = engine.HeadParams(V=V, Vpad=Vpad, w=w.to(torch.bfloat16), g_w=torch.zeros(Vpad, d, device=DEV))
+    hf = torch.randn(M, d, device=DEV, generator=g).to(torch.bfloat16)
+    tgt = torch.randint(0, V, (M,), device=DEV, generator=g)
+    sel = (torch.rand(M, device=DEV, generator=g) > 0.25).float()
+    cnt = sel.sum()
+    la, da = engine.lm_head_loss(hp, hf, tgt, sel, cnt, True, chunk_rows=4096)
+    lb, db = engine.lm_head_loss(hp, hf, tgt, sel, cnt, True, chunk_rows=1 << 20)
+    assert abs(float(la) - float(lb)) < 1e-6 * abs(float(lb))
+    assert torch.equal(da, db)
+    go = torch.ones((), device=DEV)
+    dh = engine.lm_head_backward(hp, hf, da, go)
+    engine.SideStream.join(DEV)
+    torch.cuda.synchronize()
+    dh_ref = (da.float() @ hp.w.float())
+    dw_ref = da.float().t() @ hf.float()
+    close(dh, dh_ref, 1e-3, 1e-3 * float(dh_ref.abs().max()), "LM-head dH")
+    close(hp.g_w, dw_ref, 1e-3, 1e-3 * float(dw_ref.abs().max()), "LM-head dW")
