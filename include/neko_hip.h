@@ -33,7 +33,7 @@ extern "C" {
 #define NEKO_ERR_UNSUPPORTED (-2)
 #define NEKO_ERR_LAUNCH (-3)
 
-#define NEKO_ABI_VERSION 7
+#define NEKO_ABI_VERSION 8
 
 int neko_abi_version(void);
 /* human-readable text for a return code (static storage) */
@@ -82,6 +82,12 @@ int neko_layernorm_bwd_blocks(int M);
 int neko_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                        const float* g_in, float* dx, uint16_t* dx16, float* dgamma, float* dbeta, int accumulate,
                        float* workspace, int M, int d, int drop_thr, unsigned drop_key, float drop_scale, void* stream);
+/* same with dy as bf16 [M,d] (the dgrad GEMM's bf16 output, as autocast leaves it in the reference: the gradient of a
+ * bf16 addmm input is bf16, trajectory_gpt2.py:274-277): half the bytes written by the GEMM and read here */
+int neko_layernorm_bwd_bf16dy(const uint16_t* dy, const float* x, const float* gamma, const float* mean,
+                              const float* rstd, const float* g_in, float* dx, uint16_t* dx16, float* dgamma,
+                              float* dbeta, int accumulate, float* workspace, int M, int d, int drop_thr,
+                              unsigned drop_key, float drop_scale, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Attention -- Attention._attn + split_heads/merge_heads (trajectory_gpt2.py:163-201,222-226,252)

@@ -73,8 +73,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 
 // Backward. Block = 4 waves; each wave walks rows (grid-stride) and keeps per-lane partial
 // dgamma/dbeta for its columns; the 4 waves are combined through LDS into one partial row per block.
-template <int NV>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+// DY16: dy arrives as bf16 (the dgrad GEMM's output as the reference's autocast produces it: the gradient of a bf16
+// addmm input is bf16, trajectory_gpt2.py:274-277 under train.py:33-40) -- 2 instead of 4 bytes per element read here
+// and written by the GEMM.
+template <int NV, bool DY16>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy_any, const float* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const float* __restrict__ g_in,
                                                      float* __restrict__ dx, bf16_t* __restrict__ dx16,
@@ -104,14 +107,21 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     nmu = mean[row];
     nrs = rstd[row];
     const float4* xr = reinterpret_cast<const float4*>(x + (long)row * d);
-    const float4* dr = reinterpret_cast<const float4*>(dy + (long)row * d);
+    const float4* dr = reinterpret_cast<const float4*>(static_cast<const float*>(dy_any) + (long)row * d);
+    const uint2* dr16 = reinterpret_cast<const uint2*>(static_cast<const bf16_t*>(dy_any) + (long)row * d);
     const float4* gr = g_in ? reinterpret_cast<const float4*>(g_in + (long)row * d) : nullptr;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int c = lane + 64 * i;
       const bool ok = c < nvec;
       nx[i] = ok ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
-      nd[i] = ok ? dr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (DY16) {
+        const uint2 q = ok ? dr16[c] : make_uint2(0u, 0u);
+        nd[i] = make_float4(__uint_as_float(q.x << 16), __uint_as_float(q.x & 0xffff0000u), __uint_as_float(q.y << 16),
+                            __uint_as_float(q.y & 0xffff0000u));
+      } else {
+        nd[i] = ok ? dr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
       ng[i] = (ok && gr) ? gr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
@@ -229,11 +239,15 @@ int fwd_launch(const float* x, const float* g, const float* b, bf16_t* y16, floa
   return NEKO_OK;
 }
 template <int NV>
-int bwd_launch(const float* dy, const float* x, const float* g, const float* mean, const float* rstd,
+int bwd_launch(const void* dy, int dy16, const float* x, const float* g, const float* mean, const float* rstd,
                const float* g_in, float* dx, bf16_t* dx16, float* part, int nblk, int M, int d, int thr, unsigned key,
                float scale, hipStream_t s) {
-  hipLaunchKernelGGL((ln_bwd_kernel<NV>), dim3(nblk), dim3(256), (size_t)8 * d * sizeof(float), s, dy, x, g, mean,
-                     rstd, g_in, dx, dx16, part, M, d, (uint32_t)thr, key, scale);
+  if (dy16)
+    hipLaunchKernelGGL((ln_bwd_kernel<NV, true>), dim3(nblk), dim3(256), (size_t)8 * d * sizeof(float), s, dy, x, g, mean,
+                       rstd, g_in, dx, dx16, part, M, d, (uint32_t)thr, key, scale);
+  else
+    hipLaunchKernelGGL((ln_bwd_kernel<NV, false>), dim3(nblk), dim3(256), (size_t)8 * d * sizeof(float), s, dy, x, g, mean,
+                       rstd, g_in, dx, dx16, part, M, d, (uint32_t)thr, key, scale);
   NEKO_CHECK_LAUNCH();
   return NEKO_OK;
 }
@@ -261,7 +275,7 @@ int neko_layernorm_bwd_blocks_impl(int M) {
   return nb < cap ? (nb < 1 ? 1 : nb) : cap;
 }
 
-int neko_layernorm_bwd_impl(const float* dy, const float* x, const float* gamma, const float* mean,
+int neko_layernorm_bwd_impl(const void* dy, int dy16, const float* x, const float* gamma, const float* mean,
                             const float* rstd, const float* g_in, float* dx, bf16_t* dx16, float* dgamma,
                             float* dbeta, int accumulate, float* workspace, int M, int d, int drop_thr,
                             unsigned drop_key, float drop_scale, hipStream_t s) {
@@ -271,12 +285,12 @@ int neko_layernorm_bwd_impl(const float* dy, const float* x, const float* gamma,
   const int nblk = neko_layernorm_bwd_blocks_impl(M);
   const int nv = (d / 4 + 63) / 64;
   int rc;
-  if (nv <= 1) rc = bwd_launch<1>(dy, x, gamma, mean, rstd, g_in, dx, dx16, workspace, nblk, M, d, drop_thr, drop_key, drop_scale, s);
-  else if (nv <= 2) rc = bwd_launch<2>(dy, x, gamma, mean, rstd, g_in, dx, dx16, workspace, nblk, M, d, drop_thr, drop_key, drop_scale, s);
-  else if (nv <= 3) rc = bwd_launch<3>(dy, x, gamma, mean, rstd, g_in, dx, dx16, workspace, nblk, M, d, drop_thr, drop_key, drop_scale, s);
-  else if (nv <= 4) rc = bwd_launch<4>(dy, x, gamma, mean, rstd, g_in, dx, dx16, workspace, nblk, M, d, drop_thr, drop_key, drop_scale, s);
-  else if (nv <= 8) rc = bwd_launch<8>(dy, x, gamma, mean, rstd, g_in, dx, dx16, workspace, nblk, M, d, drop_thr, drop_key, drop_scale, s);
-  else rc = bwd_launch<16>(dy, x, gamma, mean, rstd, g_in, dx, dx16, workspace, nblk, M, d, drop_thr, drop_key, drop_scale, s);
+  if (nv <= 1) rc = bwd_launch<1>(dy, dy16, x, gamma, mean, rstd, g_in, dx, dx16, workspace, nblk, M, d, drop_thr, drop_key, drop_scale, s);
+  else if (nv <= 2) rc = bwd_launch<2>(dy, dy16, x, gamma, mean, rstd, g_in, dx, dx16, workspace, nblk, M, d, drop_thr, drop_key, drop_scale, s);
+  else if (nv <= 3) rc = bwd_launch<3>(dy, dy16, x, gamma, mean, rstd, g_in, dx, dx16, workspace, nblk, M, d, drop_thr, drop_key, drop_scale, s);
+  else if (nv <= 4) rc = bwd_launch<4>(dy, dy16, x, gamma, mean, rstd, g_in, dx, dx16, workspace, nblk, M, d, drop_thr, drop_key, drop_scale, s);
+  else if (nv <= 8) rc = bwd_launch<8>(dy, dy16, x, gamma, mean, rstd, g_in, dx, dx16, workspace, nblk, M, d, drop_thr, drop_key, drop_scale, s);
+  else rc = bwd_launch<16>(dy, dy16, x, gamma, mean, rstd, g_in, dx, dx16, workspace, nblk, M, d, drop_thr, drop_key, drop_scale, s);
   if (rc != NEKO_OK) return rc;
   hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * d + 63) / 64), dim3(256), 0, s, workspace, nblk, d, dgamma,
                      dbeta, accumulate);

@@ -39,7 +39,7 @@ int neko_gemm_glds_try(const GemmArgs& a, int a_kstrided, int b_kstrided, hipStr
 int neko_layernorm_fwd_impl(const float* x, const float* gamma, const float* beta, bf16_t* y16, float* y32,
                             float* mean, float* rstd, int M, int d, float eps, hipStream_t s);
 int neko_layernorm_bwd_blocks_impl(int M);
-int neko_layernorm_bwd_impl(const float* dy, const float* x, const float* gamma, const float* mean,
+int neko_layernorm_bwd_impl(const void* dy, int dy_is_bf16, const float* x, const float* gamma, const float* mean,
                             const float* rstd, const float* g_in, float* dx, bf16_t* dx16, float* dgamma,
                             float* dbeta, int accumulate, float* workspace, int M, int d, int drop_thr,
                             unsigned drop_key, float drop_scale, hipStream_t s);

@@ -82,6 +82,22 @@ class StackCtx:
     rstdf: torch.Tensor = None
 
 
+#: dtype of the gradients that the dgrad GEMMs hand to the LayerNorm backward.  bf16 (NEKO_LN_DY_BF16=1) is what autocast
+#: leaves there in the reference and halves those bytes, but measured 0.2 ms per m-mix step SLOWER than fp32 on the same
+#: box (23.17 vs 22.96 ms: the 8-byte-per-lane bf16 epilogue stores of the N = 768 dgrads cost more than the LayerNorm
+#: backward saves), so fp32 stays the default; both paths are covered by the LayerNorm parity test.
+LN_DY_DTYPE = BF16 if os.environ.get("NEKO_LN_DY_BF16", "0") == "1" else F32
+
+
+def _dgrad_to_ln(a, w, M, N, K, ldb):
+    out = torch.empty(M, N, dtype=LN_DY_DTYPE, device=a.device)
+    if LN_DY_DTYPE == BF16:
+        ops.gemm(a, w, M, N, K, ldb=ldb, out_bf16=out)
+    else:
+        ops.gemm(a, w, M, N, K, ldb=ldb, out_f32=out)
+    return out
+
+
 class SideStream:
     """Weight / bias gradients on a second HIP stream.  They hang off the backward chain (nothing downstream reads them
     until the all-reduce / optimiser), while the chain itself is a sequence of launches whose last round rarely fills
@@ -214,8 +230,9 @@ def stack_backward(P: StackParams, ctx: StackCtx, dhf: torch.Tensor,
         ops.gemm(g16, lp.w_pr, M, 4 * d, d, ldb=d, act=2, act_in=c.pre, out_bf16=d_pre)       # dgrad * gelu'
         SideStream.fork(lambda c=c, lp=lp, g16=g16: (_wgrad(c.h, g16, 4 * d, d, M, lp.g_w_pr),
                                                     ops.colsum_bf16(g16, M, d, lp.g_b_pr)), g16)
-        d_a2 = torch.empty(M, d, dtype=F32, device=dev)
-        ops.gemm(d_pre, lp.w_fc, M, d, 4 * d, ldb=4 * d, out_f32=d_a2)
+        # gradients wrt the LayerNorm outputs leave their dgrad GEMMs as bf16, as autocast leaves them in the reference
+        # (the gradient of a bf16 addmm input is bf16): half the bytes out of the GEMM and into the LayerNorm backward
+        d_a2 = _dgrad_to_ln(d_pre, lp.w_fc, M, d, 4 * d, 4 * d)
         SideStream.fork(lambda c=c, lp=lp, d_pre=d_pre: (_wgrad(c.a2, d_pre, d, 4 * d, M, lp.g_w_fc),
                                                         ops.colsum_bf16(d_pre, M, 4 * d, lp.g_b_fc)), d_pre)
         g1 = torch.empty(M, d, dtype=F32, device=dev)
@@ -228,8 +245,7 @@ def stack_backward(P: StackParams, ctx: StackCtx, dhf: torch.Tensor,
         SideStream.fork(lambda c=c, lp=lp, g1_16=g1_16: (_wgrad(c.o, g1_16, d, d, M, lp.g_w_o),
                                                           ops.colsum_bf16(g1_16, M, d, lp.g_b_o)), g1_16)
         dqkv = ops.attn_bwd(c.qkv, c.o, d_o, ctx.kbias, ctx.kstart, c.lse, B, T, H, hd, drop=dr.attn[i] if dr else None)
-        d_a1 = torch.empty(M, d, dtype=F32, device=dev)
-        ops.gemm(dqkv, lp.w_qkv, M, d, 3 * d, ldb=3 * d, out_f32=d_a1)
+        d_a1 = _dgrad_to_ln(dqkv, lp.w_qkv, M, d, 3 * d, 3 * d)
         SideStream.fork(lambda c=c, lp=lp, dqkv=dqkv: (_wgrad(c.a1, dqkv, d, 3 * d, M, lp.g_w_qkv),
                                                       ops.colsum_bf16(dqkv, M, 3 * d, lp.g_b_qkv)), dqkv)
         g0 = torch.empty(M, d, dtype=F32, device=dev)

@@ -140,11 +140,12 @@ def layernorm_fwd(x, gamma, beta, y16=None, y32=None, mean=None, rstd=None, eps:
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, g_in=None, dx=None, dx16=None, accumulate=True, drop=None):
-    _chk(dy, torch.float32, "dy")
+    """dy fp32 or bf16 [M,d] (neko_layernorm_bwd / neko_layernorm_bwd_bf16dy)."""
+    assert dy.is_cuda and dy.dtype in (torch.float32, BF16) and dy.is_contiguous(), "dy must be a contiguous f32 / bf16 device tensor"
     M, d = x.shape[0], x.shape[1]
     nblk = _lib.load().neko_layernorm_bwd_blocks(M)
     ws = torch.empty(nblk * 2 * d, dtype=torch.float32, device=x.device)
-    _lib.call("neko_layernorm_bwd", _p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(g_in), _p(dx), _p(dx16),
+    _lib.call("neko_layernorm_bwd_bf16dy" if dy.dtype == BF16 else "neko_layernorm_bwd", _p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(g_in), _p(dx), _p(dx16),
               _p(dgamma), _p(dbeta), int(accumulate), _p(ws), M, d, *_drop(drop), _stream())
 
 

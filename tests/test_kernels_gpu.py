@@ -164,12 +164,15 @@ def test_gemm_epilogues(ops):
 # ----------------------------------------------------------------------------------------------------
 # LayerNorm
 # ----------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dy_bf16", [False, True])
 @pytest.mark.parametrize("M,d", [(5, 64), (333, 128), (1000, 768), (64, 2048)])
-def test_layernorm_fwd_bwd(ops, M, d):
+def test_layernorm_fwd_bwd(ops, M, d, dy_bf16):
     g = torch.Generator().manual_seed(d + M)
     x = torch.randn(M, d, generator=g) * 2 + 0.3
     w, b = torch.randn(d, generator=g), torch.randn(d, generator=g)
     dy, gin = torch.randn(M, d, generator=g), torch.randn(M, d, generator=g)
+    if dy_bf16:
+        dy = rb(dy)                                     # the kernel reads the same bf16 values the reference math gets
     xr = x.clone().requires_grad_(True); wr = w.clone().requires_grad_(True); br = b.clone().requires_grad_(True)
     y = torch.nn.functional.layer_norm(xr, (d,), wr, br, 1e-5)
     y.backward(dy)
@@ -181,7 +184,8 @@ def test_layernorm_fwd_bwd(ops, M, d):
     close(y16, y, 2 ** -8, 1e-5, "ln fwd bf16")
     dg = torch.ones(d, device=DEV); db = torch.ones(d, device=DEV)       # accumulate onto ones
     dx = torch.empty(M, d, device=DEV); dx16 = torch.empty(M, d, dtype=torch.bfloat16, device=DEV)
-    ops.layernorm_bwd(dy.to(DEV), xd, w.to(DEV), mean, rstd, dg, db, g_in=gin.to(DEV), dx=dx, dx16=dx16)
+    ops.layernorm_bwd(bf(dy) if dy_bf16 else dy.to(DEV), xd, w.to(DEV), mean, rstd, dg, db, g_in=gin.to(DEV), dx=dx,
+                      dx16=dx16)
     close(dx, xr.grad + gin, 1e-4, 1e-4, "ln dx")
     close(dx16, xr.grad + gin, 2 ** -8, 1e-4, "ln dx16")
     close(dg, wr.grad + 1, 1e-4, 1e-3, "ln dgamma")
