@@ -23,6 +23,8 @@ SHAPES = [
     ("dgrad pr  NT", M, 4 * D, D, False, False, "gelubwd,bf16"),
     ("dgrad fc  NT", M, D, 4 * D, False, False, "f32"),
     ("dgrad o   NT", M, D, D, False, False, "bf16"),
+    ("dgrad fc16 NT", M, D, 4 * D, False, False, "bf16"),
+    ("dgrad qkv16 NT", M, D, 3 * D, False, False, "bf16"),
     ("dgrad qkv NT", M, D, 3 * D, False, False, "f32"),
     ("wgrad pr  TN", 4 * D, D, M, True, True, "splitk"),
     ("wgrad fc  TN", D, 4 * D, M, True, True, "splitk"),
