@@ -33,7 +33,7 @@ extern "C" {
 #define NEKO_ERR_UNSUPPORTED (-2)
 #define NEKO_ERR_LAUNCH (-3)
 
-#define NEKO_ABI_VERSION 8
+#define NEKO_ABI_VERSION 9
 
 int neko_abi_version(void);
 /* human-readable text for a return code (static storage) */
@@ -186,6 +186,13 @@ int neko_gather_rows_bf16(const uint16_t* src, const int* idx, uint16_t* dst, in
 int neko_scatter_rows_f32(const float* src, const int* idx, float* dst, int n, int d, void* stream);
 int neko_colsum_bf16(const uint16_t* x, long ld, int M, int N, float* out, int accumulate, void* stream);
 int neko_sqnorm_f32(const float* g, long n, double* out_accum, void* stream);
+/* GEGLU gate of the MLP (activation_fn='geglu': gato_policy.py:97-100, MLP.forward trajectory_gpt2.py:273-278,
+ * h = gelu(c_fc x) * gated_layer(x)); flat bf16 arrays of n elements, 16-B aligned.
+ *   neko_geglu_fwd: h *= gate in place (h holds gelu(pre) from the c_fc GEMM epilogue)
+ *   neko_geglu_bwd: d_pre = dh * gate * gelu'(pre),  d_gate = dh * gelu(pre) */
+int neko_geglu_fwd(uint16_t* h, const uint16_t* gate, long n, void* stream);
+int neko_geglu_bwd(const uint16_t* dh, const uint16_t* pre, const uint16_t* gate, uint16_t* d_pre, uint16_t* d_gate,
+                   long n, void* stream);
 int neko_adamw_step(float* p, const float* g, float* m, float* v, uint16_t* p16, long n, float lr, float beta1,
                     float beta2, float eps, float weight_decay, const double* gnorm_sq, float max_norm,
                     const float* grad_scale, int* step, const int* active, void* stream);

@@ -183,6 +183,72 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
   }
 }
 
+
+// ---- GEGLU gate (MLP.forward with config.gate, trajectory_gpt2.py:273-278): h = gelu(c_fc x) * gated_layer(x) -------
+// forward : h (= gelu(pre), written by the c_fc GEMM epilogue) *= gate, in place, bf16, 8 elements (16 B) per thread.
+// backward: from dh = d(loss)/d(h) (dgrad through c_proj), pre and gate:
+//           d_pre = dh * gate * gelu'(pre)   (feeds the c_fc dgrad / wgrad)
+//           d_gate = dh * gelu(pre)          (feeds the gated_layer dgrad / wgrad)
+// gelu and gelu' share one exponential (erf_exp_parts).  HBM-bound: 3 reads + 2 writes of [M, 4d] bf16.
+__device__ __forceinline__ void unpack8(const uint4& v, float (&f)[8]) {
+  const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    f[2 * e] = __uint_as_float(w[e] << 16);
+    f[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u);
+  }
+}
+__device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
+  uint4 o;
+  o.x = pack_bf16x2(f[0], f[1]); o.y = pack_bf16x2(f[2], f[3]);
+  o.z = pack_bf16x2(f[4], f[5]); o.w = pack_bf16x2(f[6], f[7]);
+  return o;
+}
+__global__ __launch_bounds__(256) void geglu_fwd_kernel(bf16_t* __restrict__ h, const bf16_t* __restrict__ gate, long n) {
+  const long stride = (long)gridDim.x * blockDim.x * 8;
+  for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 8; i < n; i += stride) {
+    if (i + 8 <= n) {
+      float a[8], g[8];
+      unpack8(*reinterpret_cast<const uint4*>(h + i), a);
+      unpack8(*reinterpret_cast<const uint4*>(gate + i), g);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a[e] *= g[e];
+      *reinterpret_cast<uint4*>(h + i) = pack8(a);
+    } else {
+      for (long j = i; j < n; ++j) h[j] = f32_to_bf16(bf16_to_f32(h[j]) * bf16_to_f32(gate[j]));
+    }
+  }
+}
+__global__ __launch_bounds__(256) void geglu_bwd_kernel(const bf16_t* __restrict__ dh, const bf16_t* __restrict__ pre,
+                                                        const bf16_t* __restrict__ gate, bf16_t* __restrict__ d_pre,
+                                                        bf16_t* __restrict__ d_gate, long n) {
+  const long stride = (long)gridDim.x * blockDim.x * 8;
+  for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 8; i < n; i += stride) {
+    if (i + 8 <= n) {
+      float g[8], x[8], gt[8], dp[8], dg[8];
+      unpack8(*reinterpret_cast<const uint4*>(dh + i), g);
+      unpack8(*reinterpret_cast<const uint4*>(pre + i), x);
+      unpack8(*reinterpret_cast<const uint4*>(gate + i), gt);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float er, ex;
+        erf_exp_parts(x[e], er, ex);
+        const float cdf = 0.5f * (1.0f + er);
+        dg[e] = g[e] * (x[e] * cdf);
+        dp[e] = g[e] * gt[e] * fmaf(x[e] * 0.39894228040143267794f, ex, cdf);
+      }
+      *reinterpret_cast<uint4*>(d_pre + i) = pack8(dp);
+      *reinterpret_cast<uint4*>(d_gate + i) = pack8(dg);
+    } else {
+      for (long j = i; j < n; ++j) {
+        const float g = bf16_to_f32(dh[j]), x = bf16_to_f32(pre[j]);
+        d_gate[j] = f32_to_bf16(g * gelu_f(x));
+        d_pre[j] = f32_to_bf16(g * bf16_to_f32(gate[j]) * gelu_grad_f(x));
+      }
+    }
+  }
+}
+
 inline int grid_for(long n, int per_thread) {
   long b = (n + 256L * per_thread - 1) / (256L * per_thread);
   if (b > 2048) b = 2048;   // grid-stride the rest (256 CUs x 8 blocks)
@@ -241,6 +307,24 @@ int neko_adamw_step_impl(float* p, const float* g, float* m, float* v, bf16_t* p
   NEKO_CHECK_LAUNCH();
   AdamArgs a{p, g, m, v, p16, n, lr, beta1, beta2, eps, wd, max_norm, gnorm_sq, grad_scale, step, active};
   hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n, 8)), dim3(256), 0, s, a);
+  NEKO_CHECK_LAUNCH();
+  return NEKO_OK;
+}
+
+int neko_geglu_fwd_impl(bf16_t* h, const bf16_t* gate, long n, hipStream_t s) {
+  if (n <= 0) return NEKO_OK;
+  if (!h || !gate || (((uintptr_t)h | (uintptr_t)gate) & 15)) return NEKO_ERR_ARG;
+  hipLaunchKernelGGL(geglu_fwd_kernel, dim3(grid_for(n, 8)), dim3(256), 0, s, h, gate, n);
+  NEKO_CHECK_LAUNCH();
+  return NEKO_OK;
+}
+
+int neko_geglu_bwd_impl(const bf16_t* dh, const bf16_t* pre, const bf16_t* gate, bf16_t* d_pre, bf16_t* d_gate, long n,
+                        hipStream_t s) {
+  if (n <= 0) return NEKO_OK;
+  if (!dh || !pre || !gate || !d_pre || !d_gate) return NEKO_ERR_ARG;
+  if (((uintptr_t)dh | (uintptr_t)pre | (uintptr_t)gate | (uintptr_t)d_pre | (uintptr_t)d_gate) & 15) return NEKO_ERR_ARG;
+  hipLaunchKernelGGL(geglu_bwd_kernel, dim3(grid_for(n, 8)), dim3(256), 0, s, dh, pre, gate, d_pre, d_gate, n);
   NEKO_CHECK_LAUNCH();
   return NEKO_OK;
 }

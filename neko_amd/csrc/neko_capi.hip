@@ -109,6 +109,13 @@ int neko_dropout_f32(const float* x, float* y, long n, int thr, unsigned key, fl
 int neko_cast_f32_bf16(const float* x, uint16_t* y, long n, void* stream) {
   return neko_cast_f32_bf16_impl(x, y, n, S(stream));
 }
+int neko_geglu_fwd(uint16_t* h, const uint16_t* gate, long n, void* stream) {
+  return neko_geglu_fwd_impl(h, gate, n, S(stream));
+}
+int neko_geglu_bwd(const uint16_t* dh, const uint16_t* pre, const uint16_t* gate, uint16_t* d_pre, uint16_t* d_gate, long n,
+                   void* stream) {
+  return neko_geglu_bwd_impl(dh, pre, gate, d_pre, d_gate, n, S(stream));
+}
 int neko_colsum_bf16(const uint16_t* x, long ld, int M, int N, float* out, int accumulate, void* stream) {
   return neko_colsum_bf16_impl(x, ld, M, N, out, accumulate, S(stream));
 }

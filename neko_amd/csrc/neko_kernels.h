@@ -74,6 +74,9 @@ int neko_pack_embed_bwd_impl(const int* desc, const long long* tokens, const flo
 int neko_tokenize_continuous_impl(const float* x, int* ids, long n, int use_mu_law, float mu, float M, int n_bins,
                                   int offset, hipStream_t s);
 int neko_cast_f32_bf16_impl(const float* x, bf16_t* y, long n, hipStream_t s);
+int neko_geglu_fwd_impl(bf16_t* h, const bf16_t* gate, long n, hipStream_t s);
+int neko_geglu_bwd_impl(const bf16_t* dh, const bf16_t* pre, const bf16_t* gate, bf16_t* d_pre, bf16_t* d_gate, long n,
+                        hipStream_t s);
 int neko_colsum_bf16_impl(const bf16_t* x, long ld, int M, int N, float* out, int accumulate, hipStream_t s);
 int neko_mask_bias_impl(const float* mask, float* kbias, int* kstart, int B, int T, hipStream_t s);
 int neko_sqnorm_f32_impl(const float* g, long n, double* out_accum, hipStream_t s);

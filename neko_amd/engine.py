@@ -32,6 +32,9 @@ class LayerParams:
     g_ln1_w: torch.Tensor; g_ln1_b: torch.Tensor; g_ln2_w: torch.Tensor; g_ln2_b: torch.Tensor
     g_b_qkv: torch.Tensor; g_b_o: torch.Tensor; g_b_fc: torch.Tensor; g_b_pr: torch.Tensor
     g_w_qkv: torch.Tensor; g_w_o: torch.Tensor; g_w_fc: torch.Tensor; g_w_pr: torch.Tensor
+    # GEGLU gate (activation_fn='geglu', trajectory_gpt2.py:267-276): nn.Linear (4d, d) weight + bias, or None
+    w_gate: Optional[torch.Tensor] = None; b_gate: Optional[torch.Tensor] = None
+    g_w_gate: Optional[torch.Tensor] = None; g_b_gate: Optional[torch.Tensor] = None
 
 
 @dataclass
@@ -66,7 +69,7 @@ class LayerCtx:
     x: torch.Tensor = None; a1: torch.Tensor = None; mean1: torch.Tensor = None; rstd1: torch.Tensor = None
     qkv: torch.Tensor = None; o: torch.Tensor = None; lse: torch.Tensor = None
     x1: torch.Tensor = None; a2: torch.Tensor = None; mean2: torch.Tensor = None; rstd2: torch.Tensor = None
-    pre: torch.Tensor = None; h: torch.Tensor = None
+    pre: torch.Tensor = None; h: torch.Tensor = None; gate: torch.Tensor = None
 
 
 @dataclass
@@ -152,6 +155,20 @@ def _wgrad(A: torch.Tensor, Bm: torch.Tensor, Mout: int, N: int, K: int, out: to
              alpha_dev=alpha_dev)
 
 
+def _geglu_gate(lp: LayerParams, a2: torch.Tensor, h: torch.Tensor, M: int, d: int) -> Optional[torch.Tensor]:
+    """GEGLU (trajectory_gpt2.py:275-276): h (= gelu(c_fc a2), from the GEMM epilogue) *= gated_layer(a2) in place.
+    Returns the gate [M, 4d] bf16 (saved for backward) or None when the MLP is not gated."""
+    if lp.w_gate is None:
+        return None
+    gate = torch.empty(M, 4 * d, dtype=BF16, device=a2.device)
+    if M <= 8 and d % 8 == 0 and d <= 3072:
+        ops.gemv(a2, lp.w_gate, M, 4 * d, d, b_kstrided=False, ldw=d, bias=lp.b_gate, out_bf16=gate)
+    else:
+        ops.gemm(a2, lp.w_gate, M, 4 * d, d, ldb=d, bias=lp.b_gate, out_bf16=gate)
+    ops.geglu_fwd(h, gate)
+    return gate
+
+
 def stack_forward(P: StackParams, x: torch.Tensor, mask: torch.Tensor, save: bool,
                   want_f32: bool = False, want_bf16: bool = True, drops: Optional[DropSites] = None):
     """x (B,T,d) fp32 residual stream, mask (B,T) fp32 0/1.  Returns (hf16 [M,d] bf16 | None,
@@ -185,12 +202,13 @@ def stack_forward(P: StackParams, x: torch.Tensor, mask: torch.Tensor, save: boo
         pre = torch.empty(M, 4 * d, dtype=BF16, device=dev) if save else None
         h = torch.empty(M, 4 * d, dtype=BF16, device=dev)
         ops.gemm(a2, lp.w_fc, M, 4 * d, d, b_kstrided=True, bias=lp.b_fc, act=1, pre_out=pre, out_bf16=h)
+        gate = _geglu_gate(lp, a2, h, M, d)
         x2 = torch.empty(M, d, dtype=F32, device=dev)
         ops.gemm(h, lp.w_pr, M, d, 4 * d, b_kstrided=True, bias=lp.b_pr, resid=x1, out_f32=x2,
                  drop=dr.resid_mlp[li] if dr else None)
         if save:
             ctx.layers.append(LayerCtx(x=x, a1=a1, mean1=mean1, rstd1=rstd1, qkv=qkv, o=o, lse=lse, x1=x1, a2=a2,
-                                       mean2=mean2, rstd2=rstd2, pre=pre, h=h))
+                                       mean2=mean2, rstd2=rstd2, pre=pre, h=h, gate=gate))
         x = x2
     hf16 = torch.empty(M, d, dtype=BF16, device=dev) if want_bf16 else None
     hf32 = torch.empty(M, d, dtype=F32, device=dev) if want_f32 else None
@@ -227,12 +245,24 @@ def stack_backward(P: StackParams, ctx: StackCtx, dhf: torch.Tensor,
         lp, c = P.layers[i], ctx.layers[i]
         # ---- MLP: x2 = x1 + gelu(a2 Wfc + bfc) Wpr + bpr ------------------------------------------
         d_pre = torch.empty(M, 4 * d, dtype=BF16, device=dev)
-        ops.gemm(g16, lp.w_pr, M, 4 * d, d, ldb=d, act=2, act_in=c.pre, out_bf16=d_pre)       # dgrad * gelu'
+        d_gate = None
+        if c.gate is None:
+            ops.gemm(g16, lp.w_pr, M, 4 * d, d, ldb=d, act=2, act_in=c.pre, out_bf16=d_pre)   # dgrad * gelu'
+        else:                                                                                 # GEGLU: h = gelu(pre) * gate
+            ops.gemm(g16, lp.w_pr, M, 4 * d, d, ldb=d, out_bf16=d_pre)                        # d_h
+            d_pre, d_gate = ops.geglu_bwd(d_pre, c.pre, c.gate)
         SideStream.fork(lambda c=c, lp=lp, g16=g16: (_wgrad(c.h, g16, 4 * d, d, M, lp.g_w_pr),
                                                     ops.colsum_bf16(g16, M, d, lp.g_b_pr)), g16)
         # gradients wrt the LayerNorm outputs leave their dgrad GEMMs as bf16, as autocast leaves them in the reference
         # (the gradient of a bf16 addmm input is bf16): half the bytes out of the GEMM and into the LayerNorm backward
-        d_a2 = _dgrad_to_ln(d_pre, lp.w_fc, M, d, 4 * d, 4 * d)
+        if d_gate is None:
+            d_a2 = _dgrad_to_ln(d_pre, lp.w_fc, M, d, 4 * d, 4 * d)
+        else:                     # d_a2 = d_pre @ Wfc^T + d_gate @ Wgate  (fp32: the second product accumulates)
+            d_a2 = torch.empty(M, d, dtype=F32, device=dev)
+            ops.gemm(d_pre, lp.w_fc, M, d, 4 * d, ldb=4 * d, out_f32=d_a2)
+            ops.gemm(d_gate, lp.w_gate, M, d, 4 * d, b_kstrided=True, ldb=d, out_f32=d_a2, accumulate=True)
+            SideStream.fork(lambda c=c, lp=lp, d_gate=d_gate: (_wgrad(d_gate, c.a2, 4 * d, d, M, lp.g_w_gate),
+                                                              ops.colsum_bf16(d_gate, M, 4 * d, lp.g_b_gate)), d_gate)
         SideStream.fork(lambda c=c, lp=lp, d_pre=d_pre: (_wgrad(c.a2, d_pre, d, 4 * d, M, lp.g_w_fc),
                                                         ops.colsum_bf16(d_pre, M, 4 * d, lp.g_b_fc)), d_pre)
         g1 = torch.empty(M, d, dtype=F32, device=dev)
@@ -308,6 +338,7 @@ class KVDecoder:
             ops.layernorm_fwd(x1, lp.ln2_w, lp.ln2_b, y16=a2, eps=P.eps)
             h = torch.empty(1, 4 * d, dtype=BF16, device=dev)
             ops.gemv(a2, lp.w_fc, 1, 4 * d, d, b_kstrided=True, bias=lp.b_fc, act=1, out_bf16=h)
+            _geglu_gate(lp, a2, h, 1, d)
             x2 = torch.empty(1, d, dtype=F32, device=dev)
             ops.gemv(h, lp.w_pr, 1, d, 4 * d, b_kstrided=True, bias=lp.b_pr, resid=x1, out_f32=x2)
             x = x2
@@ -386,6 +417,7 @@ class KVDecoder:
             ops.layernorm_fwd(x1, lp.ln2_w, lp.ln2_b, y16=a2, eps=P.eps)
             h = torch.empty(n, 4 * d, dtype=BF16, device=dev)
             ops.gemm(a2, lp.w_fc, n, 4 * d, d, b_kstrided=True, bias=lp.b_fc, act=1, out_bf16=h)
+            _geglu_gate(lp, a2, h, n, d)
             x2 = torch.empty(n, d, dtype=F32, device=dev)
             ops.gemm(h, lp.w_pr, n, d, 4 * d, b_kstrided=True, bias=lp.b_pr, resid=x1, out_f32=x2)
             x = x2

@@ -271,6 +271,22 @@ def colsum_bf16(x, M, N, out, accumulate=True, ld=None):
               _stream())
 
 
+def geglu_fwd(h, gate):
+    """h (= gelu(pre), bf16, contiguous) *= gate in place (neko_geglu_fwd; MLP.forward trajectory_gpt2.py:275-276)."""
+    _chk(h, BF16, "h"); _chk(gate, BF16, "gate")
+    assert h.is_contiguous() and gate.is_contiguous() and h.numel() == gate.numel()
+    _lib.call("neko_geglu_fwd", _p(h), _p(gate), h.numel(), _stream())
+
+
+def geglu_bwd(dh, pre, gate):
+    """(d_pre, d_gate) = (dh * gate * gelu'(pre), dh * gelu(pre)), bf16 (neko_geglu_bwd)."""
+    _chk(dh, BF16, "dh"); _chk(pre, BF16, "pre"); _chk(gate, BF16, "gate")
+    assert dh.is_contiguous() and pre.is_contiguous() and gate.is_contiguous()
+    d_pre, d_gate = torch.empty_like(dh), torch.empty_like(dh)
+    _lib.call("neko_geglu_bwd", _p(dh), _p(pre), _p(gate), _p(d_pre), _p(d_gate), dh.numel(), _stream())
+    return d_pre, d_gate
+
+
 def sqnorm_f32(g, out_accum):
     _chk(g, torch.float32, "g"); _chk(out_accum, torch.float64, "out_accum")
     _lib.call("neko_sqnorm_f32", _p(g), g.numel(), _p(out_accum), _stream())

@@ -293,8 +293,12 @@ class GatoPolicy(nn.Module):
         if pretrained_lm is not None:
             raise NotImplementedError("pretrained_lm / LoRA (gato_policy.py:79-95) needs downloaded weights; "
                                       "out of scope of the HIP hot path (SURVEY.md 2.1 #16)")
-        if activation_fn == "geglu":
-            raise NotImplementedError("activation_fn='geglu' is not on the HIP path (no BASELINE config uses it)")
+        gate = False
+        if activation_fn == "geglu":                                        # :97-100: gated MLP around the erf GELU
+            gate, activation_fn = True, "gelu"
+        if activation_fn != "gelu":
+            raise NotImplementedError(f"activation_fn={activation_fn!r}: the HIP MLP epilogues implement ACT2FN['gelu'] "
+                                      "(erf form) and 'geglu' (arguments.py:55 default 'gelu')")
         if embed_dim % heads != 0:
             raise AssertionError("embed_dim must be divisible by heads")   # trajectory_gpt2.py:126
         if embed_dim // heads not in (32, 64, 128) or embed_dim % 8:
@@ -305,7 +309,7 @@ class GatoPolicy(nn.Module):
             raise ValueError("num_channels must be divisible by num_groups")
         config = GPT2Config(vocab_size=1, n_embd=embed_dim, n_head=heads, n_layer=layers, resid_pdrop=dropout,
                             attn_pdrop=dropout, n_positions=context_len, n_inner=embed_dim * 4,
-                            activation_function=activation_fn, n_ctx=context_len, flash=flash, gate=False)
+                            activation_function=activation_fn, n_ctx=context_len, flash=flash, gate=gate)
         self.transformer = GPT2Model(config)                                         # :115
         self.embed_token = nn.Embedding(self.vocab_size, embed_dim)                  # :117
         self.embed_dim = embed_dim

@@ -75,9 +75,8 @@ class MLP(nn.Module):
         nx = config.n_embd
         self.c_fc = Conv1D(n_state, nx)
         self.c_proj = Conv1D(nx, n_state)
-        if config.gate:
-            raise NotImplementedError("activation_fn='geglu' (trajectory_gpt2.py:267-276) is not on the HIP path; "
-                                      "no BASELINE config uses it")
+        # activation_fn='geglu' (gato_policy.py:97-100): h = act(c_fc x) * gated_layer(x), trajectory_gpt2.py:267-276
+        self.gated_layer = nn.Linear(nx, n_state) if config.gate else None
         self.dropout = nn.Dropout(config.resid_pdrop)
 
 
@@ -154,9 +153,10 @@ class GPT2Model(nn.Module):
     # ---- flat-parameter plumbing ---------------------------------------------------------------
     def layer_param_names(self, i: int) -> List[str]:
         p = f"h.{i}."
+        gate = ("mlp.gated_layer.weight", "mlp.gated_layer.bias") if self.config.gate else ()
         return [p + s for s in ("ln_1.weight", "ln_1.bias", "attn.c_attn.weight", "attn.c_attn.bias",
                                 "attn.c_proj.weight", "attn.c_proj.bias", "ln_2.weight", "ln_2.bias",
-                                "mlp.c_fc.weight", "mlp.c_fc.bias", "mlp.c_proj.weight", "mlp.c_proj.bias")]
+                                "mlp.c_fc.weight", "mlp.c_fc.bias", "mlp.c_proj.weight", "mlp.c_proj.bias") + gate]
 
     def param_groups_for_flat(self, prefix: str = "") -> "OrderedDict[str, list]":
         named = dict(self.named_parameters())
@@ -188,7 +188,12 @@ class GPT2Model(nn.Module):
         layers = []
         for i in range(self.config.n_layer):
             p = f"{pre}h.{i}."
+            gate = {}
+            if self.config.gate:        # nn.Linear layout (out, in) = (4d, d): a k-contiguous B operand
+                gate = dict(w_gate=f.sview(p + "mlp.gated_layer.weight"), b_gate=f.view(p + "mlp.gated_layer.bias"),
+                            g_w_gate=f.gview(p + "mlp.gated_layer.weight"), g_b_gate=f.gview(p + "mlp.gated_layer.bias"))
             layers.append(engine.LayerParams(
+                **gate,
                 ln1_w=f.view(p + "ln_1.weight"), ln1_b=f.view(p + "ln_1.bias"),
                 ln2_w=f.view(p + "ln_2.weight"), ln2_b=f.view(p + "ln_2.bias"),
                 b_qkv=f.view(p + "attn.c_attn.bias"), b_o=f.view(p + "attn.c_proj.bias"),

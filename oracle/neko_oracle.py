@@ -544,4 +544,9 @@ def init_state_dict(cfg: OracleConfig, seed: int = 0, resid_mid_channels: int = 
     sd["image_embedding.patch_pos_encoding.height_pos_embedding.weight"] = n(cfg.position_vocab_size, d)
     sd["image_embedding.patch_pos_encoding.width_pos_embedding.weight"] = n(cfg.position_vocab_size, d)
     sd["pos_embed_observation.weight"] = n(cfg.context_len, d)
+    if cfg.activation_fn == "geglu":    # MLP.gated_layer = nn.Linear(d, 4d) inside the transformer (trajectory_gpt2.py:267-268):
+        for i in range(L):              # N(0, 0.02) weight; drawn LAST so the other tensors match the ungated model's
+            p = f"transformer.h.{i}."   # (a small non-zero bias so that parity checks see it; the reference zeroes it)
+            sd[p + "mlp.gated_layer.weight"] = n(4 * d, d, std=0.02)
+            sd[p + "mlp.gated_layer.bias"] = n(4 * d, std=0.02)
     return sd

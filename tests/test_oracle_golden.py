@@ -128,3 +128,38 @@ def test_g7_training_trace(golden):
             torch.testing.assert_close(sd[k][2 * d:], v[2 * d:], rtol=2e-3, atol=2e-5)
             continue
         torch.testing.assert_close(sd[k], v, rtol=2e-3, atol=2e-5)
+
+
+def test_g8_geglu_oracle_matches_reference(golden):
+    """activation_fn='geglu' (gato_policy.py:97-100, MLP.forward trajectory_gpt2.py:273-278): hidden states, policy
+    logits / loss / gradients and a 30-step training trace of the gated model, captured from the imported reference."""
+    f = golden("g8_geglu")
+    cfg = _cfg(f["cfg"])
+    assert cfg.activation_fn == "geglu"
+    sd = O.init_state_dict(cfg, f["seed"])
+    h = f["hidden"]
+    out, hs = O.transformer_forward(sd, cfg, h["x"], h["mask"], return_all=True)
+    for i in range(cfg.layers):
+        torch.testing.assert_close(hs[i], h["hidden_states"][i], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(out, h["last_hidden_state"], rtol=1e-5, atol=2e-5)
+    p = f["policy"]
+    loss, logits, grads = O.loss_and_grads(sd, cfg, p["batch"])
+    torch.testing.assert_close(logits[:, ::p["row_stride"], :], p["logits_rows"], rtol=1e-4, atol=1e-4)
+    assert abs(float(loss) - p["loss"]) < 1e-5 * max(1.0, abs(p["loss"]))
+    for k, n in p["grad_norms"].items():
+        if n is None:
+            assert grads[k] is None, k
+        else:
+            assert abs(float(grads[k].norm()) - n) <= 1e-4 * max(n, 1e-6) + 1e-7, k
+    assert any("gated_layer" in k for k in p["grad_norms"])
+    for k, gref in p["small_grads"].items():
+        torch.testing.assert_close(grads[k], gref, rtol=1e-4, atol=1e-5)
+    t = f["train"]
+    cfg3 = _cfg(t["cfg"])
+    sd3 = O.init_state_dict(cfg3, t["seed"])
+    st = O.AdamWState(lr=t["lr"])
+    for step in range(t["total_steps"]):
+        lr = t["lr"] * O.lr_ratio(step, t["warmup"], t["total_steps"], t["lr"], t["init_lr"], t["min_lr"])
+        loss, gn = O.train_step(sd3, cfg3, st, t["batches"][step % len(t["batches"])], lr, 1.0)
+        assert abs(loss - t["trace"]["loss"][step]) < 1e-4 * abs(t["trace"]["loss"][step]), (step, loss)
+        assert abs(gn - t["trace"]["grad_norm"][step]) < 1e-3 * t["trace"]["grad_norm"][step], (step, gn)
