@@ -44,6 +44,8 @@ def make_batch(workload: str, B: int, seed: int, device):
         return S.SyntheticTextTask(1023, V_TEXT, seed=seed, device=device).sample_batch(B)
     if workload == "c2":   # halfcheetah-shaped, T = 240
         return S.SyntheticControlTask(17, 6, 10, seed=seed, device=device).sample_batch(B)
+    if workload == "c5-mix":   # text 1024 / Atari 494 / caption 289 / halfcheetah 240 in one batch (ragged lengths)
+        return S.ragged_mix_batch(B, seed, device)
     raise ValueError(workload)
 
 
@@ -98,7 +100,9 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=32, help="sequences per GPU per step")
-    ap.add_argument("--workload", default="m-mix", choices=["m-mix", "m-text", "c2"])
+    ap.add_argument("--workload", default="m-mix", choices=["m-mix", "m-text", "c2", "c5-mix"])
+    ap.add_argument("--ragged-groups", type=int, default=0,
+                    help="> 0: length-bucketed layout (GatoPolicy.ragged_groups) instead of padding to the longest example")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dropout", type=float, default=0.1, help="attention/residual dropout (reference default 0.1)")
     ap.add_argument("--no-optimizer", action="store_true", help="time fwd+bwd(+all-reduce) only")
@@ -134,6 +138,7 @@ def main():
     model = GatoPolicy(dev, D, L, H, dropout, resid_mid_channels=128, context_len=T, text_tokenizer=V_TEXT)
     if dropout == 0:
         model.transformer.drop.p = 0.0
+    model.ragged_groups = args.ragged_groups
     model.train()
     opt = NekoAdamW(model, lr=1e-4, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.1)
     dp = None
@@ -221,6 +226,12 @@ def main():
             tj = json.load(open(tp))
             if tj.get("shape_MNK") == dom["shape"]:
                 traffic, traffic_src = tj["traffic_bytes_per_launch"], "profiles/r01_lmhead_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, calibrated)"
+        # positions that are not padding (the metric counts every position of the padded (B, T) batch; for the
+        # ragged c5-mix workload the useful rate is the one over real tokens) and rows that went through the stack
+        from neko_amd.policy.gato_policy import K_PAD, build_layout
+        lay = build_layout(batches[0], True, T, False, ragged_groups=args.ragged_groups)
+        real_tokens = int((lay.desc[:, 0] != K_PAD).sum())
+        rows = int(lay.desc.shape[0])
         out = {
             "metric": "multimodal tokens/sec (fwd+bwd+optimizer, whole job)", "value": value, "unit": "tokens/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps,
@@ -236,6 +247,8 @@ def main():
             "step_mfma_frac": value / world * fpt / (MFMA_PEAK_TFLOPS * 1e12),
             "flops_per_token_fwd_bwd": fpt,
             "lm_head_rows_fraction": lm_frac,
+            "ragged_groups": args.ragged_groups, "rows_per_step_per_gpu": rows, "real_tokens_per_step_per_gpu": real_tokens,
+            "real_tokens_per_sec": world * real_tokens * args.steps / el,
             "roofline": {"bound": "mfma", "achieved": dom["tflops"], "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": dom["tflops"] / MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch",
                          "traffic_source": traffic_src, "kernel": dom["kernel"],

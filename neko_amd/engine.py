@@ -73,11 +73,22 @@ class LayerCtx:
 
 
 @dataclass
+class Segment:
+    """Rows [row0, row0 + B*T) of the token stream hold B sequences of T positions each.  A plain (B, T) batch is one
+    segment; a length-bucketed ragged batch (GatoPolicy.ragged_groups) is several with different T: every kernel
+    except attention works on the concatenated rows, attention runs once per segment."""
+    row0: int
+    B: int
+    T: int
+    kbias: torch.Tensor = None      # additive key bias (B, T) fp32
+    kstart: torch.Tensor = None     # first real key per sequence (B,) int32
+
+
+@dataclass
 class StackCtx:
     B: int = 0
     T: int = 0
-    kbias: torch.Tensor = None
-    kstart: torch.Tensor = None
+    segs: List[Segment] = field(default_factory=list)
     layers: List[LayerCtx] = field(default_factory=list)
     drops: Optional[DropSites] = None
     xf: torch.Tensor = None          # residual stream entering ln_f
@@ -169,18 +180,67 @@ def _geglu_gate(lp: LayerParams, a2: torch.Tensor, h: torch.Tensor, M: int, d: i
     return gate
 
 
+def _seg_drop(drop: Optional[ops.Drop], si: int) -> Optional[ops.Drop]:
+    """Attention-probability dropout indexes its mask by (sequence, head, query, key) LOCAL to a launch: every
+    segment after the first gets its own key so that masks do not repeat across segments."""
+    if drop is None or si == 0:
+        return drop
+    d2 = ops.Drop(0.0, ops.mix32(drop.key + 0x632BE5AB * si))
+    d2.thr, d2.scale = drop.thr, drop.scale
+    return d2
+
+
+def _attn_fwd_segs(qkv, segs: List[Segment], H: int, hd: int, drop):
+    if len(segs) == 1 and segs[0].B * segs[0].T == qkv.shape[0]:
+        sg = segs[0]
+        return ops.attn_fwd(qkv, sg.kbias, sg.kstart, sg.B, sg.T, H, hd, drop=drop)
+    o = torch.empty(qkv.shape[0], H * hd, dtype=BF16, device=qkv.device)
+    o[segs[-1].row0 + segs[-1].B * segs[-1].T:].zero_()      # alignment rows behind the last segment (all padding)
+    lses = []
+    for si, sg in enumerate(segs):
+        r0, r1 = sg.row0, sg.row0 + sg.B * sg.T
+        _, lse = ops.attn_fwd(qkv[r0:r1], sg.kbias, sg.kstart, sg.B, sg.T, H, hd, drop=_seg_drop(drop, si), out=o[r0:r1])
+        lses.append(lse)
+    return o, lses
+
+
+def _attn_bwd_segs(qkv, o, d_o, lse, segs: List[Segment], H: int, hd: int, drop):
+    if len(segs) == 1 and segs[0].B * segs[0].T == qkv.shape[0]:
+        sg = segs[0]
+        return ops.attn_bwd(qkv, o, d_o, sg.kbias, sg.kstart, lse, sg.B, sg.T, H, hd, drop=drop)
+    dqkv = torch.empty_like(qkv)
+    dqkv[segs[-1].row0 + segs[-1].B * segs[-1].T:].zero_()
+    for si, sg in enumerate(segs):
+        r0, r1 = sg.row0, sg.row0 + sg.B * sg.T
+        ops.attn_bwd(qkv[r0:r1], o[r0:r1], d_o[r0:r1], sg.kbias, sg.kstart, lse[si], sg.B, sg.T, H, hd,
+                     drop=_seg_drop(drop, si), dqkv=dqkv[r0:r1])
+    return dqkv
+
+
 def stack_forward(P: StackParams, x: torch.Tensor, mask: torch.Tensor, save: bool,
-                  want_f32: bool = False, want_bf16: bool = True, drops: Optional[DropSites] = None):
+                  want_f32: bool = False, want_bf16: bool = True, drops: Optional[DropSites] = None,
+                  segments: Optional[List[tuple]] = None):
     """x (B,T,d) fp32 residual stream, mask (B,T) fp32 0/1.  Returns (hf16 [M,d] bf16 | None,
-    hf32 [M,d] fp32 | None, ctx | None) where hf = ln_f(h_L)."""
+    hf32 [M,d] fp32 | None, ctx | None) where hf = ln_f(h_L).
+    segments: optional [(row0, B_k, T_k)] covering the rows of x in order, possibly followed by all-padding rows
+    (ragged groups: x is then (1, M, d))."""
     B, T, d = x.shape
     M = B * T
     H = P.heads
     hd = d // H
     dev = x.device
     x = x.reshape(M, d).contiguous()
-    kbias, kstart = ops.mask_bias(mask.to(F32))
-    ctx = StackCtx(B=B, T=T, kbias=kbias, kstart=kstart, drops=drops) if save else None
+    mask = mask.to(F32).reshape(-1)
+    segs = []
+    for (r0, Bk, Tk) in (segments or [(0, B, T)]):
+        kb, ks = ops.mask_bias(mask[r0:r0 + Bk * Tk].view(Bk, Tk))
+        segs.append(Segment(row0=r0, B=Bk, T=Tk, kbias=kb, kstart=ks))
+    # segments tile the rows in order; rows behind the last one (ragged layouts round the row count up to a multiple
+    # of 64 so that the weight-gradient contractions stay on the fast GEMM path) are padding that no attention call
+    # touches: their attention output / gradient rows are zero
+    assert segs[0].row0 == 0 and all(a.row0 + a.B * a.T == b.row0 for a, b in zip(segs, segs[1:])) \
+        and segs[-1].row0 + segs[-1].B * segs[-1].T <= M, "segments must tile the rows of x"
+    ctx = StackCtx(B=B, T=T, segs=segs, drops=drops) if save else None
     dr = drops
     if dr is not None and dr.embd is not None:
         x = ops.dropout_f32(x, dr.embd)                       # embedding dropout (:707)
@@ -191,7 +251,7 @@ def stack_forward(P: StackParams, x: torch.Tensor, mask: torch.Tensor, save: boo
         ops.layernorm_fwd(x, lp.ln1_w, lp.ln1_b, y16=a1, mean=mean1, rstd=rstd1, eps=P.eps)
         qkv = torch.empty(M, 3 * d, dtype=BF16, device=dev)
         ops.gemm(a1, lp.w_qkv, M, 3 * d, d, b_kstrided=True, bias=lp.b_qkv, out_bf16=qkv)
-        o, lse = ops.attn_fwd(qkv, kbias, kstart, B, T, H, hd, drop=dr.attn[li] if dr else None)
+        o, lse = _attn_fwd_segs(qkv, segs, H, hd, dr.attn[li] if dr else None)
         x1 = torch.empty(M, d, dtype=F32, device=dev)
         ops.gemm(o, lp.w_o, M, d, d, b_kstrided=True, bias=lp.b_o, resid=x, out_f32=x1,
                  drop=dr.resid_attn[li] if dr else None)
@@ -274,7 +334,7 @@ def stack_backward(P: StackParams, ctx: StackCtx, dhf: torch.Tensor,
         ops.gemm(g1_16, lp.w_o, M, d, d, ldb=d, out_bf16=d_o)
         SideStream.fork(lambda c=c, lp=lp, g1_16=g1_16: (_wgrad(c.o, g1_16, d, d, M, lp.g_w_o),
                                                           ops.colsum_bf16(g1_16, M, d, lp.g_b_o)), g1_16)
-        dqkv = ops.attn_bwd(c.qkv, c.o, d_o, ctx.kbias, ctx.kstart, c.lse, B, T, H, hd, drop=dr.attn[i] if dr else None)
+        dqkv = _attn_bwd_segs(c.qkv, c.o, d_o, c.lse, ctx.segs, H, hd, dr.attn[i] if dr else None)
         d_a1 = _dgrad_to_ln(dqkv, lp.w_qkv, M, d, 3 * d, 3 * d)
         SideStream.fork(lambda c=c, lp=lp, dqkv=dqkv: (_wgrad(c.a1, dqkv, d, 3 * d, M, lp.g_w_qkv),
                                                       ops.colsum_bf16(dqkv, M, 3 * d, lp.g_b_qkv)), dqkv)

@@ -166,20 +166,30 @@ def attn_set_path(mode: int) -> int:
     return int(_lib.load().neko_attn_set_path(int(mode)))
 
 
-def attn_fwd(qkv, kbias, kstart, B, T, H, hd, drop=None):
+def attn_fwd(qkv, kbias, kstart, B, T, H, hd, drop=None, out=None):
+    """out (optional): a contiguous [B*T, H*hd] bf16 row range to write into (ragged groups share one buffer)."""
     _chk(qkv, BF16, "qkv")
-    out = torch.empty(B * T, H * hd, dtype=BF16, device=qkv.device)
+    assert qkv.is_contiguous() and qkv.shape[0] == B * T
+    if out is None:
+        out = torch.empty(B * T, H * hd, dtype=BF16, device=qkv.device)
+    else:
+        _chk(out, BF16, "out"); assert out.is_contiguous() and out.shape == (B * T, H * hd)
     lse = torch.empty(B, H, T, dtype=torch.float32, device=qkv.device)
     _lib.call("neko_attn_fwd", _p(qkv), _p(kbias), _p(kstart), _p(out), _p(lse), B, T, H, hd, *_drop(drop), _stream())
     return out, lse
 
 
-def attn_bwd(qkv, out, dout, kbias, kstart, lse, B, T, H, hd, drop=None):
+def attn_bwd(qkv, out, dout, kbias, kstart, lse, B, T, H, hd, drop=None, dqkv=None):
+    """dqkv (optional): a contiguous [B*T, 3*H*hd] bf16 row range to write into."""
     _chk(dout, BF16, "dout")
     dev = qkv.device
+    assert qkv.is_contiguous() and out.is_contiguous() and dout.is_contiguous() and qkv.shape[0] == B * T
     D = torch.empty(B * H * T, dtype=torch.float32, device=dev)
     qflags = torch.empty(B * ((T + 63) // 64), dtype=torch.int32, device=dev)
-    dqkv = torch.empty(B * T, 3 * H * hd, dtype=BF16, device=dev)
+    if dqkv is None:
+        dqkv = torch.empty(B * T, 3 * H * hd, dtype=BF16, device=dev)
+    else:
+        _chk(dqkv, BF16, "dqkv"); assert dqkv.is_contiguous() and dqkv.shape == (B * T, 3 * H * hd)
     _lib.call("neko_attn_bwd", _p(qkv), _p(out), _p(dout), _p(kbias), _p(kstart), _p(lse), _p(D), _p(qflags),
               _p(dqkv), B, T, H, hd, *_drop(drop), _stream())
     return dqkv

@@ -47,6 +47,8 @@ class PackedBatch:
         self.images: List[torch.Tensor] = []        # per image example: (n_ts,3,H,W)
         self.given_img_emb: List[torch.Tensor] = [] # per example with precomputed embeddings: (n, P, d)
         self.img_order: List[tuple] = []            # ('img', idx) | ('emb', idx) in example order
+        self.segments: Optional[List[tuple]] = None # ragged groups: [(row0, B_k, T_k)] tiling the rows of desc
+        self.order: Optional[List[int]] = None      # ragged groups: example index of every sequence, in row order
 
 
 def _as_2d_ids(t):
@@ -59,8 +61,50 @@ def _as_2d_ids(t):
     return t
 
 
+def plan_ragged_groups(lengths: Sequence[int], max_groups: int) -> List[List[int]]:
+    """Partition examples into at most `max_groups` length buckets minimising the padded token count
+    sum_k B_k * T_k (T_k = longest member of bucket k).  Exact dynamic programme over the distinct lengths in
+    descending order (an optimal bucket is a contiguous range of the sorted lengths).  Returns lists of example
+    indices, longest bucket first; within a bucket the input order is kept."""
+    uniq = sorted(set(int(l) for l in lengths), reverse=True)
+    if len(uniq) > 64:                                   # many distinct lengths (free text): quantise to 16 first
+        uniq = sorted(set((u + 15) // 16 * 16 for u in uniq), reverse=True)
+        key = lambda l: (int(l) + 15) // 16 * 16
+    else:
+        key = int
+    cnt = {u: 0 for u in uniq}
+    for l in lengths:
+        cnt[key(l)] += 1
+    n, G = len(uniq), max(1, min(int(max_groups), len(uniq)))
+    pre = [0]
+    for u in uniq:
+        pre.append(pre[-1] + cnt[u])
+    INF = float("inf")
+    dp = [[INF] * (n + 1) for _ in range(G + 1)]
+    arg = [[0] * (n + 1) for _ in range(G + 1)]
+    dp[0][0] = 0
+    for g in range(1, G + 1):
+        for j in range(1, n + 1):
+            for i in range(g - 1, j):
+                if dp[g - 1][i] < INF:
+                    c = dp[g - 1][i] + uniq[i] * (pre[j] - pre[i])
+                    if c < dp[g][j]:
+                        dp[g][j], arg[g][j] = c, i
+    g = min(range(1, G + 1), key=lambda k: (dp[k][n], k))
+    cuts, j = [], n
+    while g > 0:
+        i = arg[g][j]
+        cuts.append((i, j))
+        j, g = i, g - 1
+    groups = []
+    for i, j in reversed(cuts):
+        members = set(uniq[i:j])
+        groups.append([e for e, l in enumerate(lengths) if key(l) in members])
+    return groups
+
+
 def build_layout(inputs: Sequence[dict], use_pos_encoding: bool, context_len: int, pad_seq: bool,
-                 n_patches_of=None) -> PackedBatch:
+                 n_patches_of=None, ragged_groups: int = 0) -> PackedBatch:
     """Turn the list of example dicts into one descriptor table + source lists (host only, numpy).
     Per timestep order [image patches | text | continuous obs | discrete obs | SEP | continuous act |
     discrete act] (gato_policy.py:355); positions 0..n_obs-1 get a local position (:380-385);
@@ -153,6 +197,30 @@ def build_layout(inputs: Sequence[dict], use_pos_encoding: bool, context_len: in
         if use_pos_encoding:
             d[:, :n_obs, 2] = np.arange(n_obs, dtype=np.int64)[None, :]
         per_ex.append(d.reshape(n_ts * tp, 4))
+    if ragged_groups > 0:
+        # length-bucketed layout: sequences are left-padded to the longest member of THEIR bucket,
+        # buckets are concatenated along the row axis.  Descriptor rows carry absolute source offsets, so moving an
+        # example's rows does not touch the value buffers.
+        groups = plan_ragged_groups([e.shape[0] for e in per_ex], ragged_groups)
+        blocks, segs, order, row0 = [], [], [], 0
+        for members in groups:
+            Tk = max(per_ex[i].shape[0] for i in members)
+            blk = np.zeros((len(members), Tk, 4), dtype=np.int32)
+            blk[:, :, 2] = -1
+            for r, i in enumerate(members):
+                blk[r, Tk - per_ex[i].shape[0]:] = per_ex[i]
+            blocks.append(blk.reshape(-1, 4))
+            segs.append((row0, len(members), Tk))
+            order += members
+            row0 += len(members) * Tk
+        tail = (-row0) % 64          # row count up to a multiple of 64: the weight gradients contract over the rows,
+        if tail:                     # and the fast GEMM path wants that contraction in whole 64-row steps
+            blk = np.zeros((tail, 4), dtype=np.int32)
+            blk[:, 2] = -1
+            blocks.append(blk)
+        pb.B, pb.T, pb.desc = 1, row0 + tail, np.concatenate(blocks, axis=0)
+        pb.segments, pb.order = segs, order
+        return pb
     T = max(e.shape[0] for e in per_ex)
     T_out = context_len if (pad_seq and context_len > T) else T
     B = len(per_ex)
@@ -174,8 +242,10 @@ class _PolicyCoreFn(torch.autograd.Function):
         f.ensure_shadow()
         B, T, d = x.shape
         sp = policy.transformer._stack_params()
+        rg = policy._ragged
+        segments = rg[1] if (rg is not None and tokens is not None and tokens.data_ptr() == rg[0]) else None
         hf16, _, sctx = engine.stack_forward(sp, x.detach().to(torch.float32), pmask, save=need,
-                                             drops=policy.transformer.make_drops())
+                                             drops=policy.transformer.make_drops(), segments=segments)
         hp = policy._head_params()
         logits = engine.lm_head_logits(hp, hf16).view(B, T, hp.V) if return_logits else x.new_zeros(0)
         loss = x.new_zeros(())
@@ -190,6 +260,9 @@ class _PolicyCoreFn(torch.autograd.Function):
                                                                    chunk_rows=policy.lm_head_chunk_rows)
                 ctx.sel_idx, ctx.sel_n = idx, n
             else:
+                if segments is not None:        # the shifted selection above crosses sequence boundaries in the bucketed
+                    sel = torch.zeros_like(sel)  # layout; it is only reached when the batch has no loss position at all
+                    count = sel.sum()
                 loss, dlogits = engine.lm_head_loss(hp, hf16, target, sel, count, want_grad=need,
                                                     chunk_rows=policy.lm_head_chunk_rows)
         ctx.policy, ctx.sctx, ctx.hf16, ctx.dlogits, ctx.shape = policy, sctx, hf16 if need else None, dlogits, (B, T, d)
@@ -329,6 +402,11 @@ class GatoPolicy(nn.Module):
 
         self.lm_head_chunk_rows = 4096
         self.lm_head_selected_rows = True   # LM head only at loss positions when they are known on the host
+        #: > 0: training forwards (compute_loss=True, return_logits=False) pack the batch into at most this many length
+        #: buckets instead of left-padding every example to the longest one (misc/todo.md:11);
+        #: 0 = the reference's layout.  Same loss and gradients, fewer padded positions through the stack.
+        self.ragged_groups = int(os.environ.get("NEKO_RAGGED_GROUPS", "0"))
+        self._ragged = None
         self._loss_rows = None
         self._dp = None
         self._hp = None
@@ -406,10 +484,17 @@ class GatoPolicy(nn.Module):
     def tokenize_input_dicts(self, inputs: list):
         """Returns (token_embeddings (B,T,d) f32, tokens (B,T) i64, token_target_masks (B,T) f32,
         token_masks (B,T) f32) like the reference; the work is one descriptor upload + HIP kernels."""
+        return self._tokenize(inputs, 0)[:4]
+
+    def _tokenize(self, inputs: list, ragged_groups: int):
+        """tokenize_input_dicts, optionally in the length-bucketed layout: returns (x, tokens, target masks, pad masks,
+        segments) -- (B,T,.) tensors and None, or (1,M,.) tensors and [(row0, B_k, T_k)]."""
         dev = self._dev()
         if dev.type != "cuda":
             raise RuntimeError("neko_amd.GatoPolicy computes on the GPU only (no CPU fallback)")
-        pb = build_layout(inputs, self.use_pos_encoding, self.context_len, self.pad_seq)
+        if self.pad_seq:
+            ragged_groups = 0           # pad_seq asks for context_len-wide rows (gato_policy.py:423-431)
+        pb = build_layout(inputs, self.use_pos_encoding, self.context_len, self.pad_seq, ragged_groups=ragged_groups)
         desc = self.image_embedding._upload(torch.from_numpy(pb.desc), dev)
         cont = self._gather_values(pb.cont, torch.float32, dev)
         disc = self._gather_values(pb.disc, torch.int32, dev)
@@ -428,19 +513,26 @@ class GatoPolicy(nn.Module):
         B, T, d = pb.B, pb.T, self.embed_dim
         # loss positions are known on the host (gato_policy.py:176-183): row (b,t) is selected when position t is
         # real and position t+1 is a target.  Uploaded once; lets the LM head run on the selected rows only.
-        dk = pb.desc.reshape(B, T, 4)
-        selm = np.zeros((B, T), dtype=bool)
-        selm[:, :-1] = (dk[:, :-1, 0] != K_PAD) & (dk[:, 1:, 3] != 0)
-        sel_idx = np.flatnonzero(selm.reshape(-1)).astype(np.int32)
+        selm = np.zeros(B * T, dtype=bool)
+        for (r0, Bk, Tk) in (pb.segments or [(0, B, T)]):
+            dk = pb.desc[r0:r0 + Bk * Tk].reshape(Bk, Tk, 4)
+            sk = np.zeros((Bk, Tk), dtype=bool)
+            sk[:, :-1] = (dk[:, :-1, 0] != K_PAD) & (dk[:, 1:, 3] != 0)
+            selm[r0:r0 + Bk * Tk] = sk.reshape(-1)
+        sel_idx = np.flatnonzero(selm).astype(np.int32)
         idx_dev = self.image_embedding._upload(torch.from_numpy(sel_idx if sel_idx.size else np.zeros(1, np.int32)), dev)
         self._loss_rows = (tokens.data_ptr(), B * T, idx_dev, int(sel_idx.size))
-        return x.view(B, T, d), tokens.view(B, T), tmask.view(B, T), pmask.view(B, T)
+        self._ragged = (tokens.data_ptr(), pb.segments, pb.order) if pb.segments is not None else None
+        return x.view(B, T, d), tokens.view(B, T), tmask.view(B, T), pmask.view(B, T), pb.segments
 
     # ---- forward (gato_policy.py:156-192) -------------------------------------------------------------
     def forward(self, inputs: Optional[list] = None, compute_loss=False, **kwargs):
         return_logits = kwargs.pop("return_logits", True)
         if inputs is not None:
-            token_embeddings, tokens, token_target_masks, token_masks = self.tokenize_input_dicts(inputs)
+            # length-bucketed layout: only when no (B, T, V) logits tensor has to be handed back (the training call,
+            # trainer.py:178 discards them) -- the loss and every gradient are those of the padded layout
+            ragged = self.ragged_groups if (compute_loss and not return_logits and len(inputs) > 1) else 0
+            token_embeddings, tokens, token_target_masks, token_masks, _ = self._tokenize(inputs, ragged)
         else:
             assert ("token_embeddings" in kwargs and "tokens" in kwargs and "token_target_masks" in kwargs
                     and "token_masks" in kwargs), "if inputs is None, must provide embeddings, tokens, and masks"

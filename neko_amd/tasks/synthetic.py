@@ -99,3 +99,18 @@ def metric_mix_batch(batch_size: int, seed: int, device, text_vocab: int = 50257
     for i in range(batch_size):
         out += (cap, ctl, atr)[i % 3].sample_batch(1)
     return out
+
+
+def ragged_mix_batch(batch_size: int, seed: int, device, text_vocab: int = 50257) -> List[dict]:
+    """A C5-like length mix (BASELINE configs[4]: text + MuJoCo + Atari + caption in one batch): full-context text
+    (1023 ids + SEP = 1024), Atari 13 x (36 + 1 + 1) = 494, caption 256 patches + 32 ids + SEP = 289, halfcheetah
+    10 x (17 + 1 + 6) = 240.  The reference left-pads all of them to 1024 (gato_policy.py:408-416): half of the
+    positions are padding, which is what GatoPolicy.ragged_groups removes."""
+    txt = SyntheticTextTask(1023, text_vocab, seed=seed, device=device)
+    atr = SyntheticAtariTask(13, 96, 96, seed=seed + 1, device=device)
+    cap = SyntheticCaptionTask(32, text_vocab, seed=seed + 2, device=device)
+    ctl = SyntheticControlTask(17, 6, 10, seed=seed + 3, device=device)
+    out = []
+    for i in range(batch_size):
+        out += (txt, atr, cap, ctl)[i % 4].sample_batch(1)
+    return out

@@ -39,6 +39,9 @@ class TrainingArgs:
     layers: int = 8
     heads: int = 24
     activation_fn: str = "gelu"
+    # not in the reference: > 0 packs every training batch into at most this many length buckets instead of
+    # left-padding all examples to the longest one (same loss and gradients, fewer padded positions)
+    ragged_groups: int = 0
 
     # training
     text_prop: float = 0.0

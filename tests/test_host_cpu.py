@@ -134,3 +134,67 @@ def test_synthetic_tasks_emit_reference_dict_format():
     assert pb.T == 1024
     lens = (pb.desc.reshape(6, 1024, 4)[:, :, 0] != 0).sum(1)
     assert lens.tolist() == [1024, 1008, 988, 1024, 1008, 988]
+
+
+# ---- length-bucketed ("ragged groups") layout: SURVEY 8(f) rank 3 ------------------------------------------------
+def _brute_force_padded_tokens(lengths, G):
+    """Minimum of sum_k B_k * max_k over all partitions of the DESCENDING-sorted lengths into <= G contiguous runs."""
+    import itertools
+    ls = sorted(lengths, reverse=True)
+    n, best = len(ls), None
+    for g in range(1, min(G, n) + 1):
+        for cuts in itertools.combinations(range(1, n), g - 1):
+            b = (0,) + cuts + (n,)
+            c = sum(ls[b[i]] * (b[i + 1] - b[i]) for i in range(g))
+            best = c if best is None else min(best, c)
+    return best
+
+
+def test_plan_ragged_groups_is_optimal_and_a_partition():
+    import random
+    from neko_amd.policy.gato_policy import plan_ragged_groups
+    rnd = random.Random(3)
+    for trial in range(60):
+        n = rnd.randint(1, 9)
+        lengths = [rnd.choice([24, 38, 240, 494, 1000, 1024, rnd.randint(1, 1024)]) for _ in range(n)]
+        G = rnd.randint(1, 4)
+        groups = plan_ragged_groups(lengths, G)
+        assert 1 <= len(groups) <= G
+        flat = sorted(i for g in groups for i in g)
+        assert flat == list(range(n))
+        cost = sum(len(g) * max(lengths[i] for i in g) for g in groups)
+        assert cost == _brute_force_padded_tokens(lengths, G), (lengths, G, groups)
+        assert all(g == sorted(g) for g in groups)              # input order kept inside a bucket
+    assert plan_ragged_groups([5, 5, 5], 4) == [[0, 1, 2]]       # one distinct length -> one bucket
+    many = [rnd.randint(1, 1024) for _ in range(300)]            # > 64 distinct lengths: quantised, still a partition
+    gs = plan_ragged_groups(many, 6)
+    assert sorted(i for g in gs for i in g) == list(range(300)) and len(gs) <= 6
+
+
+def test_build_layout_ragged_rows_are_the_padded_rows_regrouped():
+    import numpy as np
+    import torch
+    from neko_amd.policy.gato_policy import K_PAD, build_layout
+    g = torch.Generator().manual_seed(0)
+    inputs = [{"text": torch.randint(0, 100, (n,), generator=g).tolist()} for n in (30, 7, 30, 12)]
+    inputs.insert(2, {"continuous_obs": torch.randn(3, 4, generator=g), "continuous_actions": torch.rand(3, 2, generator=g)})
+    inputs.append({"images": torch.zeros(2, 3, 16, 32), "discrete_actions": torch.zeros(2, 1, dtype=torch.int32)})
+    flat = build_layout(inputs, True, 64, False)
+    rag = build_layout(inputs, True, 64, False, ragged_groups=3)
+    assert flat.segments is None and rag.B == 1 and rag.T == rag.desc.shape[0]
+    used = sum(b * t for _, b, t in rag.segments)
+    assert used <= rag.T < used + 64 and rag.T % 64 == 0 and rag.T < flat.B * flat.T
+    assert (rag.desc[used:, 0] == K_PAD).all()                                   # alignment rows: padding only
+    assert rag.segments[0][0] == 0 and all(a[0] + a[1] * a[2] == b[0] for a, b in zip(rag.segments, rag.segments[1:]))
+    assert sorted(rag.order) == list(range(len(inputs)))
+    fd = flat.desc.reshape(flat.B, flat.T, 4)
+    seq = 0
+    for (r0, Bk, Tk) in rag.segments:
+        blk = rag.desc[r0:r0 + Bk * Tk].reshape(Bk, Tk, 4)
+        for r in range(Bk):
+            ex = rag.order[seq]; seq += 1
+            real = fd[ex][fd[ex][:, 0] != K_PAD]
+            assert np.array_equal(blk[r][Tk - len(real):], real)             # same descriptors, same source offsets
+            assert (blk[r][:Tk - len(real), 0] == K_PAD).all()
+    # value buffers are untouched by the regrouping
+    assert len(rag.cont) == len(flat.cont) and all(torch.equal(a, b) for a, b in zip(rag.cont, flat.cont))

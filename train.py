@@ -70,6 +70,8 @@ def main(args: TrainingArgs):
         raise SystemExit(f"unsupported configuration on the HIP path: {e}")
     if args.dropout == 0:
         model.transformer.drop.p = 0.0     # the reference keeps embd_pdrop = 0.1 regardless of --dropout
+    if args.ragged_groups > 0:
+        model.ragged_groups = args.ragged_groups
     if args.init_checkpoint is not None:
         model.load_state_dict(torch.load(args.init_checkpoint, map_location=dev))
     params = sum(p.numel() for p in model.parameters() if p.requires_grad)
