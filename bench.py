@@ -101,12 +101,19 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=32, help="sequences per GPU per step")
     ap.add_argument("--workload", default="m-mix", choices=["m-mix", "m-text", "c2", "c5-mix"])
+    ap.add_argument("--model", default="768d", choices=["768d", "gato-1.2b"],
+                    help="768d = the metric's 768d x 6L x 24H (hd=32); gato-1.2b = BASELINE configs[4], 2048d x 24L x 16H "
+                         "(hd=128, streaming attention kernels) -- a side measurement, not the metric's config")
     ap.add_argument("--ragged-groups", type=int, default=0,
                     help="> 0: length-bucketed layout (GatoPolicy.ragged_groups) instead of padding to the longest example")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dropout", type=float, default=0.1, help="attention/residual dropout (reference default 0.1)")
     ap.add_argument("--no-optimizer", action="store_true", help="time fwd+bwd(+all-reduce) only")
     args = ap.parse_args()
+    global D, L, H
+    if args.model == "gato-1.2b":
+        D, L, H = 2048, 24, 16
+        args.no_cpu_baseline = True        # the fp32 CPU oracle of a 1.4 B-parameter model does not fit the time budget
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -216,7 +223,7 @@ def main():
         tokens = world * B * Tlen * args.steps
         value = tokens / el
         lm_frac = (model._loss_rows[3] / float(B * Tlen)) if (model._loss_rows and model.lm_head_selected_rows) else 1.0
-        fpt = 3 * flops_per_token_fwd(t=Tlen, lm_rows_frac=lm_frac)
+        fpt = 3 * flops_per_token_fwd(d=D, layers=L, t=Tlen, lm_rows_frac=lm_frac)
         dom = time_dominant_kernel(model, min(4096, B * Tlen))
         # HBM bytes per launch of that kernel: PMC counters cannot be collected from inside the timed process, so the
         # number is the committed rocprofv3 --pmc measurement of the same call (tools/pmc_lmhead.sh), null if absent
@@ -237,7 +244,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
             "data": "synthetic",
-            "config": {"workload": f"{args.workload}: 768d x 6L x 24H (hd=32), V=52305, T={Tlen}, "
+            "config": {"workload": f"{args.workload}: {D}d x {L}L x {H}H (hd={D // H}), V=52305, T={Tlen}, "
                                    f"{B} sequences/GPU/step, dropout {dropout}, "
                                    f"{'fwd+bwd only' if args.no_optimizer else 'fwd+bwd+clip+AdamW'}",
                        "global_batch": world * B, "seq_len": Tlen, "parallelism": f"dp{world}"},
