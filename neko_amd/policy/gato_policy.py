@@ -703,6 +703,7 @@ class GatoPolicy(nn.Module):
         """gato_policy.py:556-614.  ``task.action_type`` is compared by class name (gymnasium is not a dependency)."""
         kind = getattr(task.action_type, "__name__", str(task.action_type))
         action_tokens = task.action_tokens
+        kind = "Discrete" if kind in ("Discrete", "DiscreteSpace") else kind     # neko_amd.tasks.control_task stand-in
         if kind == "Discrete":
             action_str = "discrete"
             assert action_tokens == 1, "only support 1 discrete action token"

@@ -70,6 +70,12 @@ class TrainingArgs:
     eval_mode: str = "deterministic"
     promptless_eval: bool = False
 
+    # control-task prompting (arguments.py:126-129)
+    prompt_ep_proportion: float = 0.25
+    prompt_len_proportion: float = 0.5
+    unique_prompt_episodes: bool = False
+    top_k: Optional[int] = None
+
     # datasets (synthetic stand-ins: names select the synthetic generator shapes)
     control_datasets: List[str] = field(default_factory=list)
     text_datasets: List[str] = field(default_factory=list)

@@ -70,7 +70,13 @@ class Trainer:
         with torch.no_grad():
             for task in self.tasks:
                 if hasattr(task, "evaluate"):
-                    for k, v in task.evaluate(self.model).items():
+                    if hasattr(task, "sample_batch_configurable"):       # rollouts (trainer.py:100-107 arguments)
+                        res = task.evaluate(self.model, n_iterations=self.args.eval_episodes,
+                                            deterministic=self.args.eval_mode == "deterministic",
+                                            promptless_eval=bool(self.args.promptless_eval))
+                    else:
+                        res = task.evaluate(self.model)
+                    for k, v in res.items():
                         logs[f"evaluation/{task.name}/{k}"] = v
         logs["time/total"] = time.time() - self.start_time
         logs["time/evaluation"] = time.time() - eval_start
@@ -105,7 +111,11 @@ class Trainer:
             if n <= 0:
                 continue
             tasks = [t for t in self.tasks if getattr(t, "kind", "control") == kind]
-            if kind == "control":
+            if kind == "control" and tasks and all(hasattr(t, "sample_batch_configurable") for t in tasks):
+                # episode-store tasks (neko_amd.tasks.control_task.ControlTask): the reference's prompted sampling
+                from ..tasks.control_task import sample_control_batch
+                dicts.extend(sample_control_batch(tasks, n, a.prompt_ep_proportion, self.model.device, a.sequence_length))
+            elif kind == "control":
                 # round-robin over control tasks, like trainer.py:223-228 without prompting (synthetic data)
                 for j in range(n):
                     dicts.extend(tasks[j % len(tasks)].sample_batch(1))

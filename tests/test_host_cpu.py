@@ -198,3 +198,71 @@ def test_build_layout_ragged_rows_are_the_padded_rows_regrouped():
             assert (blk[r][:Tk - len(real), 0] == K_PAD).all()
     # value buffers are untouched by the regrouping
     assert len(rag.cont) == len(flat.cont) and all(torch.equal(a, b) for a, b in zip(rag.cont, flat.cont))
+
+
+# ---- control-task sampler against the reference's own outputs (fixture G9) --------------------
+def _g9_task(rec_case, episodes, patch_size, seed, share, top_k):
+    import types
+    import numpy as np
+    from neko_amd.tasks.control_task import BoxSpace, ControlTask, DiscreteSpace, Episode, EpisodeStore
+    c = rec_case
+    osp = DiscreteSpace(c["obs"][1]) if c["obs"][0] == "disc" else BoxSpace(c["obs"][1])
+    asp = BoxSpace((c["act"][1],)) if c["act"][0] == "box" else DiscreteSpace(c["act"][1])
+    env = types.SimpleNamespace(observation_space=osp, action_space=asp)
+    store = EpisodeStore([Episode(e["observations"], e["actions"], e["rewards"], id=i) for i, e in enumerate(episodes)],
+                         seed=seed)
+    return ControlTask(c["name"], env, store, c["max_tokens"], types.SimpleNamespace(patch_size=patch_size),
+                       training_prompt_len_proportion=0.5, share_prompt_episodes=share, top_k_prompting=top_k)
+
+
+def _same_dicts(got, ref):
+    import torch
+    assert len(got) == len(ref)
+    for g, r in zip(got, ref):
+        assert list(g.keys()) == list(r.keys())
+        for k in r:
+            want = r[k].to(torch.float32) if k == "images" else r[k]
+            assert g[k].dtype == want.dtype and g[k].shape == want.shape, (k, g[k].dtype, g[k].shape, want.shape)
+            assert torch.equal(g[k], want), k
+
+
+def test_g9_control_sampler_matches_reference_bit_exactly(golden):
+    """ControlTask.sample_batch / sample_batch_configurable (control_task.py:178-325) incl. the image transform
+    (:345-389): same episodes, same numpy seeds -> identical windows, prompts, dtypes and shapes; where the
+    reference raises (np.random.randint on a too-short episode) the restatement raises too."""
+    import numpy as np
+    f = golden("g9_sampler")
+    n_calls = 0
+    for ci, rec in enumerate(f["cases"]):
+        seed = rec["seed"]
+        task = _g9_task(rec["case"], rec["episodes"], rec["patch_size"], 77 + seed, seed % 2 == 0, 3 if seed == 1 else None)
+        assert task.tokens_per_timestep == rec["tokens_per_timestep"]
+        assert task.obs_str == rec["obs_str"] and task.action_str == rec["action_str"]
+        assert (task.top_ids is None) == (rec["top_ids"] is None)
+        if rec["top_ids"] is not None:
+            assert np.array_equal(task.top_ids, rec["top_ids"])
+        np.random.seed(500 + 10 * (ci // 2) + seed)
+        for call in rec["calls"]:
+            n_calls += 1
+            if call["kind"] == "sample_batch":
+                if "raises" in call:
+                    with pytest.raises(ValueError):
+                        task.sample_batch(call["vanilla"], dict(call["prompted"]), "cpu", max_tokens=rec["case"]["max_tokens"])
+                else:
+                    _same_dicts(task.sample_batch(call["vanilla"], dict(call["prompted"]), "cpu",
+                                                  max_tokens=rec["case"]["max_tokens"]), call["out"])
+            else:
+                _same_dicts(task.sample_batch_configurable(1, "cpu", [1.0], ["end"], max_tokens=rec["case"]["max_tokens"],
+                                                           share_prompt_episodes=True, ep_ids=task.top_ids), call["out"])
+    assert n_calls == 50
+
+
+def test_g9_trainer_control_batch_matches_reference(golden):
+    """Trainer.sample_control_batch (trainer.py:211-250): task multiset, prompted share, end / uniform split."""
+    import numpy as np
+    from neko_amd.tasks.control_task import sample_control_batch
+    t = golden("g9_sampler")["trainer"]
+    tasks = [_g9_task(r["case"], r["episodes"], r["patch_size"], 77, True, None) for r in t["tasks"]]
+    np.random.seed(t["np_seed"])
+    for bs, ref in zip(t["batch_sizes"], t["batches"]):
+        _same_dicts(sample_control_batch(tasks, bs, t["prompt_ep_proportion"], "cpu", t["sequence_length"]), ref)
