@@ -86,12 +86,56 @@ class EpisodeStore:
     def __iter__(self):
         return iter(self.episodes)
 
+    # ---- on-disk form (stands in for Minari's main_data.hdf5: h5py is not in this image) --------------------------
+    # one .npz: observations / actions / rewards concatenated over episodes along axis 0 + episode_lengths
+    def save_npz(self, path: str) -> None:
+        np.savez_compressed(path,
+                            observations=np.concatenate([e.observations for e in self.episodes], axis=0),
+                            actions=np.concatenate([e.actions for e in self.episodes], axis=0),
+                            rewards=np.concatenate([e.rewards for e in self.episodes], axis=0),
+                            episode_lengths=np.array([e.total_timesteps for e in self.episodes], dtype=np.int64))
+
+    @classmethod
+    def from_npz(cls, path: str, seed: Optional[int] = None) -> "EpisodeStore":
+        z = np.load(path)
+        ends = np.cumsum(z["episode_lengths"])
+        eps = [Episode(z["observations"][e - n:e], z["actions"][e - n:e], z["rewards"][e - n:e], id=i)
+               for i, (n, e) in enumerate(zip(z["episode_lengths"], ends))]
+        return cls(eps, seed=seed)
+
+    def spaces(self):
+        """(observation_space, action_space) inferred from the stored arrays: float -> Box, integer -> Discrete."""
+        o, a = self.episodes[0].observations, self.episodes[0].actions
+        if np.issubdtype(o.dtype, np.integer) and o.ndim == 1:
+            osp = DiscreteSpace(int(max(e.observations.max() for e in self.episodes)) + 1)
+        else:
+            osp = BoxSpace(o.shape[1:], dtype=o.dtype)
+        if np.issubdtype(a.dtype, np.integer):
+            asp = DiscreteSpace(int(max(e.actions.max() for e in self.episodes)) + 1)
+        else:
+            asp = BoxSpace(a.shape[1:] if a.ndim > 1 else (1,), dtype=a.dtype)
+        return osp, asp
+
+
     def sample_episodes(self, n_episodes: int, episode_indices=None) -> List[Episode]:
         """control_task.py:327-340."""
         if episode_indices is None:
             episode_indices = self.episode_indices
         idx = self.generator.choice(episode_indices, size=n_episodes, replace=False)
         return [self.episodes[int(i)] for i in idx]
+
+
+class SpacesOnlyEnv:
+    """An ``env`` for training without rollouts: only the two spaces (evaluate() needs a real reset/step)."""
+    can_rollout = False
+
+    def __init__(self, observation_space, action_space):
+        self.observation_space, self.action_space = observation_space, action_space
+
+    def reset(self):
+        raise RuntimeError("SpacesOnlyEnv has no simulator: pass a real environment to evaluate")
+
+    step = reset
 
 
 class ControlImageTransform:

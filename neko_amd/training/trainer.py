@@ -69,7 +69,7 @@ class Trainer:
         self.model.eval()
         with torch.no_grad():
             for task in self.tasks:
-                if hasattr(task, "evaluate"):
+                if hasattr(task, "evaluate") and getattr(getattr(task, "env", None), "can_rollout", True):
                     if hasattr(task, "sample_batch_configurable"):       # rollouts (trainer.py:100-107 arguments)
                         res = task.evaluate(self.model, n_iterations=self.args.eval_episodes,
                                             deterministic=self.args.eval_mode == "deterministic",

@@ -110,3 +110,39 @@ def test_trainer_samples_prompted_control_batches_and_trains():
     _, loss = m(batch, compute_loss=True, return_logits=False)
     loss.backward()
     assert torch.isfinite(loss)
+
+
+def test_text_task_evaluate_on_the_hip_policy():
+    from neko_amd.tasks.text_task import TokenTextTask
+    rng = np.random.default_rng(3)
+    corpus = {"train": [rng.integers(0, 128, 70).tolist() for _ in range(6)],
+              "test": [rng.integers(0, 128, n).tolist() for n in (20, 31, 9)]}     # (a 33-token document would leave a 1-token chunk: the reference raises on it)
+    task = TokenTextTask(corpus, 32)
+    m = _policy(40)
+    np.random.seed(5)
+    with torch.no_grad():
+        res = task.evaluate(m, num_examples_to_test=3)
+    assert np.isfinite(res["loss"]) and abs(res["perplexity"] - float(np.exp(res["loss"]))) < 1e-3 * res["perplexity"]
+    batch = task.sample_batch(4)
+    m.train()
+    _, loss = m(batch, compute_loss=True, return_logits=False)
+    assert torch.isfinite(loss)
+
+
+def test_train_py_on_an_episode_file(tmp_path, monkeypatch):
+    """train.py end to end on real-format data: an EpisodeStore .npz sampled with the reference's prompted sampler,
+    mixed with synthetic text, bucketed layout, 4 optimisation steps."""
+    import train
+    from neko_amd.tasks.control_task import Episode, EpisodeStore
+    from neko_amd.training.arguments import parse_args
+    rng = np.random.default_rng(4)
+    eps = [Episode(rng.standard_normal((T, 6)).astype(np.float32), (rng.random((T, 2)) * 2 - 1).astype(np.float32),
+                   rng.standard_normal(T), id=i) for i, T in enumerate((50, 70, 35, 90))]
+    path = str(tmp_path / "toy.npz")
+    EpisodeStore(eps).save_npz(path)
+    monkeypatch.chdir(tmp_path)
+    a = parse_args(["--embed_dim", "64", "--layers", "2", "--heads", "2", "--sequence_length", "90", "--batch_size", "6",
+                    "--training_steps", "4", "--log_eval_freq", "4", "--warmup_steps", "2", "--text_prop", "0.34",
+                    "--text_vocab_size", "128", "--control_datasets", path, "--prompt_ep_proportion", "0.5",
+                    "--ragged_groups", "2", "--resid_mid_channels", "128"])
+    train.main(a)

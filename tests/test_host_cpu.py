@@ -266,3 +266,65 @@ def test_g9_trainer_control_batch_matches_reference(golden):
     np.random.seed(t["np_seed"])
     for bs, ref in zip(t["batch_sizes"], t["batches"]):
         _same_dicts(sample_control_batch(tasks, bs, t["prompt_ep_proportion"], "cpu", t["sequence_length"]), ref)
+
+
+def test_g10_text_task_matches_reference(golden):
+    """TokenTextTask.sample_batch / evaluate (text_task.py:32-114) against the reference driven by a real HF fast
+    tokenizer + datasets.Dataset: same documents, same numpy seeds -> the same chunks in the same order and the same
+    evaluation loss / perplexity (predict_text replaced by the fixture's deterministic stand-in on both sides)."""
+    from neko_amd.tasks.text_task import TokenTextTask
+    f = golden("g10_text_task")
+    V = f["vocab"]
+
+    class FakePolicy:
+        device = "cpu"
+
+        def __init__(self):
+            self.module, self.text_tokenizer = self, None
+
+        def predict_text(self, batch_dict, max_length=20, deterministic=True):
+            prefix = batch_dict["text"]
+            g = torch.Generator().manual_seed(1000 * len(prefix) + int(prefix[-1]) + max_length)
+            logits = torch.randn(max_length, V, generator=g)
+            return logits, list(torch.argmax(logits, dim=-1))
+
+    for case in f["cases"]:
+        task = TokenTextTask(f["corpus"], case["context_length"])
+        np.random.seed(case["np_seed"])
+        for call in case["calls"]:
+            got = task.sample_batch(call["batch_size"], is_test=call["is_test"])
+            assert got == call["out"]
+            assert all(0 < len(d["text"]) <= case["context_length"] for d in got)
+        np.random.seed(case["eval_seed"])
+        for ev in case["eval"]:
+            m = task.evaluate(FakePolicy(), num_examples_to_test=ev["n"])
+            assert abs(m["loss"] - ev["metrics"]["loss"]) < 1e-6 * ev["metrics"]["loss"]
+            assert abs(m["perplexity"] - ev["metrics"]["perplexity"]) < 1e-5 * ev["metrics"]["perplexity"]
+
+
+def test_episode_store_npz_roundtrip_and_spaces(tmp_path):
+    from neko_amd.tasks.control_task import ControlTask, Episode, EpisodeStore, SpacesOnlyEnv
+    rng = np.random.default_rng(0)
+    eps = [Episode(rng.standard_normal((T, 4)).astype(np.float32), rng.integers(0, 3, (T,)), rng.standard_normal(T), id=i)
+           for i, T in enumerate((5, 9, 2))]
+    p = str(tmp_path / "eps.npz")
+    EpisodeStore(eps).save_npz(p)
+    st = EpisodeStore.from_npz(p, seed=1)
+    assert st.total_episodes == 3
+    for a, b in zip(st.episodes, eps):
+        assert np.array_equal(a.observations, b.observations) and np.array_equal(a.actions, b.actions)
+        assert a.total_timesteps == b.total_timesteps
+    osp, asp = st.spaces()
+    assert type(osp).__name__ == "BoxSpace" and osp.shape == (4,) and type(asp).__name__ == "DiscreteSpace" and asp.n == 3
+    task = ControlTask("toy", SpacesOnlyEnv(osp, asp), st, 64, argparse_ns(patch_size=16))
+    assert task.obs_str == "continuous_obs" and task.action_str == "discrete_actions" and task.tokens_per_timestep == 6
+    np.random.seed(0)
+    b = task.sample_batch(2, {"end": 1}, "cpu", max_tokens=24)
+    assert len(b) == 3 and all(d["discrete_actions"].dtype == torch.int32 and d["discrete_actions"].shape[1] == 1 for d in b)
+    with pytest.raises(RuntimeError):
+        task.evaluate(argparse_ns(context_len=64, device="cpu"))      # no simulator behind SpacesOnlyEnv
+
+
+def argparse_ns(**kw):
+    import types
+    return types.SimpleNamespace(**kw)

@@ -44,6 +44,16 @@ def main(args: TrainingArgs):
     tasks = []
     names = args.control_datasets or ["halfcheetah"]
     for i, n in enumerate(names):
+        if n.endswith(".npz"):
+            # real episodes: an EpisodeStore file (neko_amd.tasks.control_task; stands in for a Minari dataset) sampled
+            # with the reference's window / prompt sampler (control_task.py:178-325).  All control tasks must then be
+            # episode files: the Trainer switches to Trainer.sample_control_batch semantics (trainer.py:211-250)
+            from neko_amd.tasks.control_task import ControlTask, EpisodeStore, SpacesOnlyEnv
+            store = EpisodeStore.from_npz(n, seed=seed + i)
+            tasks.append(ControlTask(os.path.basename(n)[:-4], SpacesOnlyEnv(*store.spaces()), store, ts, args,
+                                     training_prompt_len_proportion=args.prompt_len_proportion,
+                                     share_prompt_episodes=not args.unique_prompt_episodes, top_k_prompting=args.top_k))
+            continue
         if "breakout" in n.lower() or "atari" in n.lower():
             tasks.append(S.SyntheticAtariTask(max(1, ts // 38), 96, 96, name=n, seed=seed + i, device=dev))
         elif "hopper" in n.lower():
