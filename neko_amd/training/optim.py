@@ -55,10 +55,17 @@ class NekoAdamW(torch.optim.Optimizer):
         f = self.flat
         act = self._active_groups()
         self.gnorm_sq.zero_()
+        # adjacent ranges are one launch (the flat gradient is contiguous; alignment gaps are zero)
+        runs = []
         for g, on in zip(self.groups, act):
             if on or self.flags_reduce is not None:    # DP: another rank may have used the range (zeros add 0)
                 a, b = f.group_ranges[g]
-                ops.sqnorm_f32(f.grad[a:b], self.gnorm_sq)
+                if runs and runs[-1][1] == a:
+                    runs[-1][1] = b
+                else:
+                    runs.append([a, b])
+        for a, b in runs:
+            ops.sqnorm_f32(f.grad[a:b], self.gnorm_sq)
         self._pending_clip = float(max_norm)
         gs = 1.0 if self.grad_scale is None else self.grad_scale
         return self.gnorm_sq.sqrt().to(torch.float32) * gs
