@@ -54,6 +54,9 @@ class FlatParams:
                 v.copy_(p.data)
                 p.data = v
         self._shadow_version = None
+        #: names whose gradient slice may hold data since the last whole-buffer memset (zero_grad): only those need a
+        #: memset when a backward finds their ``.grad`` detached -- the step used to zero the 498 MB buffer twice
+        self._dirty: set = set(self.offsets)
 
     # ---- views ---------------------------------------------------------------------------------
     def view(self, name: str, padded_rows: Optional[int] = None) -> torch.Tensor:
@@ -94,6 +97,7 @@ class FlatParams:
     # ---- gradients -------------------------------------------------------------------------------
     def zero_grad(self) -> None:
         self.grad.zero_()
+        self._dirty.clear()
 
     def attach_grads(self, names: Sequence[str]) -> None:
         """Point ``param.grad`` of the named parameters at their slice of the flat gradient."""
@@ -108,7 +112,8 @@ class FlatParams:
     def prepare_backward(self, names: Sequence[str]) -> None:
         """Kernels accumulate (+=) into the flat gradient.  Parameters whose ``.grad`` is None
         (fresh step, or zero_grad(set_to_none=True) from a torch optimiser) must start from zero."""
-        fresh = sorted(self.offsets[n][0] for n in names if self.param_of[n].grad is None)
+        fresh = sorted(self.offsets[n][0] for n in names if self.param_of[n].grad is None and n in self._dirty)
+        self._dirty.update(names)
         if not fresh:
             return
         ends = {o: o + _round_up(n, ALIGN) for (o, n, _) in self.offsets.values()}
