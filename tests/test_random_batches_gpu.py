@@ -1,0 +1,90 @@
+"""Randomised end-to-end parity: random multimodal batches (every example kind of SURVEY.md 8(a) row A0, random
+lengths, with / without images) x {gelu, geglu} x {reference layout, 2 or 4 length buckets} through the HIP policy
+against the CPU oracle -- loss 2e-3 relative, global gradient norm 2e-2, per-parameter gradient norms 6e-2 (bf16
+MFMA operands, fp32 accumulation), token / mask tensors bit-exact."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import neko_oracle as O  # noqa: E402
+
+DEV = "cuda"
+VOCAB = 96
+
+
+def random_batch(g, n):
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))
+    r = lambda *s: torch.rand(*s, generator=g)
+    out = []
+    for _ in range(n):
+        kind = ri(0, 5)
+        if kind == 0:
+            out.append({"text": torch.randint(0, VOCAB, (ri(2, 60),), generator=g).tolist()})
+        elif kind == 1:
+            ts, no, na = ri(1, 6), ri(1, 7), ri(1, 3)
+            out.append({"continuous_obs": torch.randn(ts, no, generator=g) * 3, "continuous_actions": r(ts, na) * 2 - 1})
+        elif kind == 2:
+            ts, no = ri(1, 5), ri(1, 4)
+            out.append({"discrete_obs": torch.randint(0, 9, (ts, no), generator=g).to(torch.int32),
+                        "discrete_actions": torch.randint(0, 5, (ts, 1), generator=g).to(torch.int32)})
+        elif kind == 3:
+            ts, h, w = ri(1, 2), 16 * ri(1, 2), 16 * ri(1, 3)
+            out.append({"images": torch.floor(r(ts, 3, h, w) * 256),
+                        "discrete_actions": torch.randint(0, 4, (ts, 1), generator=g).to(torch.int32)})
+        elif kind == 4:
+            out.append({"images": torch.floor(r(1, 3, 32, 32) * 256).to(torch.uint8),
+                        "text": torch.randint(0, VOCAB, (ri(1, 12),), generator=g).tolist()})
+        else:
+            ts, no, na = ri(1, 4), ri(1, 5), ri(1, 2)
+            out.append({"discrete_obs": torch.randint(0, 9, (ts, no), generator=g).to(torch.int32),
+                        "continuous_actions": r(ts, na) * 2 - 1})
+    return out
+
+
+def to_dev(batch):
+    return [{k: (v.to(DEV) if torch.is_tensor(v) and v.dtype != torch.uint8 else v) for k, v in ex.items()}
+            for ex in batch]
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_batch_matches_oracle(seed):
+    from neko_amd.policy.gato_policy import GatoPolicy
+    g = torch.Generator().manual_seed(7000 + seed)
+    act = "geglu" if seed % 3 == 2 else "gelu"
+    groups = (0, 2, 4)[seed % 3] if seed < 6 else (4, 0, 2)[seed % 3]
+    d, H = ((64, 2), (128, 4))[seed % 2]
+    cfg = O.OracleConfig(embed_dim=d, layers=2, heads=H, text_tokens=VOCAB, context_len=128, activation_fn=act)
+    batch = random_batch(g, 2 + seed % 5)
+    sd = O.init_state_dict(cfg, 300 + seed)
+    m = GatoPolicy(DEV, d, 2, H, 0.0, activation_fn=act, resid_mid_channels=128, context_len=128, text_tokenizer=VOCAB)
+    m.transformer.drop.p = 0.0
+    m.load_state_dict(sd, strict=True)
+    m.eval()                                   # deterministic patch positions on both sides
+    m.ragged_groups = groups
+    e_ref, t_ref, tg_ref, pm_ref = O.tokenize_input_dicts(sd, cfg, batch)
+    with torch.no_grad():
+        _, t, tg, pm = m.tokenize_input_dicts(to_dev(batch))
+    assert torch.equal(t.cpu(), t_ref) and torch.equal(tg.cpu(), tg_ref) and torch.equal(pm.cpu(), pm_ref)
+    loss_ref, _, grads_ref = O.loss_and_grads(sd, cfg, batch)
+    if not bool((tg_ref[:, 1:] * pm_ref[:, :-1]).sum() > 0):
+        pytest.skip("batch without a loss position")
+    _, loss = m(to_dev(batch), compute_loss=True, return_logits=False)
+    assert (m._ragged is not None) == (groups > 0 and len(batch) > 1)
+    loss.backward()
+    assert abs(float(loss) - float(loss_ref)) < 2e-3 * abs(float(loss_ref)), (float(loss), float(loss_ref))
+    named = dict(m.named_parameters())
+    sq = sq_ref = 0.0
+    for k, gr in grads_ref.items():
+        if gr is None:
+            assert named[k].grad is None, k
+            continue
+        assert named[k].grad is not None, k
+        n_ref, n = float(gr.norm()), float(named[k].grad.float().norm())
+        sq, sq_ref = sq + n * n, sq_ref + n_ref * n_ref
+        if k.endswith("c_attn.bias") or n_ref < 1e-6:
+            continue
+        assert abs(n - n_ref) < 6e-2 * n_ref + 1e-6, (k, n, n_ref)
+    assert abs(math.sqrt(sq) - math.sqrt(sq_ref)) < 2e-2 * math.sqrt(sq_ref)
