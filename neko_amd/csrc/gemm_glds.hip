@@ -726,6 +726,20 @@ int launch(const GemmArgs& a, hipStream_t s) {
     else if (A_KC && B_KC && a.N >= 2048 && big_out) cfg = 3;       // K = 768 dgrad through the MLP, LM-head logits
     else if (A_KC && B_KC && big_out && a.N % 128 == 0) cfg = 2;    // K = 768, N = 768 dgrad (attention out)
     else cfg = klen >= 16384 ? 1 : 0;
+    // The rules above were measured at B*T = 32768 rows.  At the README batch sizes (32 x 240 = 7680 rows, 8 x 240,
+    // 32 x 494) the same shapes are ONE partial round of 256x256 tiles and most CUs idle; tools/gemm_tile_sweep.sh
+    // (profiles/r01_step19_gemm_tile_sweep.txt): with fewer than half a round, 128x128 (wide outputs: up to 2.1x) or
+    // 256x128 (N = 768) wins; between half and 1.5 rounds wide outputs prefer 256x128 (+9..16 %), while N = 768 dgrads
+    // prefer ONE 8-wave 256x256 block per CU over two 4-wave 256x128 blocks on some CUs (+16..19 %).
+    const long t3n = (long)((a.M + 255) / 256) * ((a.N + 255) / 256) * (a.splitk > 1 ? a.splitk : 1);
+    const bool wide = a.N >= 2048;
+    if (A_KC) {
+      if (cfg == 3 && t3n < 128) cfg = wide ? 0 : 2;
+      else if (cfg == 3 && t3n < 384 && wide) cfg = 2;
+      else if (cfg == 2 && t3n >= 128 && t3n < 384 && !wide) cfg = 3;
+    } else if (cfg == 3 && t3n < 128) {
+      cfg = 0;                                  // weight gradients with a handful of output tiles
+    }
   }
   switch (cfg) {
     case 1: return launch_cfg<A_KC, B_KC, C128s4>(a, s);

@@ -52,7 +52,15 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--safe", type=int, default=0)
     ap.add_argument("--sk", type=int, default=0, help="force this split-K factor on the split-K shapes")
+    ap.add_argument("--rows", type=int, default=0, help="B*T rows instead of 32768 (README batch sizes: 7680 = 32 x 240)")
     args = ap.parse_args()
+    if args.rows:
+        shapes = []
+        for (name, m, n, k, aks, bks, ex) in SHAPES:
+            if name.startswith(("lm", "rl", "sq")):
+                continue
+            shapes.append((name, args.rows if m == M else m, n, args.rows if k == M else k, aks, bks, ex))
+        SHAPES[:] = shapes
     dev = "cuda"
     g = torch.Generator(device=dev).manual_seed(0)
     tot_us = 0.0
