@@ -722,7 +722,7 @@ int launch(const GemmArgs& a, hipStream_t s) {
     if (a.splitk > 1 || (klen >= 4096 && (long)a.M * a.N >= (long)256 * 256 * 8)) cfg = 3;
     else if (A_KC && !B_KC && a.N >= 2048 && big_out) cfg = 3;
     else if (A_KC && !B_KC && klen >= 2048 && big_out && a.N % 256 == 0) cfg = 3;    // forward MLP projection (K = 3072, N = 768): +12 % over 128x128
-    else if (A_KC && B_KC && klen >= 2048 && big_out && a.N % 128 == 0) cfg = 2;
+    else if (A_KC && B_KC && klen >= 2048 && big_out && a.N % 128 == 0 && a.N <= 4096) cfg = 2;   // (not the LM-head logits at d = 2048)
     else if (A_KC && B_KC && a.N >= 2048 && big_out) cfg = 3;       // K = 768 dgrad through the MLP, LM-head logits
     else if (A_KC && B_KC && big_out && a.N % 128 == 0) cfg = 2;    // K = 768, N = 768 dgrad (attention out)
     else cfg = klen >= 16384 ? 1 : 0;
@@ -731,11 +731,13 @@ int launch(const GemmArgs& a, hipStream_t s) {
     // (profiles/r01_step19_gemm_tile_sweep.txt): with fewer than half a round, 128x128 (wide outputs: up to 2.1x) or
     // 256x128 (N = 768) wins; between half and 1.5 rounds wide outputs prefer 256x128 (+9..16 %), while N = 768 dgrads
     // prefer ONE 8-wave 256x256 block per CU over two 4-wave 256x128 blocks on some CUs (+16..19 %).
+    // (the 2048d geometry agrees where it overlaps: N = 2048 dgrads at 8192 rows are exactly one round of 256x256 tiles
+    // and gain 13..15 % on them; its K >= 2048 forward shapes keep 256x256 even at one round)
     const long t3n = (long)((a.M + 255) / 256) * ((a.N + 255) / 256) * (a.splitk > 1 ? a.splitk : 1);
-    const bool wide = a.N >= 2048;
+    const bool wide = a.N > 2048;
     if (A_KC) {
       if (cfg == 3 && t3n < 128) cfg = wide ? 0 : 2;
-      else if (cfg == 3 && t3n < 384 && wide) cfg = 2;
+      else if (cfg == 3 && t3n < 384 && wide && klen <= 1024) cfg = 2;
       else if (cfg == 2 && t3n >= 128 && t3n < 384 && !wide) cfg = 3;
     } else if (cfg == 3 && t3n < 128) {
       cfg = 0;                                  // weight gradients with a handful of output tiles

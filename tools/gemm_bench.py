@@ -52,12 +52,17 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--safe", type=int, default=0)
     ap.add_argument("--sk", type=int, default=0, help="force this split-K factor on the split-K shapes")
+    ap.add_argument("--dim", type=int, default=0, help="embed dim instead of 768 (2048 = the Gato-1.2B geometry)")
     ap.add_argument("--rows", type=int, default=0, help="B*T rows instead of 32768 (README batch sizes: 7680 = 32 x 240)")
     args = ap.parse_args()
+    if args.dim:
+        sub = lambda v: {D: args.dim, 3 * D: 3 * args.dim, 4 * D: 4 * args.dim}.get(v, v)
+        SHAPES[:] = [(nm, sub(m), sub(n), sub(k), aks, bks, ex) for (nm, m, n, k, aks, bks, ex) in SHAPES
+                     if not nm.startswith(("rl", "sq"))]
     if args.rows:
         shapes = []
         for (name, m, n, k, aks, bks, ex) in SHAPES:
-            if name.startswith(("lm", "rl", "sq")):
+            if name.startswith(("rl", "sq")) or (name.startswith("lm") and not args.dim):
                 continue
             shapes.append((name, args.rows if m == M else m, n, args.rows if k == M else k, aks, bks, ex))
         SHAPES[:] = shapes
