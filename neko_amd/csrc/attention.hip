@@ -38,6 +38,11 @@ constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
 // v_exp_f32 is 2^x natively, and LSE is converted back to natural log when stored.
 __device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }
 
+// Workgroups are dealt to the 8 XCDs round-robin by linear id (x fastest).  With T = 1024 the grid is 8 tiles wide,
+// so tile index == XCD: one XCD got every heaviest causal tile (16 key tiles) and another every lightest (2) -- the
+// kernel ran at the speed of the first.  Rotating the tile index by (head + batch) gives every XCD the same mix.
+__device__ __forceinline__ int rotated_tile() { return (int)((blockIdx.x + blockIdx.y + blockIdx.z) % gridDim.x); }
+
 template <int HD> struct Cfg {
   static constexpr int NSTR = HD * 2 + 16;    // natural image row stride (bytes)
   static constexpr int KS = HD / 16;          // MFMA k-steps over the head dim
@@ -135,10 +140,10 @@ __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (
 // forward
 // =====================================================================================================
 template <int HD, bool DROP>
-__global__ __launch_bounds__(NT, (HD <= 32 ? NEKO_FWD_WAVES : (HD <= 64 ? 3 : 2))) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ kbias,
+__device__ __forceinline__ void attn_fwd_tile(const bf16_t* __restrict__ qkv, const float* __restrict__ kbias,
                                                       const int* __restrict__ kstart, bf16_t* __restrict__ out,
                                                       float* __restrict__ lse, int B, int T, int H, float scale,
-                                                      uint32_t drop_thr, uint32_t drop_key, float drop_scale) {
+                                                      uint32_t drop_thr, uint32_t drop_key, float drop_scale, const int tile) {
   using C = Cfg<HD>;
   __shared__ __attribute__((aligned(16))) char smem[C::NAT_BYTES + C::TR_BYTES + KT * 4 + 16];
   char* ldsK = smem;
@@ -146,7 +151,7 @@ __global__ __launch_bounds__(NT, (HD <= 32 ? NEKO_FWD_WAVES : (HD <= 64 ? 3 : 2)
   float* ldsKb = reinterpret_cast<float*>(smem + C::NAT_BYTES + C::TR_BYTES);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int qt = (gridDim.x - 1) - blockIdx.x;   // heaviest (latest) query tiles first
+  const int qt = tile;
   const int h = blockIdx.y, b = blockIdx.z;
   const int d = H * HD;
   const long ld = 3L * d;
@@ -298,6 +303,23 @@ __global__ __launch_bounds__(NT, (HD <= 32 ? NEKO_FWD_WAVES : (HD <= 64 ? 3 : 2)
   }
 }
 
+template <int HD, bool DROP>
+__global__ __launch_bounds__(NT, (HD <= 32 ? NEKO_FWD_WAVES : (HD <= 64 ? 3 : 2))) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ kbias,
+                                                      const int* __restrict__ kstart, bf16_t* __restrict__ out,
+                                                      float* __restrict__ lse, int B, int T, int H, float scale,
+                                                      uint32_t drop_thr, uint32_t drop_key, float drop_scale) {
+  // one workgroup = a heavy and a light causal tile (G-1-p and p): every workgroup walks the same number of
+  // 64-row tiles.  With one tile per workgroup the whole grid was co-resident and the kernel lasted as long as its
+  // heaviest workgroup (16 tile iterations at T = 1024 against an average of 9).
+  const int G = (T + 127) / 128, p = rotated_tile();
+  const int first = G - 1 - p, second = p;
+  attn_fwd_tile<HD, DROP>(qkv, kbias, kstart, out, lse, B, T, H, scale, drop_thr, drop_key, drop_scale, first);
+  if (second != first) {
+    __syncthreads();
+    attn_fwd_tile<HD, DROP>(qkv, kbias, kstart, out, lse, B, T, H, scale, drop_thr, drop_key, drop_scale, second);
+  }
+}
+
 // =====================================================================================================
 // backward prep: D[b,h,q] = sum_hd dO*O  and per (b, 64-query tile) "holds a masked query row" flags
 // =====================================================================================================
@@ -339,11 +361,11 @@ __global__ void attn_bwd_prep_kernel(const bf16_t* __restrict__ o, const bf16_t*
 // backward dQ: lanes own queries (same geometry as forward)
 // =====================================================================================================
 template <int HD, bool DROP>
-__global__ __launch_bounds__(NT, (HD <= 32 ? 4 : (HD <= 64 ? 2 : 1))) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+__device__ __forceinline__ void attn_bwd_dq_tile(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                          const float* __restrict__ kbias, const int* __restrict__ kstart,
                                                          const float* __restrict__ lse, const float* __restrict__ Dv,
                                                          bf16_t* __restrict__ dqkv, int B, int T, int H, float scale,
-                                                         uint32_t drop_thr, uint32_t drop_key, float drop_scale) {
+                                                         uint32_t drop_thr, uint32_t drop_key, float drop_scale, const int tile) {
   using C = Cfg<HD>;
   __shared__ __attribute__((aligned(16))) char smem[2 * C::NAT_BYTES + C::TR_BYTES + KT * 4 + 16];
   char* ldsK = smem;
@@ -352,7 +374,7 @@ __global__ __launch_bounds__(NT, (HD <= 32 ? 4 : (HD <= 64 ? 2 : 1))) void attn_
   float* ldsKb = reinterpret_cast<float*>(smem + 2 * C::NAT_BYTES + C::TR_BYTES);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int qt = (gridDim.x - 1) - blockIdx.x;
+  const int qt = tile;
   const int h = blockIdx.y, b = blockIdx.z;
   const int d = H * HD;
   const long ld = 3L * d;
@@ -486,15 +508,33 @@ __global__ __launch_bounds__(NT, (HD <= 32 ? 4 : (HD <= 64 ? 2 : 1))) void attn_
   }
 }
 
+template <int HD, bool DROP>
+__global__ __launch_bounds__(NT, (HD <= 32 ? 4 : (HD <= 64 ? 2 : 1))) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+                                                         const float* __restrict__ kbias, const int* __restrict__ kstart,
+                                                         const float* __restrict__ lse, const float* __restrict__ Dv,
+                                                         bf16_t* __restrict__ dqkv, int B, int T, int H, float scale,
+                                                         uint32_t drop_thr, uint32_t drop_key, float drop_scale) {
+  // one workgroup = a heavy and a light causal tile (G-1-p and p): every workgroup walks the same number of
+  // 64-row tiles.  With one tile per workgroup the whole grid was co-resident and the kernel lasted as long as its
+  // heaviest workgroup (16 tile iterations at T = 1024 against an average of 9).
+  const int G = (T + 127) / 128, p = rotated_tile();
+  const int first = G - 1 - p, second = p;
+  attn_bwd_dq_tile<HD, DROP>(qkv, dout, kbias, kstart, lse, Dv, dqkv, B, T, H, scale, drop_thr, drop_key, drop_scale, first);
+  if (second != first) {
+    __syncthreads();
+    attn_bwd_dq_tile<HD, DROP>(qkv, dout, kbias, kstart, lse, Dv, dqkv, B, T, H, scale, drop_thr, drop_key, drop_scale, second);
+  }
+}
+
 // =====================================================================================================
 // backward dK/dV: lanes own keys; loop over 64-query tiles
 // =====================================================================================================
 template <int HD, bool DROP>
-__global__ __launch_bounds__(NT, (HD <= 32 ? NEKO_DKV_WAVES : (HD <= 64 ? 2 : 1))) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+__device__ __forceinline__ void attn_bwd_dkv_tile(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                           const float* __restrict__ kbias, const float* __restrict__ lse,
                                                           const float* __restrict__ Dv, const int* __restrict__ qflags,
                                                           bf16_t* __restrict__ dqkv, int B, int T, int H, float scale,
-                                                          uint32_t drop_thr, uint32_t drop_key, float drop_scale) {
+                                                          uint32_t drop_thr, uint32_t drop_key, float drop_scale, const int tile) {
   using C = Cfg<HD>;
   __shared__ __attribute__((aligned(16))) char smem[2 * C::NAT_BYTES + 2 * C::TR_BYTES + 2 * KT * 4];
   char* ldsQ = smem;
@@ -505,7 +545,7 @@ __global__ __launch_bounds__(NT, (HD <= 32 ? NEKO_DKV_WAVES : (HD <= 64 ? 2 : 1)
   float* ldsD = ldsLse + KT;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int kblk = blockIdx.x;
+  const int kblk = tile;
   const int h = blockIdx.y, b = blockIdx.z;
   const int d = H * HD;
   const long ld = 3L * d;
@@ -664,11 +704,29 @@ __global__ __launch_bounds__(NT, (HD <= 32 ? NEKO_DKV_WAVES : (HD <= 64 ? 2 : 1)
   }
 }
 
+template <int HD, bool DROP>
+__global__ __launch_bounds__(NT, (HD <= 32 ? NEKO_DKV_WAVES : (HD <= 64 ? 2 : 1))) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+                                                          const float* __restrict__ kbias, const float* __restrict__ lse,
+                                                          const float* __restrict__ Dv, const int* __restrict__ qflags,
+                                                          bf16_t* __restrict__ dqkv, int B, int T, int H, float scale,
+                                                          uint32_t drop_thr, uint32_t drop_key, float drop_scale) {
+  // one workgroup = a heavy and a light causal tile (G-1-p and p): every workgroup walks the same number of
+  // 64-row tiles.  With one tile per workgroup the whole grid was co-resident and the kernel lasted as long as its
+  // heaviest workgroup (16 tile iterations at T = 1024 against an average of 9).
+  const int G = (T + 127) / 128, p = rotated_tile();
+  const int first = p, second = G - 1 - p;
+  attn_bwd_dkv_tile<HD, DROP>(qkv, dout, kbias, lse, Dv, qflags, dqkv, B, T, H, scale, drop_thr, drop_key, drop_scale, first);
+  if (second != first) {
+    __syncthreads();
+    attn_bwd_dkv_tile<HD, DROP>(qkv, dout, kbias, lse, Dv, qflags, dqkv, B, T, H, scale, drop_thr, drop_key, drop_scale, second);
+  }
+}
+
 template <int HD>
 int fwd_launch(const bf16_t* qkv, const float* kbias, const int* kstart, bf16_t* out, float* lse, int B, int T, int H,
                int thr, unsigned key, float dscale, hipStream_t s) {
   const float scale = 1.0f / sqrtf((float)HD);
-  dim3 grid((T + 127) / 128, H, B);
+  dim3 grid(((T + 127) / 128 + 1) / 2, H, B);      // tile pairs, see the kernels
   if (thr)
     hipLaunchKernelGGL((attn_fwd_kernel<HD, true>), grid, dim3(NT), 0, s, qkv, kbias, kstart, out, lse, B, T, H, scale,
                        (uint32_t)thr, key, dscale);
@@ -689,7 +747,7 @@ int bwd_launch(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const f
   hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, out, dout, kbias, D,
                      qflags, B, T, H, HD, thr ? 1.0f / dscale : 1.0f);
   NEKO_CHECK_LAUNCH();
-  dim3 grid((T + 127) / 128, H, B);
+  dim3 grid(((T + 127) / 128 + 1) / 2, H, B);      // tile pairs, see the kernels
   if (thr) {
     hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, true>), grid, dim3(NT), 0, s, qkv, dout, kbias, kstart, lse, D, dqkv, B, T,
                        H, scale, (uint32_t)thr, key, dscale);
