@@ -44,6 +44,8 @@ def make_batch(workload: str, B: int, seed: int, device):
         return S.SyntheticTextTask(1023, V_TEXT, seed=seed, device=device).sample_batch(B)
     if workload == "c2":   # halfcheetah-shaped, T = 240
         return S.SyntheticControlTask(17, 6, 10, seed=seed, device=device).sample_batch(B)
+    if workload == "c4":   # Atari Breakout-shaped (BASELINE configs[3]): 13 x (36 patches + SEP + 1 action) = 494
+        return S.SyntheticAtariTask(13, 96, 96, seed=seed, device=device).sample_batch(B)
     if workload == "c5-mix":   # text 1024 / Atari 494 / caption 289 / halfcheetah 240 in one batch (ragged lengths)
         return S.ragged_mix_batch(B, seed, device)
     raise ValueError(workload)
@@ -100,7 +102,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=32, help="sequences per GPU per step")
-    ap.add_argument("--workload", default="m-mix", choices=["m-mix", "m-text", "c2", "c5-mix"])
+    ap.add_argument("--workload", default="m-mix", choices=["m-mix", "m-text", "c2", "c4", "c5-mix"])
     ap.add_argument("--model", default="768d", choices=["768d", "gato-1.2b"],
                     help="768d = the metric's 768d x 6L x 24H (hd=32); gato-1.2b = BASELINE configs[4], 2048d x 24L x 16H "
                          "(hd=128, streaming attention kernels) -- a side measurement, not the metric's config")
@@ -156,7 +158,7 @@ def main():
 
     B = args.batch
     batches = [make_batch(args.workload, B, 1234 + rank + 100 * i, dev) for i in range(2)]
-    Tlen = 240 if args.workload == "c2" else T
+    Tlen = {"c2": 240, "c4": 494}.get(args.workload, T)
 
     def step(i):
         _, loss = model.forward(inputs=batches[i % len(batches)], compute_loss=True, return_logits=False)
