@@ -144,7 +144,7 @@ def test_g8_training_trace(golden):
     rel = [abs(a - b) / abs(b) for a, b in zip(losses, f["trace"]["loss"])]
     reln = [abs(a - b) / abs(b) for a, b in zip(norms, f["trace"]["grad_norm"])]
     assert max(rel) < 1e-3, (max(rel), rel.index(max(rel)))
-    assert max(reln) < 3e-2, max(reln)
+    assert max(reln[:5]) < 5e-3 and max(reln) < 8e-2, (reln[:5], max(reln))     # see test_g7b_training_trace_1e3
 
 
 def test_geglu_decode_cached_equals_full():

@@ -229,7 +229,14 @@ def test_g7b_training_trace_1e3():
     reln = [abs(a - b) / abs(b) for a, b in zip(norms, tr["grad_norm"])]
     print("g7b max rel loss dev", max(rel), "| max rel grad-norm dev", max(reln), "| loss", losses[0], "->", losses[-1])
     assert max(rel) < 1e-3, (max(rel), rel.index(max(rel)))
-    assert max(reln) < 6e-2, (max(reln), reln.index(max(reln)))
+    # The gradient norm of a single step is a much noisier observable than the loss: steps 0-1 agree with the reference
+    # to 1e-3..2e-3 and are bit-reproducible run to run, but after ~60 steps the bf16 trajectory has drifted enough from
+    # the fp32 one (and, through fp32-atomic summation order, from its own previous run) that a late step's norm is
+    # 2..5 % off (tools/g7b_probe.py: max 0.025..0.048 over 12 runs, always at steps 65-92).  Gate the typical
+    # deviation tightly and the worst step loosely; the loss above is the north-star gate (measured max 1e-4).
+    assert max(reln[:5]) < 5e-3, reln[:5]
+    assert sorted(reln)[len(reln) // 2] < 1.5e-2, sorted(reln)[len(reln) // 2]
+    assert max(reln) < 1.2e-1, (max(reln), reln.index(max(reln)))
 
 
 def test_gradient_accumulation_two_micro_batches():
