@@ -173,7 +173,11 @@ class ControlTask:
 
     def __init__(self, env_name: str, env, dataset: EpisodeStore, context_len: int, args,
                  training_prompt_len_proportion: float = 0.5, share_prompt_episodes: bool = True,
-                 top_k_prompting: Optional[int] = None):
+                 top_k_prompting: Optional[int] = None, host_batches: bool = False):
+        #: True: sample_batch returns CPU tensors whatever `device` says.  The reference builds two device tensors per
+        #: example (:304,314) -- 64 small pageable H2D copies per batch of 32; the HIP policy instead concatenates
+        #: host-resident sources and uploads them in ONE pinned asynchronous copy (GatoPolicy._gather_values).
+        self.host_batches = host_batches
         self.name = env_name
         self.is_atari = "ALE" in env_name
         self.env, self.dataset, self.args = env, dataset, args
@@ -262,6 +266,8 @@ class ControlTask:
                 act_l[i] = np.concatenate([ep.actions[p_start:(p_end + 1), ], act_l[i]], axis=0)
         out = []
         osp, asp = self.env.observation_space, self.env.action_space
+        if self.host_batches:
+            device = "cpu"
         for i in range(batch_size):
             obs = torch.tensor(obs_l[i], dtype=torch.float32 if _is_box(osp) else torch.int32, device=device)
             if self.image_transform is not None:

@@ -146,3 +146,23 @@ def test_train_py_on_an_episode_file(tmp_path, monkeypatch):
                     "--text_vocab_size", "128", "--control_datasets", path, "--prompt_ep_proportion", "0.5",
                     "--ragged_groups", "2", "--resid_mid_channels", "128"])
     train.main(a)
+
+
+def test_host_batches_give_the_same_loss_as_device_batches():
+    """ControlTask(host_batches=True) hands CPU tensors to the policy (one pinned upload instead of two device tensors
+    per example): identical packing, identical loss."""
+    from neko_amd.tasks.control_task import BoxSpace, ControlTask, Episode, EpisodeStore
+    rng = np.random.default_rng(6)
+    eps = [Episode(rng.standard_normal((T, 5)).astype(np.float32), (rng.random((T, 2)) * 2 - 1).astype(np.float32), id=i)
+           for i, T in enumerate((30, 45, 12))]
+    m = _policy(64)
+    losses = []
+    for host in (False, True):
+        task = ControlTask("toy", ToyEnv(BoxSpace((5,)), BoxSpace((2,)), 3), EpisodeStore(eps, seed=2), 64,
+                           types.SimpleNamespace(patch_size=16), host_batches=host)
+        np.random.seed(9)
+        batch = task.sample_batch(2, {"end": 1}, DEV, max_tokens=64)
+        assert all(t.is_cuda != host for d in batch for t in d.values())
+        with torch.no_grad():
+            losses.append(float(m(batch, compute_loss=True, return_logits=False)[1]))
+    assert losses[0] == losses[1]

@@ -52,7 +52,8 @@ def main(args: TrainingArgs):
             store = EpisodeStore.from_npz(n, seed=seed + i)
             tasks.append(ControlTask(os.path.basename(n)[:-4], SpacesOnlyEnv(*store.spaces()), store, ts, args,
                                      training_prompt_len_proportion=args.prompt_len_proportion,
-                                     share_prompt_episodes=not args.unique_prompt_episodes, top_k_prompting=args.top_k))
+                                     share_prompt_episodes=not args.unique_prompt_episodes, top_k_prompting=args.top_k,
+                                     host_batches=True))
             continue
         if "breakout" in n.lower() or "atari" in n.lower():
             tasks.append(S.SyntheticAtariTask(max(1, ts // 38), 96, 96, name=n, seed=seed + i, device=dev))
