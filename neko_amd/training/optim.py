@@ -34,6 +34,7 @@ class NekoAdamW(torch.optim.Optimizer):
         self.steps: Dict[str, torch.Tensor] = {g: torch.zeros(1, dtype=torch.int32, device=dev) for g in self.groups}
         self.active = torch.zeros(len(self.groups), dtype=torch.int32, device=dev)
         self._stager = None        # pinned staging for the per-step flag upload (event-guarded reuse)
+        self._last_act = None      # flags currently in `self.active`
         self.gnorm_sq = torch.zeros(1, dtype=torch.float64, device=dev)
         self._pending_clip: Optional[float] = None
         self.grad_scale: Optional[torch.Tensor] = None    # set by the DP reducer (1/world)
@@ -76,13 +77,17 @@ class NekoAdamW(torch.optim.Optimizer):
         grp = self.param_groups[0]
         lr, (b1, b2), eps, wd = grp["lr"], grp["betas"], grp["eps"], grp["weight_decay"]
         act = self._active_groups()
-        if self.active.is_cuda:
-            if self._stager is None:
-                from ..utils.utils import HostStager
-                self._stager = HostStager()
-            self.active.copy_(self._stager.upload(torch.tensor(act, dtype=torch.int32), self.active.device))
-        else:
-            self.active.copy_(torch.tensor(act, dtype=torch.int32))
+        # the flags rarely change from step to step: upload them only when they do (with a reducer attached the device
+        # copy is overwritten by the MAX over ranks every step, so it is refreshed every step)
+        if act != self._last_act or self.flags_reduce is not None:
+            if self.active.is_cuda:
+                if self._stager is None:
+                    from ..utils.utils import HostStager
+                    self._stager = HostStager()
+                self.active.copy_(self._stager.upload(torch.tensor(act, dtype=torch.int32), self.active.device))
+            else:
+                self.active.copy_(torch.tensor(act, dtype=torch.int32))
+            self._last_act = list(act)
         if self.flags_reduce is not None:
             self.flags_reduce(self.active)
         clip = self._pending_clip
