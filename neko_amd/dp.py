@@ -30,6 +30,9 @@ class GradReducer:
         self.handles: List = []
         self.pending: Dict[str, bool] = {}
         self.grad_scale = torch.full((1,), 1.0 / self.world, dtype=torch.float32, device=flat.grad.device)
+        #: flat-gradient slices known to stay zero on EVERY rank for the whole run (see declare_unused_rows): not reduced
+        self.zero_slices: List[tuple] = []
+        self.no_text_declared = False       # set with declare_unused_rows("embed_token.weight", 0, text_tokens)
         #: False on the accumulating micro-steps of gradient accumulation: nothing is reduced (the flat gradient keeps
         #: adding up locally) until the last micro-step, whose backward reduces every range once
         self.sync = True
@@ -58,15 +61,43 @@ class GradReducer:
             if g in self.flat.group_ranges:
                 self._reduce(g)
 
+    def declare_unused_rows(self, name: str, row0: int, row1: int) -> None:
+        """Rows [row0, row1) of parameter `name` never receive a gradient on ANY rank in this run -- a property of the
+        run's configuration that every rank must declare identically (the collective layout depends on it).  The use:
+        control-only training (BASELINE configs[1..3], text_prop = caption_prop = vqa_prop = 0) never touches the
+        50257 text rows of `embed_token` (154 MB of the 160 MB `frontend` range at 768d), and that range is the one
+        reduction that cannot overlap with backward (its gradient is produced last).  Summing zeros is the identity,
+        so skipping the slice changes nothing.  GatoPolicy refuses text input while the declaration is active."""
+        off, numel, shape = self.flat.offsets[name]
+        cols = numel // shape[0]
+        assert 0 <= row0 <= row1 <= shape[0]
+        if row1 > row0:
+            self.zero_slices.append((off + row0 * cols, off + row1 * cols))
+            self.zero_slices.sort()
+
+    def _live_ranges(self, a: int, b: int) -> List[tuple]:
+        """[a, b) minus the declared zero slices."""
+        out, cur = [], a
+        for (z0, z1) in self.zero_slices:
+            if z1 <= cur or z0 >= b:
+                continue
+            if z0 > cur:
+                out.append((cur, z0))
+            cur = max(cur, z1)
+        if cur < b:
+            out.append((cur, b))
+        return out
+
     def _reduce(self, gname: str) -> None:
         if self.flat.grad.is_cuda:
             from .engine import SideStream
             SideStream.join(self.flat.grad.device)      # weight gradients are produced on the side stream
         a, b = self.flat.group_ranges[gname]
-        for s in range(a, b, self.bucket_elems):
-            e = min(b, s + self.bucket_elems)
-            self.handles.append(dist.all_reduce(self.flat.grad[s:e], op=dist.ReduceOp.SUM, group=self.group,
-                                                async_op=True))
+        for (la, lb) in self._live_ranges(a, b):
+            for s in range(la, lb, self.bucket_elems):
+                e = min(lb, s + self.bucket_elems)
+                self.handles.append(dist.all_reduce(self.flat.grad[s:e], op=dist.ReduceOp.SUM, group=self.group,
+                                                    async_op=True))
 
     def reduce_flags(self, flags: torch.Tensor) -> None:
         if self.world > 1:   # stream-ordered (NCCL: the current stream waits on the comm stream, the host does not)

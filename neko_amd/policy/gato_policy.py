@@ -495,6 +495,10 @@ class GatoPolicy(nn.Module):
         if self.pad_seq:
             ragged_groups = 0           # pad_seq asks for context_len-wide rows (gato_policy.py:423-431)
         pb = build_layout(inputs, self.use_pos_encoding, self.context_len, self.pad_seq, ragged_groups=ragged_groups)
+        if self._dp is not None and getattr(self._dp, "no_text_declared", False) and \
+                bool(np.isin(pb.desc[:, 0], (K_TOKEN, K_DEVID)).any()):
+            raise RuntimeError("text tokens in a batch, but the data-parallel reducer was told that the text rows of "
+                               "embed_token never receive gradients (GradReducer.declare_unused_rows)")
         desc = self.image_embedding._upload(torch.from_numpy(pb.desc), dev)
         cont = self._gather_values(pb.cont, torch.float32, dev)
         disc = self._gather_values(pb.disc, torch.int32, dev)

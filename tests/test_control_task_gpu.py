@@ -166,3 +166,16 @@ def test_host_batches_give_the_same_loss_as_device_batches():
         with torch.no_grad():
             losses.append(float(m(batch, compute_loss=True, return_logits=False)[1]))
     assert losses[0] == losses[1]
+
+
+def test_text_is_refused_when_the_reducer_was_told_there_is_none():
+    """GradReducer.declare_unused_rows("embed_token.weight", 0, text_tokens) skips reducing the text rows; a batch that
+    contains text would then silently diverge across ranks, so the policy refuses it."""
+    m = _policy(64)
+    m._dp = types.SimpleNamespace(no_text_declared=True, group_ready=lambda *_: None)
+    ctl = [{"continuous_obs": torch.randn(3, 4).to(DEV), "continuous_actions": (torch.rand(3, 2) * 2 - 1).to(DEV)}]
+    _, loss = m(ctl, compute_loss=True, return_logits=False)
+    assert torch.isfinite(loss)
+    with pytest.raises(RuntimeError, match="declare_unused_rows"):
+        m(ctl + [{"text": [1, 2, 3]}], compute_loss=True, return_logits=False)
+    m._dp = None

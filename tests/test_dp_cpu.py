@@ -16,7 +16,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, results):
+def _worker(rank, world, port, results, declare=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -27,6 +27,8 @@ def _worker(rank, world, port, results):
         flat = m._flat
         dp = GradReducer(flat, bucket_bytes=64 * 1024)      # small buckets: several slices per range
         dp.broadcast_parameters()
+        if declare:                 # control-only run: the 64 text rows of the token embedding never see a gradient
+            dp.declare_unused_rows("embed_token.weight", 0, m.text_tokens)
         w0 = flat.data.clone()
         # rank-specific gradients; rank 1 has "no images" (its image range stays zero and it never signals it)
         g = torch.Generator().manual_seed(7 + rank)
@@ -49,7 +51,15 @@ def _worker(rank, world, port, results):
         dist.all_gather(gathered, local)
         expect = sum(gathered)
         na, nb = flat.group_ranges["never"]
-        ok_sum = torch.allclose(flat.grad[:na], expect[:na], rtol=1e-6, atol=1e-6)
+        if declare:                 # the declared slice is left alone (local values), everything around it is summed
+            o, n, shape = flat.offsets["embed_token.weight"]
+            z0, z1 = o, o + m.text_tokens * shape[1]
+            assert z1 - z0 == 64 * 64 and z1 < o + n
+            skipped_untouched = torch.equal(flat.grad[z0:z1], local[z0:z1])
+            expect[z0:z1] = local[z0:z1]
+        else:
+            skipped_untouched = True
+        ok_sum = torch.allclose(flat.grad[:na], expect[:na], rtol=1e-6, atol=1e-6) and skipped_untouched
         ok_never = torch.equal(flat.grad[na:nb], local[na:nb])       # the never-used range is not reduced
         w_all = [torch.zeros_like(w0) for _ in range(world)]
         dist.all_gather(w_all, w0)
@@ -59,13 +69,14 @@ def _worker(rank, world, port, results):
         dist.destroy_process_group()
 
 
-def test_grad_reducer_world2_gloo():
+@pytest.mark.parametrize("declare", [False, True])
+def test_grad_reducer_world2_gloo(declare):
     world = 2
     port = _free_port()
     ctx = mp.get_context("spawn")
     with ctx.Manager() as mgr:
         results = mgr.dict()
-        procs = [ctx.Process(target=_worker, args=(r, world, port, results)) for r in range(world)]
+        procs = [ctx.Process(target=_worker, args=(r, world, port, results, declare)) for r in range(world)]
         for p in procs:
             p.start()
         for p in procs:

@@ -328,3 +328,18 @@ def test_episode_store_npz_roundtrip_and_spaces(tmp_path):
 def argparse_ns(**kw):
     import types
     return types.SimpleNamespace(**kw)
+
+
+def test_reducer_live_ranges_around_declared_zero_rows():
+    import types
+    from neko_amd.dp import GradReducer
+    flat = types.SimpleNamespace(grad=torch.zeros(1), offsets={"e": (100, 50 * 8, (50, 8)), "f": (600, 40, (40,))},
+                                 group_ranges={"g": (64, 704)})
+    dp = GradReducer(flat)
+    assert dp._live_ranges(64, 704) == [(64, 704)]
+    dp.declare_unused_rows("e", 0, 30)            # elements [100, 340)
+    assert dp._live_ranges(64, 704) == [(64, 100), (340, 704)]
+    dp.declare_unused_rows("e", 40, 50)           # elements [420, 500)
+    assert dp._live_ranges(64, 704) == [(64, 100), (340, 420), (500, 704)]
+    assert dp._live_ranges(0, 64) == [(0, 64)] and dp._live_ranges(120, 300) == []
+    assert sum(b - a for a, b in dp._live_ranges(64, 704)) == 640 - 240 - 80

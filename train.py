@@ -108,6 +108,11 @@ def main(args: TrainingArgs):
         dp = GradReducer(model._flat)
         dp.broadcast_parameters()
         dp.attach(model, optimizer)
+        if args.text_prop == 0 and args.caption_prop == 0 and args.vqa_prop == 0:
+            # control-only run (same arguments on every rank): the text rows of the token embedding never see a
+            # gradient, so the one reduction that cannot hide behind backward shrinks from 160 MB to 6 MB at 768d
+            dp.declare_unused_rows("embed_token.weight", 0, model.text_tokens)
+            dp.no_text_declared = True
     trainer = Trainer(model=model, optimizer=optimizer, accelerator=None, scheduler=scheduler, tasks=tasks,
                       exp_name=exp_name, args=args, dp=dp)
     trainer.train()
