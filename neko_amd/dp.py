@@ -93,6 +93,9 @@ class GradReducer:
             from .engine import SideStream
             SideStream.join(self.flat.grad.device)      # weight gradients are produced on the side stream
         a, b = self.flat.group_ranges[gname]
+        dirty = getattr(self.flat, "_dirty", None)
+        if dirty is not None:       # a reduced slice may hold other ranks' gradients even if this rank never wrote it
+            dirty.update(n for n, (o, _, _) in self.flat.offsets.items() if a <= o < b)
         for (la, lb) in self._live_ranges(a, b):
             for s in range(la, lb, self.bucket_elems):
                 e = min(lb, s + self.bucket_elems)
