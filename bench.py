@@ -241,6 +241,14 @@ def main():
         lay = build_layout(batches[0], True, T, False, ragged_groups=args.ragged_groups)
         real_tokens = int((lay.desc[:, 0] != K_PAD).sum())
         rows = int(lay.desc.shape[0])
+        # MFMA-pipe utilisation of the same kernel from the committed SQ counter pass (tools/pmc_gemm.sh): context for
+        # `frac`, which is priced against the nominal 2.5 PFLOP/s at 2.4 GHz while the chip sustains ~1.5-1.7 GHz here
+        mfma_busy = None
+        cp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_step19_gemm_counters.txt")
+        if os.path.exists(cp) and D == 768:
+            import re
+            mm = re.search(r"lmlogit16: .*?MFMA pipe busy ([0-9.]+) %", open(cp).read())
+            mfma_busy = float(mm.group(1)) / 100 if mm else None
         out = {
             "metric": "multimodal tokens/sec (fwd+bwd+optimizer, whole job)", "value": value, "unit": "tokens/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps,
@@ -261,7 +269,9 @@ def main():
             "roofline": {"bound": "mfma", "achieved": dom["tflops"], "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": dom["tflops"] / MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch",
                          "traffic_source": traffic_src, "kernel": dom["kernel"],
-                         "shape_MNK": dom["shape"], "ms_per_launch": dom["ms"]},
+                         "shape_MNK": dom["shape"], "ms_per_launch": dom["ms"],
+                         "mfma_pipe_busy_pmc": mfma_busy,
+                         "mfma_pipe_busy_source": "profiles/r01_step19_gemm_counters.txt (SQ_VALU_MFMA_BUSY_CYCLES)" if mfma_busy else None},
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
