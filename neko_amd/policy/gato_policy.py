@@ -400,7 +400,7 @@ class GatoPolicy(nn.Module):
         self.use_pos_encoding = use_pos_encoding
         self.pos_embed_observation = nn.Embedding(context_len, embed_dim)            # :149
 
-        self.lm_head_chunk_rows = 4096
+        self.lm_head_chunk_rows = int(os.environ.get("NEKO_LM_CHUNK_ROWS", "4096"))
         self.lm_head_selected_rows = True   # LM head only at loss positions when they are known on the host
         #: > 0: training forwards (compute_loss=True, return_logits=False) pack the batch into at most this many length
         #: buckets instead of left-padding every example to the longest one (misc/todo.md:11);
