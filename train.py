@@ -12,6 +12,8 @@ import os
 import sys
 from datetime import datetime
 
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")     # see bench.py: before the HIP runtime initialises
+
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
