@@ -343,3 +343,11 @@ def test_reducer_live_ranges_around_declared_zero_rows():
     assert dp._live_ranges(64, 704) == [(64, 100), (340, 420), (500, 704)]
     assert dp._live_ranges(0, 64) == [(0, 64)] and dp._live_ranges(120, 300) == []
     assert sum(b - a for a, b in dp._live_ranges(64, 704)) == 640 - 240 - 80
+
+
+def test_ragged_layout_is_skipped_when_it_saves_little():
+    from neko_amd.policy.gato_policy import build_layout
+    full = [{"text": list(range(n))} for n in (100, 98, 97, 100)]          # 1.5 % padding
+    assert build_layout(full, True, 128, False, ragged_groups=4).segments is None
+    mixed = [{"text": list(range(n))} for n in (100, 20, 97, 25)]
+    assert build_layout(mixed, True, 128, False, ragged_groups=4).segments is not None

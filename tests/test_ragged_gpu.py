@@ -61,9 +61,11 @@ def test_ragged_loss_and_grads_equal_padded_layout_and_oracle(groups):
     m.zero_grad()
     m.ragged_groups = groups
     _, loss_rag = m(to_dev(batch), compute_loss=True, return_logits=False)
-    assert m._ragged is not None and len(m._ragged[1]) == min(groups, 6)
-    rows = sum(b * t for _, b, t in m._ragged[1])
-    assert rows < len(batch) * 91 or groups == 1
+    if groups == 1:          # one bucket removes no padding: the policy keeps the reference layout (< 10 % rows saved)
+        assert m._ragged is None
+    else:
+        assert m._ragged is not None and len(m._ragged[1]) == min(groups, 6)
+        assert sum(b * t for _, b, t in m._ragged[1]) < 0.9 * len(batch) * 91
     loss_rag.backward()
     g_rag = grads_of(m)
     assert abs(float(loss_rag) - float(loss_pad)) < 2e-6 * abs(float(loss_pad)), (float(loss_rag), float(loss_pad))
