@@ -48,6 +48,10 @@ def make_batch(workload: str, B: int, seed: int, device):
         return S.SyntheticTextTask(1023, V_TEXT, seed=seed, device=device).sample_batch(B)
     if workload == "c2":   # halfcheetah-shaped, T = 240
         return S.SyntheticControlTask(17, 6, 10, seed=seed, device=device).sample_batch(B)
+    if workload == "c3":   # 3-task MuJoCo mix (BASELINE configs[2]): halfcheetah 10 x 24, hopper 16 x 15, walker2d 10 x 24 = 240 each
+        tasks = [S.SyntheticControlTask(17, 6, 10, seed=seed, device=device), S.SyntheticControlTask(11, 3, 16, seed=seed + 1, device=device),
+                 S.SyntheticControlTask(17, 6, 10, seed=seed + 2, device=device)]
+        return [tasks[i % 3].sample_batch(1)[0] for i in range(B)]
     if workload == "c4":   # Atari Breakout-shaped (BASELINE configs[3]): 13 x (36 patches + SEP + 1 action) = 494
         return S.SyntheticAtariTask(13, 96, 96, seed=seed, device=device).sample_batch(B)
     if workload == "c5-mix":   # text 1024 / Atari 494 / caption 289 / halfcheetah 240 in one batch (ragged lengths)
@@ -106,7 +110,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=32, help="sequences per GPU per step")
-    ap.add_argument("--workload", default="m-mix", choices=["m-mix", "m-text", "c2", "c4", "c5-mix"])
+    ap.add_argument("--workload", default="m-mix", choices=["m-mix", "m-text", "c2", "c3", "c4", "c5-mix"])
     ap.add_argument("--model", default="768d", choices=["768d", "gato-1.2b"],
                     help="768d = the metric's 768d x 6L x 24H (hd=32); gato-1.2b = BASELINE configs[4], 2048d x 24L x 16H "
                          "(hd=128, streaming attention kernels) -- a side measurement, not the metric's config")
@@ -159,10 +163,13 @@ def main():
         dp = GradReducer(model._flat)
         dp.broadcast_parameters()
         dp.attach(model, opt)
+        if args.workload in ("c2", "c3", "c4"):      # control-only workloads: no rank ever touches the text rows (see dp.py)
+            dp.declare_unused_rows("embed_token.weight", 0, model.text_tokens)
+            dp.no_text_declared = True
 
     B = args.batch
     batches = [make_batch(args.workload, B, 1234 + rank + 100 * i, dev) for i in range(2)]
-    Tlen = {"c2": 240, "c4": 494}.get(args.workload, T)
+    Tlen = {"c2": 240, "c3": 240, "c4": 494}.get(args.workload, T)
 
     def step(i):
         _, loss = model.forward(inputs=batches[i % len(batches)], compute_loss=True, return_logits=False)
