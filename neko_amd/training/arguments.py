@@ -79,7 +79,32 @@ class TrainingArgs:
     # datasets (synthetic stand-ins: names select the synthetic generator shapes)
     control_datasets: List[str] = field(default_factory=list)
     text_datasets: List[str] = field(default_factory=list)
+    text_datasets_paths: List[str] = field(default_factory=list)
     caption_dataset: str = ""
+    # the remaining dataset / LoRA / evaluation flags of arguments.py:58-61,95-123 are accepted so that existing command
+    # lines parse; the readers behind them (webdataset tar shards, VQA json, HF hub) are outside this build
+    caption_train_data: List[str] = field(default_factory=list)
+    caption_test_data: List[str] = field(default_factory=list)
+    test_data_prop: float = 0.1
+    vqa_dataset: str = ""
+    vqa_train_data: List[str] = field(default_factory=list)
+    vqa_test_data: List[str] = field(default_factory=list)
+    train_img_name_prefix: List[str] = field(default_factory=list)
+    train_img_file_name_len: List[str] = field(default_factory=list)
+    test_img_name_prefix: List[str] = field(default_factory=list)
+    test_img_file_name_len: List[str] = field(default_factory=list)
+    questions_file: str = "questions.json"
+    annotations_file: str = "annotations.json"
+    eval_text_num_examples: int = 100
+    eval_text_log_examples: bool = False
+    eval_caption_num_examples: int = 100
+    eval_caption_log_examples: bool = False
+    eval_vqa_num_examples: int = 100
+    eval_vqa_log_examples: bool = False
+    lora: bool = False                     # needs --pretrained_lm (train.py:109-112): rejected with it
+    lora_r: int = 8
+    lora_alpha: int = 32
+    lora_dropout: float = 0.1
 
     # logging / saving
     use_wandb: bool = False

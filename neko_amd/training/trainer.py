@@ -74,6 +74,10 @@ class Trainer:
                         res = task.evaluate(self.model, n_iterations=self.args.eval_episodes,
                                             deterministic=self.args.eval_mode == "deterministic",
                                             promptless_eval=bool(self.args.promptless_eval))
+                    elif getattr(task, "kind", "") == "text" and hasattr(task, "text_dataset"):      # trainer.py:108-112
+                        res = task.evaluate(self.model, num_examples_to_test=self.args.eval_text_num_examples,
+                                            deterministic=self.args.eval_mode == "deterministic",
+                                            log_examples_to_output=self.args.eval_text_log_examples)
                     else:
                         res = task.evaluate(self.model)
                     for k, v in res.items():

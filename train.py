@@ -69,6 +69,8 @@ def main(args: TrainingArgs):
         tasks.append(S.SyntheticCaptionTask(ts - 257, args.text_vocab_size, seed=seed + 60, device=dev))
     assert args.vqa_prop == 0, "no synthetic VQA task (same dict format as caption)"
 
+    if args.lora:
+        raise SystemExit("--lora needs --pretrained_lm (train.py:109-112): downloaded weights are outside this build")
     try:
         tok = None if args.text_vocab_size <= 0 else args.text_vocab_size
         model = GatoPolicy(device=dev, embed_dim=args.embed_dim, layers=args.layers, heads=args.heads,
