@@ -1,6 +1,7 @@
 """CPU tests of the host side: the C-ABI library loads and exports every symbol include/neko_hip.h declares
 (no compute calls), the policy mirrors the reference's state_dict, the packing layout builder agrees with the
 oracle, the LR schedule matches, the product refuses to run without a GPU."""
+import dataclasses
 import os
 import re
 
@@ -351,3 +352,15 @@ def test_ragged_layout_is_skipped_when_it_saves_little():
     assert build_layout(full, True, 128, False, ragged_groups=4).segments is None
     mixed = [{"text": list(range(n))} for n in (100, 20, 97, 25)]
     assert build_layout(mixed, True, 128, False, ragged_groups=4).segments is not None
+
+
+def test_cli_accepts_every_flag_name_of_the_reference():
+    """Flag names of gato/training/arguments.py (the TrainingArgs dataclass; list frozen from the reference file):
+    `train.py` is API surface, existing command lines must parse."""
+    from neko_amd.training.arguments import TrainingArgs, parse_args
+    reference_flags = ['M', 'activation_fn', 'adam_eps', 'annotations_file', 'batch_size', 'beta_1', 'beta_2', 'caption_dataset', 'caption_prop', 'caption_test_data', 'caption_train_data', 'continuous_tokens', 'control_datasets', 'cpu', 'device', 'disable_cosine_decay', 'disable_grad_clip', 'disable_inner_pos_encoding', 'disable_patch_pos_encoding', 'discrete_tokens', 'dropout', 'embed_dim', 'eval_caption_log_examples', 'eval_caption_num_examples', 'eval_episodes', 'eval_mode', 'eval_text_log_examples', 'eval_text_num_examples', 'eval_vqa_log_examples', 'eval_vqa_num_examples', 'flash', 'grad_norm_clip', 'gradient_accumulation_steps', 'heads', 'init_checkpoint', 'init_lr', 'layers', 'learning_rate', 'log_eval_freq', 'lora', 'lora_alpha', 'lora_dropout', 'lora_r', 'min_factor', 'mixed_precision', 'mu', 'num_groups', 'pad_seq', 'patch_position_vocab_size', 'patch_size', 'pretrained_lm', 'prompt_ep_proportion', 'prompt_len_proportion', 'promptless_eval', 'questions_file', 'resid_mid_channels', 'save_dir', 'save_mode', 'save_model', 'sequence_length', 'test_data_prop', 'test_img_file_name_len', 'test_img_name_prefix', 'text_datasets', 'text_datasets_paths', 'text_prop', 'tokenizer_model_name', 'top_k', 'train_img_file_name_len', 'train_img_name_prefix', 'training_steps', 'unique_prompt_episodes', 'use_wandb', 'vqa_dataset', 'vqa_prop', 'vqa_test_data', 'vqa_train_data', 'wandb_project', 'warmup_steps', 'weight_decay']
+    ours = {f.name for f in dataclasses.fields(TrainingArgs)}
+    assert not [n for n in reference_flags if n not in ours]
+    a = parse_args(["--embed_dim", "128", "--layers", "3", "--heads", "4", "--sequence_length", "256", "--text_prop", "1.0",
+                    "--text_datasets", "wikitext-2-v1", "--text_datasets_paths", "wikitext", "--disable_cosine_decay"])
+    assert a.embed_dim == 128 and a.text_prop == 1.0 and a.text_datasets == ["wikitext-2-v1"] and a.disable_cosine_decay
