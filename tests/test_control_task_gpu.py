@@ -179,3 +179,24 @@ def test_text_is_refused_when_the_reducer_was_told_there_is_none():
     with pytest.raises(RuntimeError, match="declare_unused_rows"):
         m(ctl + [{"text": [1, 2, 3]}], compute_loss=True, return_logits=False)
     m._dp = None
+
+
+def test_caption_and_vqa_tasks_on_the_hip_policy():
+    import random
+    from neko_amd.tasks.caption_task import TokenCaptionTask, TokenVqaTask
+    rng = np.random.default_rng(8)
+    img = lambda: torch.tensor(rng.integers(0, 256, (1, 3, 32, 32)).astype(np.uint8))
+    ids = lambda n: rng.integers(0, 128, n).tolist()
+    cap = {p: [{"image": img(), "text": ids(6)} for _ in range(3)] for p in ("train", "test")}
+    vqa = {p: [{"image": img(), "question": ids(4), "answers": [ids(2), ids(3)]} for _ in range(3)] for p in ("train", "test")}
+    m = _policy(48)
+    random.seed(1)
+    for task in (TokenCaptionTask(cap), TokenVqaTask(vqa)):
+        batch = task.sample_batch(3)
+        m.train()
+        _, loss = m(batch, compute_loss=True, return_logits=False)
+        assert torch.isfinite(loss)
+        m.eval()
+        with torch.no_grad():
+            res = task.evaluate(m, num_examples_to_test=2)
+        assert np.isfinite(res["loss"]) and res["perplexity"] > 1.0

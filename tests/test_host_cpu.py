@@ -364,3 +364,40 @@ def test_cli_accepts_every_flag_name_of_the_reference():
     a = parse_args(["--embed_dim", "128", "--layers", "3", "--heads", "4", "--sequence_length", "256", "--text_prop", "1.0",
                     "--text_datasets", "wikitext-2-v1", "--text_datasets_paths", "wikitext", "--disable_cosine_decay"])
     assert a.embed_dim == 128 and a.text_prop == 1.0 and a.text_datasets == ["wikitext-2-v1"] and a.disable_cosine_decay
+
+
+def test_g11_caption_and_vqa_tasks_match_reference(golden):
+    """TokenCaptionTask / TokenVqaTask (caption_task.py:112-159, vqa_task.py:85-141): same items, same Python `random`
+    seed -> the same sampled batches and the same evaluation loss / perplexity as the imported reference."""
+    import random
+    from neko_amd.tasks.caption_task import TokenCaptionTask, TokenVqaTask
+    f = golden("g11_caption_vqa")
+    V = f["vocab"]
+
+    class FakePolicy:
+        device = "cpu"
+
+        def __init__(self):
+            self.module = self
+
+        def _logits(self, image, prompt, max_length):
+            g = torch.Generator().manual_seed(int(image.sum()) % 100003 + 7 * len(prompt) + max_length)
+            return torch.randn(max_length, V, generator=g)
+
+        def predict_caption(self, image, max_length=128, deterministic=True):
+            return self._logits(image, [], max_length), "n/a"
+
+        def predict_response(self, image, prompt_tokens=(), max_length=16, deterministic=True):
+            return self._logits(image, list(prompt_tokens), max_length), "n/a"
+
+    ct, vt, model = TokenCaptionTask(f["caption"]), TokenVqaTask(f["vqa"]), FakePolicy()
+    random.seed(2024)
+    for kind, n, ref in f["calls"]:
+        if kind.endswith("sample"):
+            got = (ct if kind.startswith("caption") else vt).sample_batch(n)
+            assert len(got) == len(ref)
+            for g, r in zip(got, ref):
+                assert list(g.keys()) == ["images", "text"] and g["text"] == r["text"] and torch.equal(g["images"], r["images"])
+        else:
+            m = (ct if kind.startswith("caption") else vt).evaluate(model, num_examples_to_test=n)
+            assert abs(m["loss"] - ref["loss"]) < 1e-6 * ref["loss"] and abs(m["perplexity"] - ref["perplexity"]) < 1e-5 * ref["perplexity"]
