@@ -3,12 +3,12 @@
 AdamW) of the 768d x 6L x 24H Gato policy on fixed-shape synthetic multimodal sequences (T = 1024).
 
     python bench.py --gpus 1 --steps 10 --warmup 3
+    python bench.py --gpus N ...            # N > 1 without a launcher: spawns N ranks itself (torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0 (contract in the task statement).  metric = BASELINE.json's
-"multimodal tokens/sec (fwd+bwd)", value = whole-job tokens/s with inputs resident on the device,
-T counts every position of the padded sequence.
+Prints ONE JSON line on rank 0 (contract in the task statement).  metric = BASELINE.json's metric, value = whole-job
+tokens/s with inputs resident on the device, T counts every position of the padded sequence.
 """
 from __future__ import annotations
 
@@ -21,6 +21,8 @@ import time
 # kernel arguments in device memory: launches of the ~400 kernels of a step start ~0.6 us sooner each (C2 step -4 %,
 # metric step -1 %); read by the HIP runtime when it initialises, so it has to be in the environment before torch loads
 os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+# dmabuf IPC for RCCL / cross-process device memory: also read once, when the runtime initialises
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import torch
 
@@ -31,6 +33,22 @@ D, L, H, T, V_TEXT = 768, 6, 24, 1024, 50257
 V = V_TEXT + 2048
 MFMA_PEAK_TFLOPS = 2500.0      # dense bf16, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
+METRIC = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"] if os.path.exists(os.path.join(ROOT, "BASELINE.json")) \
+    else "multimodal tokens/sec/GPU (fwd+bwd), 768d\u00d76L seq_len=1024, at 1/2/4/8 MI355X"
+
+
+def launch_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (one per GPU) through
+    torch.distributed.run and hand back their exit code.  Called BEFORE anything in this process has touched the GPU;
+    the children are new processes (never an exec of one that initialised HIP).  Rank 0's JSON line goes to our stdout."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd).returncode
 
 
 def flops_per_token_fwd(d=D, layers=L, t=T, v=V, lm_rows_frac=1.0):
@@ -59,28 +77,40 @@ def make_batch(workload: str, B: int, seed: int, device):
     raise ValueError(workload)
 
 
-def cpu_baseline(seconds_budget: float = 30.0):
-    """The CPU oracle (plain PyTorch fp32 restatement of the reference path, pinned to reference fixtures)
-    timed on this box's host cores on a bounded sample of the same workload: ONE text sequence of
-    T=1024 (1023 ids + SEP) through the same 768d x 6L x 24H model, forward + backward."""
+def cpu_baseline():
+    """the CPU oracle (plain PyTorch fp32 restatement of the reference path, pinned to reference
+    fixtures) on the seeded M-text batch B = 2 x (1023 ids + SEP), 768d x 6L x 24H, dropout 0.1 (explicit Bernoulli masks
+    at the reference's four dropout sites), 1 warm-up + 3 timed forward+backward iterations on this box's host cores."""
     from oracle import neko_oracle as O
-    cores = min(os.cpu_count() or 1, 32)      # more intra-op threads than this only oversubscribe the small GEMMs
+    hw = os.cpu_count() or 1
+    # intra-op threads: every hardware thread by default (BASELINE.md section 3); NEKO_CPU_BASELINE_THREADS overrides
+    # (profiles/r02_cpu_baseline_threads.txt holds the sweep measured on the GPU box)
+    cores = int(os.environ.get("NEKO_CPU_BASELINE_THREADS", hw))
     torch.set_num_threads(cores)
     cfg = O.OracleConfig(embed_dim=D, layers=L, heads=H, text_tokens=V_TEXT, context_len=T)
     sd = O.init_state_dict(cfg, 0)
     g = torch.Generator().manual_seed(1234)
     batch = [{"text": torch.randint(0, V_TEXT, (T - 1,), generator=g).tolist()} for _ in range(2)]
-    t0 = time.time()
-    n = 0
-    while True:
-        O.loss_and_grads(sd, cfg, batch)
-        n += 1
-        el = time.time() - t0
-        if n >= 2 or el > seconds_budget * 0.5:
-            break
-    return {"value": n * 2 * T / el, "unit": "tokens/s", "cores": cores, "kind": "port",
-            "sample": f"{n} x (B=2, T=1024 text) fwd+bwd of the 768d/6L/24H model, fp32, torch CPU threads={cores} "
-                      f"of {os.cpu_count()} hardware threads"}
+
+    def masks():
+        keep = lambda *shape: (torch.rand(*shape, generator=g) >= 0.1).to(torch.float32) / 0.9
+        dm = {"embd": keep(2, T, D)}
+        for i in range(L):
+            dm[("attn", i)] = keep(2, H, T, T)
+            dm[("resid_attn", i)] = keep(2, T, D)
+            dm[("resid_mlp", i)] = keep(2, T, D)
+        return dm
+
+    times = []
+    for it in range(4):
+        t0 = time.perf_counter()
+        dm = masks()                               # mask generation is part of the reference's step (31 % of it, BASELINE.md)
+        O.loss_and_grads(sd, cfg, batch, drop_masks=dm)
+        times.append(time.perf_counter() - t0)
+    el = sum(times[1:]) / 3
+    return {"value": 2 * T / el, "unit": "tokens/s", "cores": cores, "kind": "port",
+            "sample": f"1 warm-up + 3 timed x (B=2, T=1024 text) fwd+bwd of the 768d/6L/24H model, fp32, dropout 0.1, "
+                      f"torch intra-op threads={cores} of {hw} hardware threads; {el:.2f} s per iteration"}
 
 
 def time_dominant_kernel(model, rows: int, iters: int = 10):
@@ -104,6 +134,53 @@ def time_dominant_kernel(model, rows: int, iters: int = 10):
             "ms": ms, "tflops": flops / ms / 1e9}
 
 
+def _time_events(fn, iters: int = 10, warm: int = 2) -> float:
+    """Average ms per call, HIP events on the stream the kernels are launched on (torch's current stream)."""
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def time_more_kernels(B: int, Tlen: int, dropout: float):
+    """The kernels the step's time actually sits in (the LM-head GEMM is 5 % of it), timed live at the
+    workload's shapes: attention forward / backward of one layer (useful causal FLOPs: 2 B T^2 d forward, 2.5x that
+    backward) and the three K = 768 / K = 3072 GEMM shapes of a block."""
+    from neko_amd import ops
+    M, d, hd = B * Tlen, D, D // H
+    out = []
+    qkv = (torch.randn(M, 3 * d, device="cuda") * 0.5).to(torch.bfloat16)
+    kb, ks = ops.mask_bias(torch.ones(B, Tlen, device="cuda"))
+    drop = ops.Drop(dropout, 12345) if dropout > 0 else None
+    o, lse = ops.attn_fwd(qkv, kb, ks, B, Tlen, H, hd, drop=drop)
+    do = torch.randn_like(o)
+    ms = _time_events(lambda: ops.attn_fwd(qkv, kb, ks, B, Tlen, H, hd, drop=drop))
+    fl = 2.0 * B * Tlen * Tlen * d
+    out.append({"kernel": "attention forward (one layer)", "ms_per_launch": ms, "achieved": fl / ms / 1e9, "unit": "TFLOP/s",
+                "frac": fl / ms / 1e9 / MFMA_PEAK_TFLOPS, "bound": "mfma (hd=32: VALU-issue limited, DESIGN 4)"})
+    ms = _time_events(lambda: ops.attn_bwd(qkv, o, do, kb, ks, lse, B, Tlen, H, hd, drop=drop))
+    out.append({"kernel": "attention backward (one layer)", "ms_per_launch": ms, "achieved": 2.5 * fl / ms / 1e9,
+                "unit": "TFLOP/s", "frac": 2.5 * fl / ms / 1e9 / MFMA_PEAK_TFLOPS, "bound": "mfma"})
+    a = torch.randn(M, d, device="cuda").to(torch.bfloat16)
+    for name, N, K in (("c_attn forward", 3 * d, d), ("c_fc forward + GELU", 4 * d, d), ("mlp c_proj forward", d, 4 * d)):
+        x = a if K == d else torch.randn(M, K, device="cuda").to(torch.bfloat16)
+        w = (torch.randn(K, N, device="cuda") * 0.02).to(torch.bfloat16)
+        bias = torch.zeros(N, device="cuda")
+        y = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+        pre = torch.empty(M, N, dtype=torch.bfloat16, device="cuda") if "GELU" in name else None
+        ms = _time_events(lambda: ops.gemm(x, w, M, N, K, b_kstrided=True, bias=bias, act=1 if pre is not None else 0,
+                                           pre_out=pre, out_bf16=y))
+        fl = 2.0 * M * N * K
+        out.append({"kernel": f"gemm {name}", "shape_MNK": [M, N, K], "ms_per_launch": ms, "achieved": fl / ms / 1e9,
+                    "unit": "TFLOP/s", "frac": fl / ms / 1e9 / MFMA_PEAK_TFLOPS, "bound": "mfma"})
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -125,9 +202,25 @@ def main():
         D, L, H = 2048, 24, 16
         args.no_cpu_baseline = True        # the fp32 CPU oracle of a 1.4 B-parameter model does not fit the time budget
 
+    # ---- ranks: one process per GPU.  `--gpus N` without a launcher spawns the N ranks here, before any GPU call ----
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            sys.exit(launch_ranks(args.gpus))
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ['WORLD_SIZE']} ranks")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("NEKO_BENCH_LAUNCH_CHECK") == "1":
+        # launcher self-test (tests/test_dp_cpu.py, no GPU): rendezvous + one real all-reduce over gloo, rank 0 reports
+        torch.distributed.init_process_group("gloo")
+        t = torch.ones(1)
+        torch.distributed.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": args.gpus, "ranks_seen": int(t.item()),
+                              "world_size": torch.distributed.get_world_size()}), flush=True)
+        torch.distributed.destroy_process_group()
+        return
     # NEKO_BENCH_BACKEND=gloo + NEKO_BENCH_ONE_DEVICE=1: dry run of the multi-rank flow on a 1-GPU box (every rank on
     # cuda:0, gradients reduced through the host) -- exercises the DP hooks, barriers and max-over-ranks timing, not
     # a performance configuration
@@ -137,7 +230,6 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
             torch.distributed.init_process_group("nccl", device_id=dev)
         else:
@@ -159,9 +251,13 @@ def main():
     model.train()
     opt = NekoAdamW(model, lr=1e-4, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.1)
     dp = None
+    ranks_seen = 1
     if world > 1:
-        dp = GradReducer(model._flat)
+        dp = GradReducer(model._flat, payload=os.environ.get("NEKO_DP_PAYLOAD", "fp32"))
         dp.broadcast_parameters()
+        t = torch.ones(1, device=dev)
+        torch.distributed.all_reduce(t)              # a real collective: how many ranks RCCL actually connected
+        ranks_seen = int(t.item())
         dp.attach(model, opt)
         if args.workload in ("c2", "c3", "c4"):      # control-only workloads: no rank ever touches the text rows (see dp.py)
             dp.declare_unused_rows("embed_token.weight", 0, model.text_tokens)
@@ -171,12 +267,19 @@ def main():
     batches = [make_batch(args.workload, B, 1234 + rank + 100 * i, dev) for i in range(2)]
     Tlen = {"c2": 240, "c3": 240, "c4": 494}.get(args.workload, T)
 
+    # exposed communication: the time the compute stream stalls between "backward enqueued" and "every reduction done"
+    comm_ev = []
+
     def step(i):
         _, loss = model.forward(inputs=batches[i % len(batches)], compute_loss=True, return_logits=False)
         loss.backward()
         if dp is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
             dp.flush()
             dp.finish()
+            e1.record()
+            comm_ev.append((e0, e1))
         if not args.no_optimizer:
             opt.clip_grad_norm_(1.0)
             opt.step()
@@ -189,6 +292,7 @@ def main():
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
+    comm_ev.clear()
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = step(i)
@@ -197,6 +301,7 @@ def main():
         torch.distributed.barrier()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    exposed_comm_ms = (sum(a.elapsed_time(b) for a, b in comm_ev) / len(comm_ev)) if comm_ev else 0.0
     if world > 1:
         t = torch.tensor([el], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -235,17 +340,20 @@ def main():
     if rank == 0:
         tokens = world * B * Tlen * args.steps
         value = tokens / el
-        lm_frac = (model._loss_rows[3] / float(B * Tlen)) if (model._loss_rows and model.lm_head_selected_rows) else 1.0
+        lp = model.last_pack
+        lm_frac = (lp.n_loss / float(B * Tlen)) if (lp is not None and lp.n_loss > 0 and model.lm_head_selected_rows) else 1.0
         fpt = 3 * flops_per_token_fwd(d=D, layers=L, t=Tlen, lm_rows_frac=lm_frac)
         dom = time_dominant_kernel(model, min(4096, B * Tlen))
         # HBM bytes per launch of that kernel: PMC counters cannot be collected from inside the timed process, so the
         # number is the committed rocprofv3 --pmc measurement of the same call (tools/pmc_lmhead.sh), null if absent
         traffic, traffic_src = None, None
-        tp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_lmhead_traffic.json")
-        if os.path.exists(tp):
+        import glob
+        for tp in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_lmhead_traffic.json")), reverse=True):    # newest round first
             tj = json.load(open(tp))
             if tj.get("shape_MNK") == dom["shape"]:
-                traffic, traffic_src = tj["traffic_bytes_per_launch"], "profiles/r01_lmhead_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, calibrated)"
+                traffic = tj["traffic_bytes_per_launch"]
+                traffic_src = f"profiles/{os.path.basename(tp)} (committed rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE pass of this call, calibrated; not re-measured in this run)"
+                break
         # positions that are not padding (the metric counts every position of the padded (B, T) batch; for the
         # ragged c5-mix workload the useful rate is the one over real tokens) and rows that went through the stack
         from neko_amd.policy.gato_policy import K_PAD, build_layout
@@ -255,13 +363,15 @@ def main():
         # MFMA-pipe utilisation of the same kernel from the committed SQ counter pass (tools/pmc_gemm.sh): context for
         # `frac`, which is priced against the nominal 2.5 PFLOP/s at 2.4 GHz while the chip sustains ~1.5-1.7 GHz here
         mfma_busy = None
-        cp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_step19_gemm_counters.txt")
-        if os.path.exists(cp) and D == 768:
+        cps = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_gemm_counters.txt")), reverse=True)
+        cp = cps[0] if cps else None
+        if cp and D == 768:
             import re
             mm = re.search(r"lmlogit16: .*?MFMA pipe busy ([0-9.]+) %", open(cp).read())
             mfma_busy = float(mm.group(1)) / 100 if mm else None
         out = {
-            "metric": "multimodal tokens/sec (fwd+bwd+optimizer, whole job)", "value": value, "unit": "tokens/s",
+            "metric": METRIC, "value": value, "unit": "tokens/s",
+            "value_includes": "fwd + bwd + gradient all-reduce + clip + AdamW (whole job, all GPUs)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
             "data": "synthetic",
@@ -282,7 +392,14 @@ def main():
                          "traffic_source": traffic_src, "kernel": dom["kernel"],
                          "shape_MNK": dom["shape"], "ms_per_launch": dom["ms"],
                          "mfma_pipe_busy_pmc": mfma_busy,
-                         "mfma_pipe_busy_source": "profiles/r01_step19_gemm_counters.txt (SQ_VALU_MFMA_BUSY_CYCLES)" if mfma_busy else None},
+                         "mfma_pipe_busy_source": f"profiles/{os.path.basename(cp)} (SQ_VALU_MFMA_BUSY_CYCLES)" if mfma_busy else None},
+            "roofline_step": {"bound": "mfma", "achieved": value / world * fpt / 1e12, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                              "frac": value / world * fpt / (MFMA_PEAK_TFLOPS * 1e12),
+                              "what": "executed model FLOPs of the whole step (fwd+bwd, LM head on loss rows only) / step time, per GPU"},
+            "roofline_more": time_more_kernels(B, Tlen, dropout) if D == 768 else None,
+            "rccl_ranks_seen": ranks_seen,
+            "exposed_comm_ms_per_step": exposed_comm_ms,
+            "dp_payload": (dp.payload if dp is not None else None),
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

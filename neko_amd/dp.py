@@ -22,7 +22,14 @@ import torch.distributed as dist
 
 
 class GradReducer:
-    def __init__(self, flat, bucket_bytes: int = 64 << 20, group=None):
+    def __init__(self, flat, bucket_bytes: int = 64 << 20, group=None, payload: str = "fp32"):
+        """payload: "fp32" (default: what DDP sends for the reference's fp32 master gradients) or "bf16" -- every bucket is
+        rounded to bf16 into a staging buffer, summed over the ranks in bf16 and widened back into the fp32 gradient:
+        half the bytes on each xGMI link (249 instead of 498 MB per step at 768d) for one extra rounding of each rank's
+        gradient (relative 2^-9; the sum itself is still exact to bf16 per hop).  NEKO_DP_PAYLOAD selects it in bench.py /
+        train.py."""
+        assert payload in ("fp32", "bf16"), payload
+        self.payload = payload
         self.flat = flat
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -36,6 +43,7 @@ class GradReducer:
         #: False on the accumulating micro-steps of gradient accumulation: nothing is reduced (the flat gradient keeps
         #: adding up locally) until the last micro-step, whose backward reduces every range once
         self.sync = True
+        self.model = None
 
     def broadcast_parameters(self, src: int = 0) -> None:
         """One-time parameter broadcast rank0 -> all (DDP constructor semantics)."""
@@ -89,6 +97,9 @@ class GradReducer:
         return out
 
     def _reduce(self, gname: str) -> None:
+        if self.model is not None and self.model._flat is not self.flat:
+            raise RuntimeError("GradReducer: the model's flat parameter storage was rebuilt after attach() "
+                               "(a .to() / .cuda() that really moved parameters); attach after the model is on its device")
         if self.flat.grad.is_cuda:
             from .engine import SideStream
             SideStream.join(self.flat.grad.device)      # weight gradients are produced on the side stream
@@ -99,8 +110,18 @@ class GradReducer:
         for (la, lb) in self._live_ranges(a, b):
             for s in range(la, lb, self.bucket_elems):
                 e = min(lb, s + self.bucket_elems)
-                self.handles.append(dist.all_reduce(self.flat.grad[s:e], op=dist.ReduceOp.SUM, group=self.group,
-                                                    async_op=True))
+                g = self.flat.grad[s:e]
+                if self.payload == "bf16":
+                    st = torch.empty(e - s, dtype=torch.bfloat16, device=g.device)
+                    if g.is_cuda:
+                        from . import ops
+                        ops.cast_f32_bf16(g, st)
+                    else:
+                        st.copy_(g)
+                    h = dist.all_reduce(st, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                    self.handles.append((h, st, g))
+                else:
+                    self.handles.append((dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True), None, g))
 
     def reduce_flags(self, flags: torch.Tensor) -> None:
         if self.world > 1:   # stream-ordered (NCCL: the current stream waits on the comm stream, the host does not)
@@ -108,12 +129,15 @@ class GradReducer:
 
     def finish(self) -> None:
         """Make the current stream wait for every outstanding reduction (no host block on CUDA)."""
-        for h in self.handles:
+        for h, staged, g in self.handles:
             h.wait()
+            if staged is not None:
+                g.copy_(staged)          # widen the summed bf16 payload back into the fp32 gradient (stream-ordered)
         self.handles.clear()
 
     def attach(self, model, optimizer) -> None:
         model._dp = self
+        self.model = model
         model.image_embedding._on_grads_ready = lambda: self.group_ready("image")
         optimizer.grad_scale = self.grad_scale
         optimizer.flags_reduce = self.reduce_flags

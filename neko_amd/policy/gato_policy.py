@@ -244,14 +244,16 @@ class _PolicyCoreFn(torch.autograd.Function):
     """packed embeddings -> (logits | empty, loss | empty): transformer stack + LM head + masked CE."""
 
     @staticmethod
-    def forward(ctx, policy: "GatoPolicy", x, pmask, tokens, tmask, compute_loss: bool, return_logits: bool, *params):
+    def forward(ctx, policy: "GatoPolicy", x, pmask, tokens, tmask, compute_loss: bool, return_logits: bool, pack, *params):
+        """pack: the `_PackInfo` of the `_tokenize` call that produced (x, tokens, tmask, pmask) in THIS forward, or None
+        when the caller handed the four tensors in (kwargs form, gato_policy.py:161-165): the loss positions are then
+        derived from the masks that were passed, as the reference does (:176-183)."""
         need = bool(compute_loss) and any(ctx.needs_input_grad)   # grad mode is off inside Function.forward
         f = policy._flat
         f.ensure_shadow()
         B, T, d = x.shape
         sp = policy.transformer._stack_params()
-        rg = policy._ragged
-        segments = rg[1] if (rg is not None and tokens is not None and tokens.data_ptr() == rg[0]) else None
+        segments = pack.segments if pack is not None else None
         hf16, _, sctx = engine.stack_forward(sp, x.detach().to(torch.float32), pmask, save=need,
                                              drops=policy.transformer.make_drops(), segments=segments)
         hp = policy._head_params()
@@ -261,9 +263,8 @@ class _PolicyCoreFn(torch.autograd.Function):
         ctx.sel_idx = None
         if compute_loss:
             target, sel, count = engine.shift_targets(tokens, tmask, pmask)
-            cached = policy._loss_rows_for(tokens)
-            if cached is not None and policy.lm_head_selected_rows:
-                idx, n = cached
+            if pack is not None and pack.n_loss > 0 and policy.lm_head_selected_rows:
+                idx, n = pack.loss_idx, pack.n_loss
                 loss, hf16, dlogits = engine.lm_head_loss_selected(hp, hf16, target, idx, n, want_grad=need,
                                                                    chunk_rows=policy.lm_head_chunk_rows)
                 ctx.sel_idx, ctx.sel_n = idx, n
@@ -302,6 +303,16 @@ class _PolicyCoreFn(torch.autograd.Function):
         f.attach_grads(names)
         ctx.sctx = ctx.hf16 = ctx.dlogits = None
         return (None, gx.view(B, T, d)) + (None,) * (len(ctx.needs_input_grad) - 2)
+
+
+class _PackInfo:
+    """What the host knows about a batch it has just packed: the loss positions (row (b, t) is selected when position t
+    is real and position t+1 is a target, gato_policy.py:176-183) as a device index list, and the length buckets of the
+    ragged layout.  Handed from `_tokenize` to the policy core of the SAME forward call, never cached across calls."""
+    __slots__ = ("loss_idx", "n_loss", "segments", "order", "rows")
+
+    def __init__(self, loss_idx, n_loss, segments, order, rows):
+        self.loss_idx, self.n_loss, self.segments, self.order, self.rows = loss_idx, n_loss, segments, order, rows
 
 
 class _StubTokenizer:
@@ -414,8 +425,7 @@ class GatoPolicy(nn.Module):
         #: buckets instead of left-padding every example to the longest one (misc/todo.md:11);
         #: 0 = the reference's layout.  Same loss and gradients, fewer padded positions through the stack.
         self.ragged_groups = int(os.environ.get("NEKO_RAGGED_GROUPS", "0"))
-        self._ragged = None
-        self._loss_rows = None
+        self.last_pack: Optional[_PackInfo] = None      # statistics of the last packed batch (bench / logging only)
         self._dp = None
         self._hp = None
         self._flat: Optional[FlatParams] = None
@@ -439,13 +449,22 @@ class GatoPolicy(nn.Module):
         self._hp = None
 
     def _apply(self, fn, *a, **k):
-        # .to()/.cuda()/.float() re-materialise parameters: rebuild the flat storage afterwards
+        """.to() / .cuda() / .float(): a call that leaves every parameter where it is (the usual `model.to(device)`
+        after construction, train.py:106, accelerator.prepare) keeps the flat storage -- optimisers, gradient reducers
+        and captured decode graphs hold pointers into it.  A call that really moves or converts parameters rebuilds
+        the storage; objects built on the old one (NekoAdamW, GradReducer) then refuse to run."""
         super()._apply(fn, *a, **k)
-        if getattr(self, "_flat", None) is not None:
+        f = getattr(self, "_flat", None)
+        if f is None:
+            return self
+        intact = all(p.device == f.device and p.dtype == torch.float32 and p.data_ptr() == f.view(n).data_ptr()
+                     for n, p in f.param_of.items())
+        if not intact:
             dev = next(self.parameters()).device
-            if dev != self._flat.device:
-                self.device = dev
+            self.device = dev
             self._flatten(dev)
+            self._decoders = {}          # captured graphs point into the old storage
+            self.last_pack = None
         return self
 
     def _frontend_names(self) -> List[str]:
@@ -460,14 +479,6 @@ class GatoPolicy(nn.Module):
                                          w=self._flat.sview("predict_token.weight", padded_rows=self.Vpad),
                                          g_w=self._flat.gview("predict_token.weight", padded_rows=self.Vpad))
         return self._hp
-
-    def _loss_rows_for(self, tokens):
-        """(idx int32 device tensor, n) of the loss positions if `tokens` is the tensor the last
-        tokenize_input_dicts() produced (host-known selection), else None."""
-        c = getattr(self, "_loss_rows", None)
-        if c is None or tokens is None or tokens.data_ptr() != c[0] or tokens.numel() != c[1] or c[3] == 0:
-            return None
-        return c[2], c[3]
 
     @property
     def module(self):
@@ -496,7 +507,7 @@ class GatoPolicy(nn.Module):
 
     def _tokenize(self, inputs: list, ragged_groups: int):
         """tokenize_input_dicts, optionally in the length-bucketed layout: returns (x, tokens, target masks, pad masks,
-        segments) -- (B,T,.) tensors and None, or (1,M,.) tensors and [(row0, B_k, T_k)]."""
+        pack info) -- (B,T,.) tensors, or (1,M,.) tensors with pack.segments = [(row0, B_k, T_k)]."""
         dev = self._dev()
         if dev.type != "cuda":
             raise RuntimeError("neko_amd.GatoPolicy computes on the GPU only (no CPU fallback)")
@@ -533,9 +544,9 @@ class GatoPolicy(nn.Module):
             selm[r0:r0 + Bk * Tk] = sk.reshape(-1)
         sel_idx = np.flatnonzero(selm).astype(np.int32)
         idx_dev = self.image_embedding._upload(torch.from_numpy(sel_idx if sel_idx.size else np.zeros(1, np.int32)), dev)
-        self._loss_rows = (tokens.data_ptr(), B * T, idx_dev, int(sel_idx.size))
-        self._ragged = (tokens.data_ptr(), pb.segments, pb.order) if pb.segments is not None else None
-        return x.view(B, T, d), tokens.view(B, T), tmask.view(B, T), pmask.view(B, T), pb.segments
+        pack = _PackInfo(idx_dev, int(sel_idx.size), pb.segments, pb.order, B * T)
+        self.last_pack = pack
+        return x.view(B, T, d), tokens.view(B, T), tmask.view(B, T), pmask.view(B, T), pack
 
     # ---- forward (gato_policy.py:156-192) -------------------------------------------------------------
     def forward(self, inputs: Optional[list] = None, compute_loss=False, **kwargs):
@@ -544,8 +555,9 @@ class GatoPolicy(nn.Module):
             # length-bucketed layout: only when no (B, T, V) logits tensor has to be handed back (the training call,
             # trainer.py:178 discards them) -- the loss and every gradient are those of the padded layout
             ragged = self.ragged_groups if (compute_loss and not return_logits and len(inputs) > 1) else 0
-            token_embeddings, tokens, token_target_masks, token_masks, _ = self._tokenize(inputs, ragged)
+            token_embeddings, tokens, token_target_masks, token_masks, pack = self._tokenize(inputs, ragged)
         else:
+            pack = None
             assert ("token_embeddings" in kwargs and "tokens" in kwargs and "token_target_masks" in kwargs
                     and "token_masks" in kwargs), "if inputs is None, must provide embeddings, tokens, and masks"
             token_embeddings = kwargs["token_embeddings"]
@@ -559,15 +571,16 @@ class GatoPolicy(nn.Module):
         names = self.transformer._param_names() + ["predict_token.weight"]
         params = [self._flat.param_of[n] for n in names]
         logits, loss = _PolicyCoreFn.apply(self, token_embeddings, token_masks.to(torch.float32), tokens,
-                                           token_target_masks, bool(compute_loss), bool(return_logits), *params)
+                                           token_target_masks, bool(compute_loss), bool(return_logits), pack, *params)
         return (logits if return_logits else None), (loss if compute_loss else None)
 
-    # ---- inference helpers (gato_policy.py:434-614): same loops, full forward per token -----------------
+    # ---- inference helpers (gato_policy.py:434-470, 477-544, 556-614) ----------------------------------------------
     # KV-cached decode.  The reference re-runs the whole forward for every generated token;
-    # with kv_cache=True (default) only the new positions go through the stack (engine.KVDecoder) and the LM head
-    # runs on the last row only.  Semantics are the reference's, including the sliding window: once context_len
-    # positions are in flight the window is truncated on the left and RE-PRIMED (every remaining row recomputed
-    # without the dropped ones, exactly what the full forward does).  kv_cache=False keeps the full-forward loops.
+    # here only the new positions go through the stack (engine.KVDecoder) and the LM head runs on the last row only.
+    # Semantics are the reference's, including the sliding window: once context_len positions are in flight the
+    # window is truncated on the left and RE-PRIMED (every remaining row recomputed without the dropped ones, exactly
+    # what a full forward over the truncated window computes).  Pinned by fixture G12 (tests/golden/
+    # make_fixture_decode.py: the reference's own predict_text / predict_response / predict_control outputs).
     def _decode_tokens(self, token_embeddings, n_tokens, start_token, end_token, deterministic):
         """Autoregressive continuation of ONE unpadded sequence.  Returns (logits (n_tokens, end-start+1) fp32,
         list of 0-d token tensors in the global vocabulary)."""
@@ -626,52 +639,18 @@ class GatoPolicy(nn.Module):
         return torch.stack(all_logits, dim=0), tokens
 
     @torch.no_grad()
-    def predict_text(self, batch_dict, max_length=20, deterministic=True, kv_cache=True):
+    def predict_text(self, batch_dict, max_length=20, deterministic=True):
         start_token, end_token = self.token_starts["text"], self.token_ends["text"]
-        token_embeddings, _, _, token_masks = self.tokenize_input_dicts([batch_dict])
-        if kv_cache:
-            return self._decode_tokens(token_embeddings, max_length, start_token, end_token, deterministic)
-        concat_logits, predicted_tokens = None, []
-        for _ in range(max_length):
-            logits, _ = self.forward(token_embeddings=token_embeddings, token_masks=token_masks,
-                                     token_target_masks=None, tokens=None)
-            logits = logits[0, -1, start_token:(end_token + 1)]
-            concat_logits = logits.unsqueeze(0) if concat_logits is None else torch.cat([concat_logits, logits.unsqueeze(0)], dim=0)
-            if deterministic:
-                token = torch.argmax(logits, dim=-1)
-            else:
-                token = torch.multinomial(torch.nn.functional.softmax(logits, dim=-1), num_samples=1)[0]
-            token = token + start_token
-            token_masks = torch.cat([token_masks, torch.ones(token_masks.shape[0], 1, device=token_masks.device)], dim=1)
-            new_embedding = self._flat.view("embed_token.weight")[token]
-            token_embeddings = torch.cat([token_embeddings, new_embedding.reshape(1, 1, -1)], dim=1)
-            token_embeddings = token_embeddings[:, -self.context_len:, :]
-            token_masks = token_masks[:, -self.context_len:]
-            predicted_tokens.append(token)
-        return concat_logits, predicted_tokens
+        token_embeddings, _, _, _ = self.tokenize_input_dicts([batch_dict])
+        return self._decode_tokens(token_embeddings, max_length, start_token, end_token, deterministic)
 
     @torch.no_grad()
-    def predict_response(self, image, prompt_tokens=[], max_length=128, deterministic=True, kv_cache=True):
+    def predict_response(self, image, prompt_tokens=[], max_length=128, deterministic=True):
         start_token, end_token = self.token_starts["text"], self.token_ends["text"]
         image_embeddings = self.image_embedding(image)
-        n_images, n_patches = image_embeddings.shape[0], image_embeddings.shape[1]
-        assert n_images == 1, "number of images should always be 1 for predicting response"
-        if kv_cache:
-            return self._predict_response_cached(image_embeddings, list(prompt_tokens), max_length, start_token, end_token,
-                                                 deterministic)
-        pred_logits, response_tokens = None, []
-        for idx in range(max_length):
-            batch_dict = {"image_embeddings": image_embeddings, "text": torch.tensor(prompt_tokens + response_tokens)}
-            logits, _ = self.forward([batch_dict])
-            assert logits.shape[0] == 1, "batch size should always be 1 for predicting response"
-            nxt = logits[0, n_patches - 1 + len(prompt_tokens) + idx, start_token:(end_token + 1)]
-            if deterministic:
-                next_token = torch.argmax(nxt).item()
-            else:
-                next_token = torch.multinomial(torch.nn.functional.softmax(nxt, dim=-1), num_samples=1).item()
-            pred_logits = nxt.unsqueeze(0) if pred_logits is None else torch.cat([pred_logits, nxt.unsqueeze(0)], dim=0)
-            response_tokens.append(next_token)
-        return pred_logits, self.text_tokenizer.decode(response_tokens)
+        assert image_embeddings.shape[0] == 1, "number of images should always be 1 for predicting response"
+        return self._predict_response_cached(image_embeddings, list(prompt_tokens), max_length, start_token, end_token,
+                                             deterministic)
 
     def _predict_response_cached(self, image_embeddings, prompt_tokens, max_length, start_token, end_token, deterministic):
         """The packed sequence is [patches | prompt | response ... | SEP]: the logits of the last text position do not
@@ -711,47 +690,24 @@ class GatoPolicy(nn.Module):
                                      deterministic=deterministic)
 
     @torch.no_grad()
-    def predict_control(self, input: dict, task, deterministic: bool = True, kv_cache: bool = True):
-        """gato_policy.py:556-614.  ``task.action_type`` is compared by class name (gymnasium is not a dependency)."""
+    def predict_control(self, input: dict, task, deterministic: bool = True):
+        """gato_policy.py:556-614: the action of ONE control example whose last timestep's action slots are padding.
+        ``task.action_type`` is compared by class name (gymnasium is not a dependency of the HIP path)."""
         kind = getattr(task.action_type, "__name__", str(task.action_type))
-        action_tokens = task.action_tokens
-        kind = "Discrete" if kind in ("Discrete", "DiscreteSpace") else kind     # neko_amd.tasks.control_task stand-in
-        if kind == "Discrete":
-            action_str = "discrete"
-            assert action_tokens == 1, "only support 1 discrete action token"
-        else:
-            action_str = "continuous"
-        start_token, end_token = self.token_starts[action_str], self.token_ends[action_str]
-        if action_str == "discrete":
+        discrete = kind in ("Discrete", "DiscreteSpace")                      # neko_amd.tasks.control_task stand-in
+        n_tok = task.action_tokens
+        space = "discrete" if discrete else "continuous"
+        first, last = self.token_starts[space], self.token_ends[space]
+        if discrete:
+            assert n_tok == 1, "only support 1 discrete action token"
             assert task.env.action_space.n <= self.discrete_tokens, "discrete action space too large for model"
-            end_token = start_token + task.env.action_space.n - 1
-        token_embeddings, _, _, token_masks = self.tokenize_input_dicts([input])
-        token_embeddings = token_embeddings[:, :-action_tokens, :]
-        token_masks = token_masks[:, :-action_tokens]
-        predicted_tokens = []
-        if kv_cache:       # one priming pass over the history, then one cached step per action token
-            _, predicted_tokens = self._decode_tokens(token_embeddings, action_tokens, start_token, end_token, deterministic)
-            if kind == "Discrete":
-                return predicted_tokens[0] - start_token
-            return self.continuous_action_tokenizer.decode(torch.stack(predicted_tokens, dim=0))
-        for _ in range(action_tokens):
-            logits, _ = self.forward(token_embeddings=token_embeddings.contiguous(), token_masks=token_masks.contiguous(),
-                                     token_target_masks=None, tokens=None)
-            logits = logits[0, -1, start_token:(end_token + 1)]
-            if deterministic:
-                token = torch.argmax(logits, dim=-1)
-            else:
-                token = torch.multinomial(torch.nn.functional.softmax(logits, dim=-1), num_samples=1)[0]
-            token = token + start_token
-            token_masks = torch.cat([token_masks, torch.ones(token_masks.shape[0], 1, device=token_masks.device)], dim=1)
-            new_embedding = self._flat.view("embed_token.weight")[token]
-            token_embeddings = torch.cat([token_embeddings, new_embedding.reshape(1, 1, -1)], dim=1)
-            token_embeddings = token_embeddings[:, -self.context_len:, :]
-            token_masks = token_masks[:, -self.context_len:]
-            predicted_tokens.append(token)
-        if kind == "Discrete":
-            return predicted_tokens[0] - start_token
-        return self.continuous_action_tokenizer.decode(torch.stack(predicted_tokens, dim=0))
+            last = first + task.env.action_space.n - 1
+        emb = self.tokenize_input_dicts([input])[0][:, :-n_tok, :]           # history without the padded action slots
+        # one priming pass over the history, then one cached step per action token
+        _, chosen = self._decode_tokens(emb, n_tok, first, last, deterministic)
+        if discrete:
+            return chosen[0] - first
+        return self.continuous_action_tokenizer.decode(torch.stack(chosen, dim=0))
 
 
 class _PackEmbedV2(torch.autograd.Function):

@@ -127,8 +127,8 @@ def build_parser() -> argparse.ArgumentParser:
             p.add_argument(name, action="store_true", default=default)
         elif str(f.type).startswith("List"):
             p.add_argument(name, nargs="+", default=default)
-        elif "Optional" in str(f.type):
-            p.add_argument(name, default=default)
+        elif "Optional" in str(f.type):      # Optional[int] -> int, Optional[str] -> str (a bare default=None would leave '5' a string)
+            p.add_argument(name, type=int if "int" in str(f.type) else str, default=default)
         else:
             p.add_argument(name, type=type(default), default=default)
     return p
@@ -136,4 +136,19 @@ def build_parser() -> argparse.ArgumentParser:
 
 def parse_args(argv=None) -> TrainingArgs:
     ns = build_parser().parse_args(argv)
-    return TrainingArgs(**vars(ns))
+    args = TrainingArgs(**vars(ns))
+    check_supported(args)
+    return args
+
+
+def check_supported(args: TrainingArgs) -> None:
+    """The HIP path computes on the MI355X with bf16 MFMA operands and fp32 accumulation, nothing else: flags that ask
+    for another device or precision (reference: `--cpu` train.py:41, `--mixed_precision no|fp16` arguments.py:22) are
+    refused loudly instead of being accepted and ignored."""
+    if args.cpu or str(args.device).startswith("cpu"):
+        raise SystemExit("neko_amd: --cpu / --device cpu is not supported -- the HIP path has no CPU fallback "
+                         "(the reference's CPU run is what oracle/ restates for the parity tests)")
+    if args.mixed_precision != "bf16":
+        raise SystemExit(f"neko_amd: --mixed_precision {args.mixed_precision} is not supported -- the kernels use bf16 MFMA "
+                         "operands with fp32 accumulation, statistics, residual stream, gradients and optimiser state "
+                         "(= the reference's `--mixed_precision bf16`); pass --mixed_precision bf16 or drop the flag")

@@ -40,6 +40,12 @@ class NekoAdamW(torch.optim.Optimizer):
         self.grad_scale: Optional[torch.Tensor] = None    # set by the DP reducer (1/world)
         self.flags_reduce = None                          # DP: callable(active tensor) -> union over ranks
 
+    def _check_storage(self):
+        if self.model._flat is not self.flat:
+            raise RuntimeError("NekoAdamW: the model's flat parameter storage was rebuilt after this optimiser was created "
+                               "(a .to() / .cuda() that really moved or converted parameters); build the optimiser after "
+                               "the model is on its device")
+
     # which ranges received gradients this step (host knowledge: param.grad attached by the backward)
     def _active_groups(self):
         f = self.flat
@@ -53,6 +59,7 @@ class NekoAdamW(torch.optim.Optimizer):
     def clip_grad_norm_(self, max_norm: float) -> torch.Tensor:
         """Like ``accelerator.clip_grad_norm_(model.parameters(), max_norm)`` (trainer.py:182): computes the global
         L2 norm now (device scalar, returned without sync) and applies the clip inside the next ``step()``."""
+        self._check_storage()
         f = self.flat
         act = self._active_groups()
         self.gnorm_sq.zero_()
@@ -73,6 +80,7 @@ class NekoAdamW(torch.optim.Optimizer):
 
     @torch.no_grad()
     def step(self, closure=None):
+        self._check_storage()
         f = self.flat
         grp = self.param_groups[0]
         lr, (b1, b2), eps, wd = grp["lr"], grp["betas"], grp["eps"], grp["weight_decay"]

@@ -78,6 +78,11 @@ class Trainer:
                         res = task.evaluate(self.model, num_examples_to_test=self.args.eval_text_num_examples,
                                             deterministic=self.args.eval_mode == "deterministic",
                                             log_examples_to_output=self.args.eval_text_log_examples)
+                    elif getattr(task, "kind", "") in ("caption", "vqa") and hasattr(task, "dataset"):   # trainer.py:113-122
+                        k = task.kind
+                        res = task.evaluate(self.model, num_examples_to_test=getattr(self.args, f"eval_{k}_num_examples"),
+                                            deterministic=self.args.eval_mode == "deterministic",
+                                            log_examples_to_output=getattr(self.args, f"eval_{k}_log_examples"))
                     else:
                         res = task.evaluate(self.model)
                     for k, v in res.items():

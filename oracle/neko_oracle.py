@@ -13,8 +13,8 @@ import this module.  The product path (``neko_amd``) never imports it and has no
 PARITY PIN: the reference has no tests/golden vectors for this path,
 so this oracle is pinned against fixtures produced by importing the reference itself in the
 build container: ``tests/golden/make_fixtures.py`` -> ``tests/golden/*.pt``; checked by
-``tests/test_oracle_golden.py`` (and, when /root/reference is present, live against the
-imported reference by ``tests/test_oracle_vs_reference.py``).
+``tests/test_oracle_golden.py`` (fixtures G1-G12; every generator script under
+``tests/golden/make_fixture*.py`` re-runs the imported reference when /root/reference is present).
 
 Floating-point gradients come from torch autograd over these differentiable functions.
 ``bf16=True`` arguments emulate the HIP kernels' rounding points (bf16 GEMM operands and

@@ -2,6 +2,7 @@
 of gato/tasks/control_task.py:104-176): prompt from the end of a stored episode, one predict_control call per
 environment step (KV-cached), context trimmed to whole timesteps.  The sampler itself is pinned bit-exactly against
 the reference on the CPU (tests/test_host_cpu.py, fixture G9); here the loop runs on the GPU with toy environments."""
+import os
 import types
 
 import numpy as np
@@ -63,13 +64,18 @@ def test_continuous_rollout_with_prompt_and_window_trim():
     assert res == {"mean_return": pytest.approx(1.5 * 7), "mean_episode_len": 7.0}
     acts = np.stack(env.actions)
     assert acts.shape == (7, 2) and np.isfinite(acts).all() and (np.abs(acts) <= 1.0).all()
-    # the cached decode and the reference's full-forward loop pick the same action tokens
+    # the captured-graph decode and the eager cached decode pick the same action tokens (both are pinned to the
+    # reference's predict_control by fixture G12, tests/test_decode_gpu.py)
     np.random.seed(1)
     d = task.sample_batch_configurable(1, DEV, [1.0], ["end"], max_tokens=40, ep_ids=task.top_ids)[0]
     with torch.no_grad():
-        a_kv = m.predict_control(d, task=task, deterministic=True, kv_cache=True)
-        a_full = m.predict_control(d, task=task, deterministic=True, kv_cache=False)
-    assert torch.equal(a_kv, a_full)
+        a_graph = m.predict_control(d, task=task, deterministic=True)
+        os.environ["NEKO_DECODE_GRAPH"] = "0"
+        try:
+            a_eager = m.predict_control(d, task=task, deterministic=True)
+        finally:
+            os.environ.pop("NEKO_DECODE_GRAPH")
+    assert torch.equal(a_graph, a_eager)
     with torch.no_grad():
         res0 = task.evaluate(m, n_iterations=1, promptless_eval=True)
     assert res0["mean_episode_len"] == 7.0

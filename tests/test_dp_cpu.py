@@ -16,7 +16,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, results, declare=False):
+def _worker(rank, world, port, results, declare=False, payload="fp32"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -25,7 +25,7 @@ def _worker(rank, world, port, results, declare=False):
         torch.manual_seed(100 + rank)            # different initial weights per rank
         m = GatoPolicy("cpu", 64, 2, 2, 0.0, resid_mid_channels=128, context_len=32, text_tokenizer=64)
         flat = m._flat
-        dp = GradReducer(flat, bucket_bytes=64 * 1024)      # small buckets: several slices per range
+        dp = GradReducer(flat, bucket_bytes=64 * 1024, payload=payload)      # small buckets: several slices per range
         dp.broadcast_parameters()
         if declare:                 # control-only run: the 64 text rows of the token embedding never see a gradient
             dp.declare_unused_rows("embed_token.weight", 0, m.text_tokens)
@@ -49,7 +49,11 @@ def _worker(rank, world, port, results, declare=False):
         dp.reduce_flags(flags)
         gathered = [torch.zeros_like(local) for _ in range(world)]
         dist.all_gather(gathered, local)
-        expect = sum(gathered)
+        if payload == "bf16":       # each rank's gradient is rounded to bf16, summed in bf16, widened back
+            expect = sum(t.to(torch.bfloat16) for t in gathered).to(torch.float32)
+            expect[flat.group_ranges["never"][0]:] = local[flat.group_ranges["never"][0]:]
+        else:
+            expect = sum(gathered)
         na, nb = flat.group_ranges["never"]
         if declare:                 # the declared slice is left alone (local values), everything around it is summed
             o, n, shape = flat.offsets["embed_token.weight"]
@@ -69,14 +73,14 @@ def _worker(rank, world, port, results, declare=False):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("declare", [False, True])
-def test_grad_reducer_world2_gloo(declare):
+@pytest.mark.parametrize("declare,payload", [(False, "fp32"), (True, "fp32"), (False, "bf16"), (True, "bf16")])
+def test_grad_reducer_world2_gloo(declare, payload):
     world = 2
     port = _free_port()
     ctx = mp.get_context("spawn")
     with ctx.Manager() as mgr:
         results = mgr.dict()
-        procs = [ctx.Process(target=_worker, args=(r, world, port, results, declare)) for r in range(world)]
+        procs = [ctx.Process(target=_worker, args=(r, world, port, results, declare, payload)) for r in range(world)]
         for p in procs:
             p.start()
         for p in procs:
@@ -87,3 +91,26 @@ def test_grad_reducer_world2_gloo(declare):
             assert res["ok_sum"] and res["ok_never"] and res["same_w"], res
             assert res["flags"] == [1, 1, 1]          # union over ranks of "range took part in this step"
             assert abs(res["scale"] - 0.5) < 1e-12    # averaging folded into the optimiser's gradient scale
+
+
+def test_bench_gpus_flag_spawns_the_ranks():
+    """`python bench.py --gpus 2` with no launcher in the environment must start 2 rank processes itself (VERDICT r01:
+    the flag used to be parsed and ignored), rendezvous on 127.0.0.1 and run a real collective; `--gpus` that
+    disagrees with an existing WORLD_SIZE is an error.  NEKO_BENCH_LAUNCH_CHECK=1 stops after the collective (gloo, no GPU)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["NEKO_BENCH_LAUNCH_CHECK"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout            # ONE JSON line, from rank 0
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["world_size"] == 2
+    env["WORLD_SIZE"] = "4"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True,
+                       text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=4" in r.stderr

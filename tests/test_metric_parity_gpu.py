@@ -1,0 +1,112 @@
+"""Policy-level parity AT THE SHAPES THAT CARRY THE METRIC: the HIP policy (through the C ABI) against the CPU oracle
+(`O.loss_and_grads`, fp32) on the same weights and the same seeded multimodal batch, eval-mode patch positions,
+dropout 0 (gato/policy/gato_policy.py:156-192).
+
+  * M        768d x 6L x 24H (hd = 32), V = 52305, T = 1024, B = 3 = `metric_mix_batch(3)`: one caption-like
+             example (256 patches + 767 ids + SEP), one left-padded 42 x 24 control example, one left-padded 26 x 38 Atari
+             example -- the 256^2 GEMM tile rules, the split-K weight gradients, the LM-head chunking and the loss-row
+             selection at V = 52305 all run here;
+  * C5 geom  2048d x 16H (hd = 128, streaming attention kernels), 2 layers, V = 52305, T = 1024, same batch;
+  * hd = 64  512d x 8H, 2 layers, small vocabulary, mixed ragged batch.
+
+Gates (SURVEY.md 8(d), bf16 MFMA operands with fp32 accumulation): loss 1e-3 relative, sub-sampled logits 2e-2 of the
+logits scale, every per-parameter gradient L2 norm 2e-2 relative, total gradient norm 5e-3 relative."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import neko_oracle as O  # noqa: E402
+
+DEV = "cuda"
+
+
+def _cpu_batch(batch):
+    out = []
+    for ex in batch:
+        out.append({k: (v.detach().cpu().to(torch.float32) if torch.is_tensor(v) and v.dtype == torch.uint8
+                        else (v.detach().cpu() if torch.is_tensor(v) else v)) for k, v in ex.items()})
+    return out
+
+
+def _dev_batch(batch):
+    return [{k: (v.to(DEV) if torch.is_tensor(v) and v.dtype != torch.uint8 else v) for k, v in ex.items()} for ex in batch]
+
+
+def _compare(cfg: O.OracleConfig, batch, seed: int, row_stride: int, loss_tol=1e-3, logit_tol=2e-2, gn_tol=2e-2,
+             total_tol=5e-3):
+    from neko_amd.policy.gato_policy import GatoPolicy
+    torch.set_num_threads(max(1, min(64, torch.get_num_threads())))
+    sd = O.init_state_dict(cfg, seed)
+    m = GatoPolicy(DEV, cfg.embed_dim, cfg.layers, cfg.heads, 0.0, resid_mid_channels=128, context_len=cfg.context_len,
+                   text_tokenizer=cfg.text_tokens)
+    m.transformer.drop.p = 0.0
+    r = m.load_state_dict(sd, strict=True)
+    assert not r.missing_keys and not r.unexpected_keys
+    m.eval()                                        # deterministic patch positions on both sides
+    logits, loss = m(_dev_batch(batch), compute_loss=True)
+    loss.backward()
+    torch.cuda.synchronize()
+    sub = logits[:, ::row_stride, :].detach().float().cpu()
+    del logits
+    loss_ref, logits_ref, grads_ref = O.loss_and_grads(sd, cfg, _cpu_batch(batch))
+    lrel = abs(float(loss) - float(loss_ref)) / abs(float(loss_ref))
+    sub_ref = logits_ref[:, ::row_stride, :]
+    lerr = float((sub - sub_ref).abs().max() / sub_ref.abs().max())
+    named = dict(m.named_parameters())
+    worst, sq, sq_ref = (0.0, None), 0.0, 0.0
+    for k, gref in grads_ref.items():
+        g = named[k].grad
+        if gref is None:
+            assert g is None, k
+            continue
+        assert g is not None, k
+        gn, rn = float(g.float().norm()), float(gref.norm())
+        sq += gn * gn
+        sq_ref += rn * rn
+        if k.endswith("c_attn.bias"):
+            continue        # its K third has a mathematically zero gradient: what is left there is rounding noise
+        rel = abs(gn - rn) / max(rn, 1e-12)
+        if rel > worst[0]:
+            worst = (rel, k)
+    trel = abs(math.sqrt(sq) - math.sqrt(sq_ref)) / math.sqrt(sq_ref)
+    print(f"[parity {cfg.embed_dim}d x {cfg.layers}L x {cfg.heads}H V={cfg.vocab_size}] loss {float(loss):.6f} vs {float(loss_ref):.6f} "
+          f"(rel {lrel:.2e}); logits {lerr:.2e}; worst grad norm {worst[0]:.2e} ({worst[1]}); total norm {trel:.2e}")
+    assert lrel < loss_tol, (float(loss), float(loss_ref))
+    assert lerr < logit_tol, lerr
+    assert worst[0] < gn_tol, worst
+    assert trel < total_tol, trel
+    # direction too, not only length: a few whole gradients against the oracle's
+    for k in ("transformer.h.0.attn.c_attn.weight", f"transformer.h.{cfg.layers - 1}.mlp.c_proj.weight",
+              "transformer.ln_f.weight", "image_embedding.post_embedding_projection.weight", "separator_token"):
+        if grads_ref.get(k) is None:
+            continue
+        a, b = named[k].grad.detach().float().cpu().reshape(-1), grads_ref[k].reshape(-1)
+        cos = float(torch.dot(a, b) / (a.norm() * b.norm()).clamp(min=1e-20))
+        assert cos > 0.999, (k, cos)
+
+
+def test_metric_shape_768d_6L_hd32_vs_oracle():
+    from neko_amd.tasks import synthetic as S
+    cfg = O.OracleConfig(embed_dim=768, layers=6, heads=24)
+    _compare(cfg, S.metric_mix_batch(3, 5, "cpu"), seed=11, row_stride=37)
+
+
+def test_c5_geometry_2048d_hd128_vs_oracle():
+    from neko_amd.tasks import synthetic as S
+    cfg = O.OracleConfig(embed_dim=2048, layers=2, heads=16)
+    _compare(cfg, S.metric_mix_batch(3, 6, "cpu"), seed=12, row_stride=53)
+
+
+def test_hd64_512d_vs_oracle():
+    cfg = O.OracleConfig(embed_dim=512, layers=2, heads=8, text_tokens=1000, context_len=512)
+    g = torch.Generator().manual_seed(3)
+    batch = [{"text": torch.randint(0, 1000, (383,), generator=g).tolist()},
+             {"continuous_obs": torch.randn(13, 17, generator=g), "continuous_actions": torch.rand(13, 6, generator=g) * 2 - 1},
+             {"images": torch.floor(torch.rand(9, 3, 96, 96, generator=g) * 256),
+              "discrete_actions": torch.randint(0, 4, (9, 1), generator=g).to(torch.int32)},
+             {"images": torch.floor(torch.rand(1, 3, 64, 96, generator=g) * 256),
+              "text": torch.randint(0, 1000, (100,), generator=g).tolist()}]
+    _compare(cfg, batch, seed=13, row_stride=7)

@@ -163,3 +163,22 @@ def test_g8_geglu_oracle_matches_reference(golden):
         loss, gn = O.train_step(sd3, cfg3, st, t["batches"][step % len(t["batches"])], lr, 1.0)
         assert abs(loss - t["trace"]["loss"][step]) < 1e-4 * abs(t["trace"]["loss"][step]), (step, loss)
         assert abs(gn - t["trace"]["grad_norm"][step]) < 1e-3 * t["trace"]["grad_norm"][step], (step, gn)
+
+
+@pytest.mark.parametrize("name", ["text_short", "text_sliding_window", "text_128d", "text_geglu"])
+def test_g12_oracle_reproduces_reference_decode_logits(golden, name):
+    """Fixture G12 holds what the reference's own predict_text returned (gato_policy.py:434-470).  The oracle has no
+    decode loop; teacher-forcing the reference's tokens through its forward must give the same logits rows and
+    arg-maxes: the window is [prompt ids + SEP | embed_token rows of the chosen tokens], truncated on the left to
+    context_len, and the row of interest is always the last one."""
+    c = next(x for x in golden("g12_decode")["cases"] if x["name"] == name)
+    cfg = O.OracleConfig(**c["cfg"])
+    sd = O.init_state_dict(cfg, c["weight_seed"])
+    emb, _, _, mask = O.tokenize_input_dicts(sd, cfg, [{"text": list(c["prompt"])}])
+    lo, hi = 0, cfg.text_tokens - 1
+    for i, tok in enumerate(c["tokens"]):
+        hidden = O.transformer_forward(sd, cfg, emb, torch.ones(emb.shape[:2]))
+        row = O.lm_head(sd, hidden[:, -1])[0, lo:hi + 1]
+        assert torch.allclose(row, c["logits"][i], rtol=1e-4, atol=2e-5), (name, i)
+        assert int(torch.argmax(row)) + lo == tok
+        emb = torch.cat([emb, sd["embed_token.weight"][tok].reshape(1, 1, -1)], dim=1)[:, -cfg.context_len:]

@@ -3,8 +3,8 @@ fixtures captured from the imported reference (tests/golden/*.pt) and against th
 seeded inputs.
 
 Tolerances (bf16 MFMA operands, fp32 accumulation/statistics; SURVEY.md 8(d) parity gates):
-  tokens / masks: bit-exact;  fp32 gathers: 1e-6;  hidden states / logits: 3e-2 of the tensor scale;
-  loss: 2e-3 relative (one batch), 100-step trace: see test;  per-parameter grad norms: 5e-2 relative.
+  tokens / masks: bit-exact;  fp32 gathers: 1e-6;  hidden states / logits: 2e-2 of the tensor scale;
+  loss: 1e-3 relative (one batch), 100-step trace: see test;  per-parameter grad norms: 2e-2 relative.
 """
 import math
 
@@ -95,7 +95,7 @@ def test_g5_transformer(golden, name):
     ref = f["last_hidden_state"]
     assert out.shape == ref.shape
     valid = f["mask"].bool()
-    assert relerr(out.cpu()[valid], ref[valid]) < 3e-2
+    assert relerr(out.cpu()[valid], ref[valid]) < 2e-2
     # padded query rows follow the reference's finite -1e4 semantics too
     assert relerr(out, ref) < 5e-2
 
@@ -106,8 +106,8 @@ def test_g6_logits_loss_grads(golden):
     m, _ = make_policy(cfg, f["seed"])
     logits, loss = m(to_dev(f["batch"]), compute_loss=True)
     assert tuple(logits.shape) == f["logits_shape"]
-    assert relerr(logits[:, ::f["row_stride"], :], f["logits_rows"]) < 3e-2
-    assert abs(float(loss) - f["loss"]) < 2e-3 * abs(f["loss"]), (float(loss), f["loss"])
+    assert relerr(logits[:, ::f["row_stride"], :], f["logits_rows"]) < 2e-2
+    assert abs(float(loss) - f["loss"]) < 1e-3 * abs(f["loss"]), (float(loss), f["loss"])
     loss.backward()
     named = dict(m.named_parameters())
     sq = 0.0
@@ -121,12 +121,12 @@ def test_g6_logits_loss_grads(golden):
         sq += gn * gn
         if k.endswith("c_attn.bias"):
             continue        # its K third has a mathematically zero gradient (rounding noise only)
-        assert abs(gn - n) < 5e-2 * n + 1e-6, (k, gn, n)
-    assert abs(math.sqrt(sq) - f["total_grad_norm"]) < 2e-2 * f["total_grad_norm"]
+        assert abs(gn - n) < 2e-2 * n + 1e-6, (k, gn, n)
+    assert abs(math.sqrt(sq) - f["total_grad_norm"]) < 5e-3 * f["total_grad_norm"]
     for k, gref in f["small_grads"].items():
         if k.endswith("c_attn.bias"):
             continue
-        assert relerr(named[k].grad, gref) < 8e-2, (k, relerr(named[k].grad, gref))
+        assert relerr(named[k].grad, gref) < 4e-2, (k, relerr(named[k].grad, gref))
 
 
 def test_forward_kwargs_form_and_no_logits(golden):
@@ -139,7 +139,7 @@ def test_forward_kwargs_form_and_no_logits(golden):
         none_logits, loss2 = m(to_dev(f["batch"]), compute_loss=True, return_logits=False)
         logits3, loss3 = m(token_embeddings=e, tokens=None, token_target_masks=None, token_masks=pm)
     assert none_logits is None and loss3 is None
-    assert abs(float(loss) - f["loss"]) < 2e-3 * abs(f["loss"])
+    assert abs(float(loss) - f["loss"]) < 1e-3 * abs(f["loss"])
     assert float(loss2) == float(loss)
     assert torch.equal(logits3, logits)
 
@@ -159,7 +159,7 @@ def test_bf16_emulating_oracle_is_tighter():
     ref32 = O.transformer_forward(sd, cfg, x, mask, bf16=False)
     v = mask.bool()
     e16, e32 = relerr(out.cpu()[v], ref16[v]), relerr(out.cpu()[v], ref32[v])
-    assert e16 < 1e-2 and e32 < 3e-2, (e16, e32)
+    assert e16 < 1e-2 and e32 < 2e-2, (e16, e32)
 
 
 def test_g7_training_trace(golden):

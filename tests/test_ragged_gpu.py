@@ -62,10 +62,10 @@ def test_ragged_loss_and_grads_equal_padded_layout_and_oracle(groups):
     m.ragged_groups = groups
     _, loss_rag = m(to_dev(batch), compute_loss=True, return_logits=False)
     if groups == 1:          # one bucket removes no padding: the policy keeps the reference layout (< 10 % rows saved)
-        assert m._ragged is None
+        assert m.last_pack.segments is None
     else:
-        assert m._ragged is not None and len(m._ragged[1]) == min(groups, 6)
-        assert sum(b * t for _, b, t in m._ragged[1]) < 0.9 * len(batch) * 91
+        assert m.last_pack.segments is not None and len(m.last_pack.segments) == min(groups, 6)
+        assert sum(b * t for _, b, t in m.last_pack.segments) < 0.9 * len(batch) * 91
     loss_rag.backward()
     g_rag = grads_of(m)
     assert abs(float(loss_rag) - float(loss_pad)) < 2e-6 * abs(float(loss_pad)), (float(loss_rag), float(loss_pad))
@@ -92,16 +92,16 @@ def test_ragged_is_only_used_when_no_logits_are_returned():
     batch = to_dev(ragged_batch())
     with torch.no_grad():
         logits, loss = m(batch, compute_loss=True)                    # logits requested: the reference (B, T, V) layout
-        assert m._ragged is None and tuple(logits.shape)[:2] == (len(batch), 91)
+        assert m.last_pack.segments is None and tuple(logits.shape)[:2] == (len(batch), 91)
         _, loss2 = m(batch, compute_loss=True, return_logits=False)
-        assert m._ragged is not None
+        assert m.last_pack.segments is not None
         e, t, tg, pm = m.tokenize_input_dicts(batch)                  # public packing call keeps the reference's shapes
         assert tuple(t.shape) == (len(batch), 91)
     assert abs(float(loss) - float(loss2)) < 2e-6 * abs(float(loss))
     m.pad_seq = True
     with torch.no_grad():
         m(batch, compute_loss=True, return_logits=False)
-    assert m._ragged is None                                          # pad_seq asks for context_len-wide rows
+    assert m.last_pack.segments is None                                          # pad_seq asks for context_len-wide rows
 
 
 def test_ragged_with_dropout_trains_and_masks_differ_per_bucket():
@@ -141,7 +141,7 @@ def test_g7b_trace_in_ragged_layout(golden):
     losses = []
     for step in range(f["total_steps"]):
         _, loss = m.forward(inputs=batches[step % len(batches)], compute_loss=True, return_logits=False)
-        assert m._ragged is not None and len(m._ragged[1]) == 2
+        assert m.last_pack.segments is not None and len(m.last_pack.segments) == 2
         loss.backward()
         opt.clip_grad_norm_(1.0)
         opt.step(); sch.step(); opt.zero_grad()
@@ -165,6 +165,6 @@ def test_ragged_full_size_mix_matches_padded_loss():
         _, l_pad = m(batch, compute_loss=True, return_logits=False)
         m.ragged_groups = 4
         _, l_rag = m(batch, compute_loss=True, return_logits=False)
-    rows = sum(b * t for _, b, t in m._ragged[1])
+    rows = sum(b * t for _, b, t in m.last_pack.segments)
     assert rows < 0.6 * 16 * 1024
     assert abs(float(l_rag) - float(l_pad)) < 1e-5 * abs(float(l_pad)), (float(l_rag), float(l_pad))

@@ -72,7 +72,7 @@ def test_random_batch_matches_oracle(seed):
     if not bool((tg_ref[:, 1:] * pm_ref[:, :-1]).sum() > 0):
         pytest.skip("batch without a loss position")
     _, loss = m(to_dev(batch), compute_loss=True, return_logits=False)
-    assert m._ragged is None or (groups > 0 and len(batch) > 1)      # buckets only when they save >= 10 % of the rows
+    assert m.last_pack.segments is None or (groups > 0 and len(batch) > 1)      # buckets only when they save >= 10 % of the rows
     loss.backward()
     assert abs(float(loss) - float(loss_ref)) < 2e-3 * abs(float(loss_ref)), (float(loss), float(loss_ref))
     named = dict(m.named_parameters())

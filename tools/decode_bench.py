@@ -33,8 +33,26 @@ def timeit(fn, n):
     return (time.perf_counter() - t0) / n * 1e3
 
 
-for kv in (False, True):
-    tc = timeit(lambda: m.predict_control(ex, task, kv_cache=kv), 5)
-    tt = timeit(lambda: m.predict_text(prompt, max_length=64, kv_cache=kv), 2)
-    print(f"kv_cache={kv!s:5}: predict_control (6 action tokens after 984 positions) {tc:8.2f} ms/env step   "
+def full_forward_decode(emb, n_tokens, lo, hi):
+    """The cost model of the reference's loops (gato_policy.py:446-468, 585-612): one full forward over the whole window
+    and a (T, V) logits tensor per generated token.  Bench-only baseline; parity of the cached path is fixture G12."""
+    table = m._flat.view("embed_token.weight")
+    for _ in range(n_tokens):
+        mask = torch.ones(emb.shape[:2], device=emb.device)
+        logits, _ = m.forward(token_embeddings=emb, token_masks=mask, token_target_masks=None, tokens=None)
+        tok = torch.argmax(logits[0, -1, lo:hi + 1]) + lo
+        emb = torch.cat([emb, table[tok].reshape(1, 1, -1)], dim=1)[:, -m.context_len:]
+
+
+with torch.no_grad():
+    emb_c = m.tokenize_input_dicts([ex])[0][:, :-6]
+    emb_t = m.tokenize_input_dicts([prompt])[0]
+    c0, c1 = m.token_starts["continuous"], m.token_ends["continuous"]
+    tc = timeit(lambda: full_forward_decode(emb_c, 6, c0, c1), 5)
+    tt = timeit(lambda: full_forward_decode(emb_t, 64, 0, m.token_ends["text"]), 2)
+    print(f"full forward per token: predict_control-shaped (6 action tokens after 984 positions) {tc:8.2f} ms/env step   "
+          f"predict_text-shaped (64 tokens after 900) {tt:9.1f} ms = {tt / 64:6.2f} ms/token")
+    tc = timeit(lambda: m.predict_control(ex, task), 5)
+    tt = timeit(lambda: m.predict_text(prompt, max_length=64), 2)
+    print(f"KV-cached decode      : predict_control (6 action tokens after 984 positions) {tc:8.2f} ms/env step   "
           f"predict_text (64 tokens after 900) {tt:9.1f} ms = {tt / 64:6.2f} ms/token")

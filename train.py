@@ -13,6 +13,7 @@ import sys
 from datetime import datetime
 
 os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")     # see bench.py: before the HIP runtime initialises
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC for RCCL: read when the runtime initialises
 
 import torch
 
@@ -36,7 +37,6 @@ def main(args: TrainingArgs):
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.distributed.init_process_group("nccl", device_id=dev)
     args.device = str(dev)
     exp_name = f"neko-gato_{datetime.now().strftime('%y-%m-%d_%H-%M-%S')}"
