@@ -83,9 +83,10 @@ def cpu_baseline():
     at the reference's four dropout sites), 1 warm-up + 3 timed forward+backward iterations on this box's host cores."""
     from oracle import neko_oracle as O
     hw = os.cpu_count() or 1
-    # intra-op threads: every hardware thread by default (BASELINE.md section 3); NEKO_CPU_BASELINE_THREADS overrides
-    # (profiles/r02_cpu_baseline_threads.txt holds the sweep measured on the GPU box)
-    cores = int(os.environ.get("NEKO_CPU_BASELINE_THREADS", hw))
+    # intra-op threads: BASELINE.md section 3 says every hardware thread, but on the GPU box's 256 hardware threads that
+    # is the SLOWEST setting by far (torch's fork/join per small op: 75.9 s per iteration = 27 tokens/s with 256 threads,
+    # measured r02; sweep in profiles/r02_cpu_baseline_threads.txt), so the baseline runs at the fastest measured count
+    cores = int(os.environ.get("NEKO_CPU_BASELINE_THREADS", min(hw, 32)))
     torch.set_num_threads(cores)
     cfg = O.OracleConfig(embed_dim=D, layers=L, heads=H, text_tokens=V_TEXT, context_len=T)
     sd = O.init_state_dict(cfg, 0)

@@ -274,8 +274,8 @@ struct BwdSmem {
   float dh3[3][HALO][HALO];                           // dy, zero halo
   __attribute__((aligned(16))) bf16_t im1[PS * PS * 32];   // im2col of gx       [pixel][k]
   __attribute__((aligned(16))) bf16_t im3[PS * PS * 32];   // flipped im2col of dy [pixel][q]
-  __attribute__((aligned(16))) bf16_t t2[PS * PS * 32];    // h2 tile   [pixel][32 channels of tile t]
-  __attribute__((aligned(16))) bf16_t t1[PS * PS * 32];    // d_h1 tile [pixel][32 channels of tile t]
+  __attribute__((aligned(16))) bf16_t tt[PS * PS * 32];    // [pixel][32 channels of tile t]: first the h2 tile (dW2 operand),
+                                                           // then, once those MFMAs have read it, the d_h1 tile (dW1 operand)
   __attribute__((aligned(16))) bf16_t w1[C * 32];     // [c][k], piece ^= (c>>2)&3 (bias hi/lo in columns 27/28)
   __attribute__((aligned(16))) bf16_t w2c[C * 32];    // [c][q], piece ^= (c>>2)&3
   __attribute__((aligned(16))) float red[2][8][4];    // GroupNorm statistics partials [pass][group of tile][wave]
@@ -324,7 +324,10 @@ __device__ __forceinline__ float reduce_scatter32(float (&v)[32], int l32) {
   return v[0];
 }
 
-__global__ __launch_bounds__(256, 1) void resblock_bwd_kernel(const float* __restrict__ xp, const float* __restrict__ dy,
+// Occupancy: 77 KB of LDS and <= 256 VGPRs per lane -> TWO blocks (8 waves, 2 per SIMD) per CU.  The first version kept
+// separate h2 / d_h1 tiles (93 KB: one block, one wave per SIMD per CU) and every barrier, LDS round trip and shuffle
+// chain of the per-patch dependency chain was exposed: 539 us per call at MFMA busy 3.9 % / HBM 0.9 % (r01 counters).
+__global__ __launch_bounds__(256, 2) void resblock_bwd_kernel(const float* __restrict__ xp, const float* __restrict__ dy,
                                                               int P, const float* __restrict__ w1,
                                                               const float* __restrict__ b1, const float* __restrict__ gw,
                                                               const float* __restrict__ gb, const float* __restrict__ w2,
@@ -355,11 +358,17 @@ __global__ __launch_bounds__(256, 1) void resblock_bwd_kernel(const float* __res
   if (tid < C) { s.gw[tid] = gw[tid]; s.gb[tid] = gb[tid]; }
   const float inv_n = 1.0f / (float)(CPG * PS * PS);
 
-  f32x16 dw2acc[4], dw1acc[4];     // [t]: dW2[q][32t + n], dW1[32t + m][k]
+  // Weight gradients: per channel tile t two 32x32 outputs (dW2[q][32t + n], dW1[32t + m][k]), each a contraction over the
+  // patch's 256 pixels = 16 k-steps.  Wave w owns ONE of the two outputs (wkind = w & 1: 0 dW2, 1 dW1) and HALF of the
+  // k-steps (pixels 128 * (w >> 1) ..): 4 x 16 accumulator registers per wave that live across patches.  (Each wave
+  // contracting its own 64 pixels for both outputs needed 128, which with the recompute's own 200 registers forced one
+  // wave per SIMD.)  The tiles a wave reads were written by other waves: see the barriers in channel_tile.
+  const int wkind = __builtin_amdgcn_readfirstlane(wave & 1), wkhalf = __builtin_amdgcn_readfirstlane(wave >> 1);
+  f32x16 dwacc[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { dw2acc[t][r] = 0.f; dw1acc[t][r] = 0.f; }
+    for (int r = 0; r < 16; ++r) dwacc[t][r] = 0.f;
   float b2acc[3] = {0.f, 0.f, 0.f};
 
   // next patch's pixels are requested one patch ahead (see the forward kernel)
@@ -454,44 +463,52 @@ __global__ __launch_bounds__(256, 1) void resblock_bwd_kernel(const float* __res
         }
       }
       // ---- h2 = GELU(u), du = d_h2 * GELU'(u), u = xhat*gamma + beta; per-channel sums over this lane's 2 pixels -------
-      float gwv[16], sums[32], tv[2][16];
+      // one pixel tile at a time, h2 written to the [pixel][channel] tile straight away (registers 4qq..4qq+3 are channels
+      // 8qq + 4h + {0..3}): 16 live h2 values instead of 32, and gamma / beta are re-read from LDS where needed instead
+      // of being held across the barriers -- the kernel has to fit 256 registers for two waves per SIMD
+      float sums[32];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int c = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
-        gwv[r] = s.gw[c];
-        const float gbv = s.gb[c];
-        float s1 = 0.f, s2 = 0.f;
+      for (int r = 0; r < 32; ++r) sums[r] = 0.f;
 #pragma unroll
-        for (int pt = 0; pt < 2; ++pt) {
+      for (int pt = 0; pt < 2; ++pt) {
+        float tv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int c = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
           const float xh = acc[pt][r];
-          const float u = fmaf(xh, gwv[r], gbv);
+          const float u = fmaf(xh, s.gw[c], s.gb[c]);
           float er, e;
           erf_exp_parts(u, er, e);
           const float cdf = 0.5f * (1.0f + er);
-          tv[pt][r] = u * cdf;                                                   // h2
+          tv[r] = u * cdf;                                                       // h2
           const float du = dacc[pt][r] * fmaf(u * 0.39894228040143267794f, e, cdf);
           dacc[pt][r] = du;                                                      // d(GN out)
-          s1 += du;
-          s2 = fmaf(du, xh, s2);
+          sums[r] += du;                       // kind 0: sum du      -> dbeta
+          sums[16 + r] = fmaf(du, xh, sums[16 + r]);       // kind 1: sum du*xhat -> dgamma
+          if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);     // 4 GELUs in flight at a time (register pressure)
         }
-        sums[r] = s1;            // kind 0: sum du      -> dbeta
-        sums[16 + r] = s2;       // kind 1: sum du*xhat -> dgamma
-      }
-      // h2 -> wave-private [pixel][channel] tile: registers 4qq..4qq+3 are channels 8qq + 4h + {0..3}
-#pragma unroll
-      for (int pt = 0; pt < 2; ++pt) {
         const int pix = 64 * wave + 32 * pt + l32;
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq)
-          *reinterpret_cast<uint2*>(&s.t2[pix * 32 + ((qq ^ ((pix >> 2) & 3)) << 3) + 4 * h]) =
-              make_uint2(pack_bf16x2(tv[pt][4 * qq], tv[pt][4 * qq + 1]), pack_bf16x2(tv[pt][4 * qq + 2], tv[pt][4 * qq + 3]));
+          *reinterpret_cast<uint2*>(&s.tt[pix * 32 + ((qq ^ ((pix >> 2) & 3)) << 3) + 4 * h]) =
+              make_uint2(pack_bf16x2(tv[4 * qq], tv[4 * qq + 1]), pack_bf16x2(tv[4 * qq + 2], tv[4 * qq + 3]));
       }
       {
         const float tot = reduce_scatter32(sums, l32);       // lane l32 holds index l32 = kind*16 + r
         const int r = l32 & 15;
         s.cs[wave][l32 >> 4][(r & 3) + 8 * (r >> 2) + 4 * h] = tot;
       }
-      __syncthreads();
+      __syncthreads();       // h2 tile and channel-sum partials of every wave are visible
+      // ---- dW2 += dZ^T . h2 (waves of kind 0), between the two barriers of the channel sums: after the second one the tile
+      // is free for d_h1
+      if (wkind == 0) {
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+          const bf16x8_v a4 = tr_frag32(s.im3, 128 * wkhalf, ks, lane);      // rows = q
+          const bf16x8_v b4 = tr_frag32(s.tt, 128 * wkhalf, ks, lane);       // cols = channel of tile t
+          dwacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a4, b4, dwacc[t], 0, 0, 0);
+        }
+      }
       if (tid < 64) {
         const int kind = tid >> 5, cl = tid & 31;
         const float v = (s.cs[0][kind][cl] + s.cs[1][kind][cl]) + (s.cs[2][kind][cl] + s.cs[3][kind][cl]);
@@ -499,43 +516,41 @@ __global__ __launch_bounds__(256, 1) void resblock_bwd_kernel(const float* __res
         s.acc_gn[kind == 1 ? 0 : 1][32 * t + cl] += v;       // [0] dgamma, [1] dbeta
       }
       __syncthreads();
-      // ---- d_h1 = rstd_g * (du*gamma - A_g/N - xhat*B_g/N) -> t1 tile ---------------------------------------------
+      // ---- d_h1 = rstd_g * (du*gamma - A_g/N - xhat*B_g/N) -> the tile --------------------------------------------------
 #pragma unroll
       for (int qq = 0; qq < 4; ++qq) {
-        float A = 0.f, Bv = 0.f;
+        float gm[4], A = 0.f, Bv = 0.f;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int cl = e + 8 * qq + 4 * h;
-          A = fmaf(gwv[4 * qq + e], s.cst[0][cl], A);
-          Bv = fmaf(gwv[4 * qq + e], s.cst[1][cl], Bv);
+          gm[e] = s.gw[32 * t + cl];
+          A = fmaf(gm[e], s.cst[0][cl], A);
+          Bv = fmaf(gm[e], s.cst[1][cl], Bv);
         }
         A *= inv_n;
         Bv *= inv_n;
 #pragma unroll
-        for (int pt = 0; pt < 2; ++pt)
+        for (int pt = 0; pt < 2; ++pt) {
+          const int pix = 64 * wave + 32 * pt + l32;
+          float v[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int r = 4 * qq + e;
-            tv[pt][r] = rstd[qq] * (fmaf(dacc[pt][r], gwv[r], -A) - acc[pt][r] * Bv);
+            v[e] = rstd[qq] * (fmaf(dacc[pt][r], gm[e], -A) - acc[pt][r] * Bv);
           }
+          *reinterpret_cast<uint2*>(&s.tt[pix * 32 + ((qq ^ ((pix >> 2) & 3)) << 3) + 4 * h]) =
+              make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+        }
       }
+      __syncthreads();       // d_h1 tile of every wave is visible (the next tile's h2 is written two barriers later)
+      // ---- dW1 += d_h1^T . im2col (waves of kind 1) ---------------------------------------------------------------------
+      if (wkind == 1) {
 #pragma unroll
-      for (int pt = 0; pt < 2; ++pt) {
-        const int pix = 64 * wave + 32 * pt + l32;
-#pragma unroll
-        for (int qq = 0; qq < 4; ++qq)
-          *reinterpret_cast<uint2*>(&s.t1[pix * 32 + ((qq ^ ((pix >> 2) & 3)) << 3) + 4 * h]) =
-              make_uint2(pack_bf16x2(tv[pt][4 * qq], tv[pt][4 * qq + 1]), pack_bf16x2(tv[pt][4 * qq + 2], tv[pt][4 * qq + 3]));
-      }
-      // ---- weight gradients: contraction over this wave's 64 pixels (4 k-steps of 16) --------------------------------
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const bf16x8_v a4 = tr_frag32(s.im3, 64 * wave, ks, lane);      // rows = q
-        const bf16x8_v b4 = tr_frag32(s.t2, 64 * wave, ks, lane);       // cols = channel of tile t
-        dw2acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a4, b4, dw2acc[t], 0, 0, 0);
-        const bf16x8_v a5 = tr_frag32(s.t1, 64 * wave, ks, lane);       // rows = channel of tile t
-        const bf16x8_v b5 = tr_frag32(s.im1, 64 * wave, ks, lane);      // cols = k (27: ones -> db1)
-        dw1acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a5, b5, dw1acc[t], 0, 0, 0);
+        for (int ks = 0; ks < 8; ++ks) {
+          const bf16x8_v a5 = tr_frag32(s.tt, 128 * wkhalf, ks, lane);       // rows = channel of tile t
+          const bf16x8_v b5 = tr_frag32(s.im1, 128 * wkhalf, ks, lane);      // cols = k (27: ones -> db1)
+          dwacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a5, b5, dwacc[t], 0, 0, 0);
+        }
       }
     };   // channel tile
     channel_tile(std::integral_constant<int, 0>{});
@@ -544,31 +559,30 @@ __global__ __launch_bounds__(256, 1) void resblock_bwd_kernel(const float* __res
     channel_tile(std::integral_constant<int, 3>{});
   }     // patches
 
-  // ---- block result: sum the 4 waves' accumulators through LDS (im1 is dead), one 32x32 tile at a time --------------
+  // ---- block result: the two k-halves of every output meet in LDS (im1 is dead), one channel tile at a time -----------
   __syncthreads();
-  float* scr = reinterpret_cast<float*>(s.im1);      // 4 x 1024 floats
+  float* scr = reinterpret_cast<float*>(s.im1);      // [wave][32 x 32] floats
 #pragma unroll
-  for (int t = 0; t < 4; ++t)
+  for (int t = 0; t < 4; ++t) {
 #pragma unroll
-    for (int which = 0; which < 2; ++which) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = (r & 3) + 8 * (r >> 2) + 4 * h;
-        scr[wave * 1024 + m * 32 + l32] = which ? dw1acc[t][r] : dw2acc[t][r];
-      }
-      __syncthreads();
-      for (int i = tid; i < 1024; i += 256) {
-        const float v = (scr[i] + scr[1024 + i]) + (scr[2048 + i] + scr[3072 + i]);
-        const int m = i >> 5, n = i & 31;
-        if (which == 0) {                              // dW2[q = m][c = 32t + n]
-          if (m < 27) dw2[((m / 9) * C + 32 * t + n) * 9 + (m % 9)] = v;
-        } else {                                       // dW1[c = 32t + m][k = n]; k == 27 is the ones column
-          if (n < 27) dw1[(32 * t + m) * 27 + n] = v;
-          else if (n == 27) db1[32 * t + m] = v;
-        }
-      }
-      __syncthreads();
+    for (int r = 0; r < 16; ++r) {
+      const int m = (r & 3) + 8 * (r >> 2) + 4 * h;
+      scr[wave * 1024 + m * 32 + l32] = dwacc[t][r];
     }
+    __syncthreads();
+    for (int i = tid; i < 2048; i += 256) {
+      const int which = i >> 10, e = i & 1023;             // waves (which, which + 2) hold the two halves of output `which`
+      const float v = scr[which * 1024 + e] + scr[(which + 2) * 1024 + e];
+      const int m = e >> 5, n = e & 31;
+      if (which == 0) {                              // dW2[q = m][c = 32t + n]
+        if (m < 27) dw2[((m / 9) * C + 32 * t + n) * 9 + (m % 9)] = v;
+      } else {                                       // dW1[c = 32t + m][k = n]; k == 27 is the ones column
+        if (n < 27) dw1[(32 * t + m) * 27 + n] = v;
+        else if (n == 27) db1[32 * t + m] = v;
+      }
+    }
+    __syncthreads();
+  }
   if (tid < C) {
     dgw[tid] = s.acc_gn[0][tid];
     dgb[tid] = s.acc_gn[1][tid];
@@ -669,7 +683,7 @@ int neko_patch_resblock_fwd_impl(const void* images, int images_are_u8, int n, i
 }
 
 // blocks (= partial rows) the backward uses for P patches; workspace = blocks * neko_patch_resblock_ws_stride floats
-int neko_patch_resblock_bwd_blocks_impl(int P) { return P < 256 ? (P < 1 ? 1 : P) : 256; }   // one block per CU
+int neko_patch_resblock_bwd_blocks_impl(int P) { return P < 512 ? (P < 1 ? 1 : P) : 512; }   // two blocks per CU
 int neko_patch_resblock_ws_stride_impl() { return PART_STRIDE; }
 
 int neko_patch_resblock_bwd_impl(const float* x_patches, const float* dy, int P, const float* w1, const float* b1,

@@ -140,7 +140,9 @@ def test_forward_kwargs_form_and_no_logits(golden):
         logits3, loss3 = m(token_embeddings=e, tokens=None, token_target_masks=None, token_masks=pm)
     assert none_logits is None and loss3 is None
     assert abs(float(loss) - f["loss"]) < 1e-3 * abs(f["loss"])
-    assert float(loss2) == float(loss)
+    # the kwargs form derives the loss rows from the masks it is given and runs the LM head on every row, the dict form
+    # runs it on the host-known loss rows only: same rows, different GEMM tiling -> equal to fp32 summation noise
+    assert abs(float(loss2) - float(loss)) < 2e-6 * abs(float(loss))
     assert torch.equal(logits3, logits)
 
 

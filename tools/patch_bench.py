@@ -9,7 +9,8 @@ sd = O.init_state_dict(cfg, 21)
 pe = "image_embedding.patch_embedding."
 names = ["conv1.weight", "conv1.bias", "gn2.weight", "gn2.bias", "conv2.weight", "conv2.bias"]
 dev = {n: sd[pe + n].cuda().contiguous() for n in names}
-imgs = torch.floor(torch.rand(26, 3, 96, 96) * 256).cuda()
+frames = int(sys.argv[2]) if len(sys.argv) > 2 else 26      # 286 frames = 10296 patches: the Atari share of an m-mix step
+imgs = torch.floor(torch.rand(frames, 3, 96, 96) * 256).cuda()
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 y16, xp = ops.patch_resblock_fwd(imgs, *[dev[n] for n in names], 128, 32)
 dy = torch.randn(xp.shape, device="cuda")
