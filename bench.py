@@ -158,13 +158,13 @@ def time_more_kernels(B: int, Tlen: int, dropout: float):
     qkv = (torch.randn(M, 3 * d, device="cuda") * 0.5).to(torch.bfloat16)
     kb, ks = ops.mask_bias(torch.ones(B, Tlen, device="cuda"))
     drop = ops.Drop(dropout, 12345) if dropout > 0 else None
-    o, lse = ops.attn_fwd(qkv, kb, ks, B, Tlen, H, hd, drop=drop)
+    o, lse, dmask = ops.attn_fwd(qkv, kb, ks, B, Tlen, H, hd, drop=drop, want_mask=True)      # the training call
     do = torch.randn_like(o)
-    ms = _time_events(lambda: ops.attn_fwd(qkv, kb, ks, B, Tlen, H, hd, drop=drop))
+    ms = _time_events(lambda: ops.attn_fwd(qkv, kb, ks, B, Tlen, H, hd, drop=drop, want_mask=True))
     fl = 2.0 * B * Tlen * Tlen * d
     out.append({"kernel": "attention forward (one layer)", "ms_per_launch": ms, "achieved": fl / ms / 1e9, "unit": "TFLOP/s",
                 "frac": fl / ms / 1e9 / MFMA_PEAK_TFLOPS, "bound": "mfma (hd=32: VALU-issue limited, DESIGN 4)"})
-    ms = _time_events(lambda: ops.attn_bwd(qkv, o, do, kb, ks, lse, B, Tlen, H, hd, drop=drop))
+    ms = _time_events(lambda: ops.attn_bwd(qkv, o, do, kb, ks, lse, B, Tlen, H, hd, drop=drop, mask=dmask))
     out.append({"kernel": "attention backward (one layer)", "ms_per_launch": ms, "achieved": 2.5 * fl / ms / 1e9,
                 "unit": "TFLOP/s", "frac": 2.5 * fl / ms / 1e9 / MFMA_PEAK_TFLOPS, "bound": "mfma"})
     a = torch.randn(M, d, device="cuda").to(torch.bfloat16)

@@ -33,7 +33,7 @@ extern "C" {
 #define NEKO_ERR_UNSUPPORTED (-2)
 #define NEKO_ERR_LAUNCH (-3)
 
-#define NEKO_ABI_VERSION 9
+#define NEKO_ABI_VERSION 10
 
 int neko_abi_version(void);
 /* human-readable text for a return code (static storage) */
@@ -102,14 +102,20 @@ int neko_layernorm_bwd_bf16dy(const uint16_t* dy, const float* x, const float* g
  *   Two schedules compute the same sums: head-resident kernels (hd = 32, T <= 1024: one workgroup per (b, h) keeps
  *   the head's K/V or Q/dO in LDS) and streaming kernels (any T, hd).  neko_attn_set_path(0) = automatic (default),
  *   (1) = always streaming; returns the previous mode (any other argument only queries).  Process-wide tuning knob.
+ *   drop_mask (optional, only touched when drop_thr > 0): neko_attn_mask_dwords(B, T, H, hd) uint32 of device memory
+ *   (0 = the schedule in use does not exchange masks: pass null).  The forward stores its keep decisions there (scalar
+ *   stores of the compares' lane masks) and the backward of the SAME forward call applies them instead of re-hashing
+ *   every element in both of its kernels; with null both directions hash -- identical decisions either way.
  * ------------------------------------------------------------------------------------------- */
 int neko_attn_set_path(int mode);
 int neko_mask_bias(const float* mask, float* kbias, int* kstart, int B, int T, void* stream);
+long neko_attn_mask_dwords(int B, int T, int H, int hd);
 int neko_attn_fwd(const uint16_t* qkv, const float* kbias, const int* kstart, uint16_t* out, float* lse, int B,
-                  int T, int H, int hd, int drop_thr, unsigned drop_key, float drop_scale, void* stream);
+                  int T, int H, int hd, int drop_thr, unsigned drop_key, float drop_scale, uint32_t* drop_mask,
+                  void* stream);
 int neko_attn_bwd(const uint16_t* qkv, const uint16_t* out, const uint16_t* dout, const float* kbias,
                   const int* kstart, const float* lse, float* D, int* qflags, uint16_t* dqkv, int B, int T, int H,
-                  int hd, int drop_thr, unsigned drop_key, float drop_scale, void* stream);
+                  int hd, int drop_thr, unsigned drop_key, float drop_scale, const uint32_t* drop_mask, void* stream);
 
 /* Skinny-M (M <= 8, K <= 3072) companion of neko_gemm_bf16 for incremental decode: a pure weight stream instead of
  * the tiled MFMA loop.  y[M,N] = x[M,K] . W (+ bias[N]) (act 1 = GELU on the bf16-rounded pre-activation) (+ resid),

@@ -25,9 +25,10 @@ SIGNATURES = {
     "neko_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, C.c_uint, _f, _vp],
     "neko_layernorm_bwd_bf16dy": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, C.c_uint, _f, _vp],
     "neko_mask_bias": [_vp, _vp, _vp, _i, _i, _vp],
-    "neko_attn_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, C.c_uint, _f, _vp],
+    "neko_attn_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, C.c_uint, _f, _vp, _vp],
+    "neko_attn_mask_dwords": [_i, _i, _i, _i],
     "neko_attn_set_path": [_i],
-    "neko_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, C.c_uint, _f, _vp],
+    "neko_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, C.c_uint, _f, _vp, _vp],
     "neko_gemv_bf16": [_vp, _l, _vp, _l, _i, _i, _i, _i, _vp, _vp, _l, _i, _vp, _l, _vp, _l, _vp],
     "neko_attn_decode": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "neko_ce_fwd_bwd": [_vp, _l, _i, _i, _vp, _vp, _vp, _vp, _l, _i, _vp],
@@ -74,6 +75,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)       # AttributeError if the library lacks a declared symbol
         fn.argtypes = args
         fn.restype = _i
+    lib.neko_attn_mask_dwords.restype = C.c_long
     lib.neko_status_string.argtypes = [_i]
     lib.neko_status_string.restype = C.c_char_p
     _lib = lib

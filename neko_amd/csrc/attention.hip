@@ -739,10 +739,10 @@ int fwd_launch(const bf16_t* qkv, const float* kbias, const int* kstart, bf16_t*
 template <int HD>
 int bwd_launch(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const float* kbias, const int* kstart,
                const float* lse, float* D, int* qflags, bf16_t* dqkv, int B, int T, int H, int thr, unsigned key,
-               float dscale, hipStream_t s) {
+               float dscale, const uint32_t* dmask, hipStream_t s) {
   const float scale = 1.0f / sqrtf((float)HD);
   if (neko_attn_path_mode() == 0 && neko_attn_res_applicable(T, HD))
-    return neko_attn_bwd_res_impl(qkv, out, dout, kbias, kstart, lse, dqkv, B, T, H, thr, key, dscale, s);
+    return neko_attn_bwd_res_impl(qkv, out, dout, kbias, kstart, lse, dqkv, B, T, H, thr, key, dscale, dmask, s);
   const long total = (long)B * T * H;
   hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, out, dout, kbias, D,
                      qflags, B, T, H, HD, thr ? 1.0f / dscale : 1.0f);
@@ -777,12 +777,17 @@ int neko_attn_set_path_impl(int mode) {
   return prev;
 }
 
+// dwords of the dropout keep-mask buffer neko_attn_fwd fills for neko_attn_bwd (0: the schedule in use re-hashes instead)
+long neko_attn_mask_dwords_impl(int B, int T, int H, int hd) {
+  return g_attn_path == 0 ? neko_attn_res_mask_dwords(B, T, H, hd) : 0;
+}
+
 int neko_attn_fwd_impl(const bf16_t* qkv, const float* kbias, const int* kstart, bf16_t* out, float* lse, int B, int T,
-                       int H, int hd, int drop_thr, unsigned drop_key, float drop_scale, hipStream_t s) {
+                       int H, int hd, int drop_thr, unsigned drop_key, float drop_scale, uint32_t* dmask, hipStream_t s) {
   if (B <= 0 || T <= 0) return NEKO_OK;
   if (!qkv || !kbias || !out || !lse || H <= 0 || drop_thr < 0 || drop_thr > 255) return NEKO_ERR_ARG;
   if (g_attn_path == 0 && neko_attn_res_applicable(T, hd))
-    return neko_attn_fwd_res_impl(qkv, kbias, kstart, out, lse, B, T, H, drop_thr, drop_key, drop_scale, s);
+    return neko_attn_fwd_res_impl(qkv, kbias, kstart, out, lse, B, T, H, drop_thr, drop_key, drop_scale, dmask, s);
   switch (hd) {
     case 32: return fwd_launch<32>(qkv, kbias, kstart, out, lse, B, T, H, drop_thr, drop_key, drop_scale, s);
     case 64: return fwd_launch<64>(qkv, kbias, kstart, out, lse, B, T, H, drop_thr, drop_key, drop_scale, s);
@@ -794,16 +799,16 @@ int neko_attn_fwd_impl(const bf16_t* qkv, const float* kbias, const int* kstart,
 // workspace: D fp32 [B*H*T] and qflags int32 [B*ceil(T/64)]
 int neko_attn_bwd_impl(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const float* kbias, const int* kstart,
                        const float* lse, float* D, int* qflags, bf16_t* dqkv, int B, int T, int H, int hd,
-                       int drop_thr, unsigned drop_key, float drop_scale, hipStream_t s) {
+                       int drop_thr, unsigned drop_key, float drop_scale, const uint32_t* dmask, hipStream_t s) {
   if (B <= 0 || T <= 0) return NEKO_OK;
   if (!qkv || !out || !dout || !kbias || !lse || !D || !qflags || !dqkv || H <= 0) return NEKO_ERR_ARG;
   switch (hd) {
     case 32: return bwd_launch<32>(qkv, out, dout, kbias, kstart, lse, D, qflags, dqkv, B, T, H, drop_thr, drop_key,
-                                   drop_scale, s);
+                                   drop_scale, dmask, s);
     case 64: return bwd_launch<64>(qkv, out, dout, kbias, kstart, lse, D, qflags, dqkv, B, T, H, drop_thr, drop_key,
-                                   drop_scale, s);
+                                   drop_scale, dmask, s);
     case 128: return bwd_launch<128>(qkv, out, dout, kbias, kstart, lse, D, qflags, dqkv, B, T, H, drop_thr, drop_key,
-                                   drop_scale, s);
+                                   drop_scale, dmask, s);
     default: return NEKO_ERR_UNSUPPORTED;
   }
 }

@@ -73,6 +73,39 @@ __device__ __forceinline__ uint32_t quad_bcast(uint32_t x, int i) {   // value o
     default: return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0xFF, 0xf, 0xf, true);
   }
 }
+// ---- dropout keep decisions computed ONCE (forward) and reused by both backward kernels ------------------------------
+// The forward kernel's compare "hash byte >= threshold" for accumulator register r lands in an SGPR pair: a 64-bit lane
+// mask whose low word is {keep(query q0 + l, key k0 + c(r))}_l and whose high word is the same for key k0 + c(r) + 4
+// (c(r) = (r & 3) + 8 (r >> 2)).  Those 16 pairs = 32 dwords per 32 x 32 sub-tile are written with scalar stores
+// (s_store_dwordx4: wave-uniform data never touches a VGPR) to   mask[(b*H + h)][query block][key block][32]   and
+//   * dQ (same lane = query geometry) reads them back with scalar loads and applies each as the SGPR-pair operand of ONE
+//     v_cndmask_b32 -- instead of 10 VALU per hash word + compare + select per element;
+//   * dK/dV (lane = key) loads, per lane, the dword of ITS key (bits = the 32 queries of the block) and tests bit
+//     c(r) + 4 (lane / 32) with one v_bfe_i32 per register.
+// tools/probe/sstore_probe.hip checks the scalar-store / scalar-load round trip across kernels on gfx950.
+typedef uint32_t u32x4_s __attribute__((ext_vector_type(4)));
+// loads through the constant address space with a wave-uniform address are always scalar loads (s_load_dwordx*); through a
+// plain global pointer hipcc only selects them when it can prove that no store of the kernel may alias
+typedef __attribute__((address_space(4))) const unsigned long long const_u64;
+__device__ __forceinline__ const void* uniform_ptr(const void* p) {
+  const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+  return reinterpret_cast<const void*>(((uintptr_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32)) << 32) |
+                                       (uintptr_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a));
+}
+// two lane masks -> 16 bytes at base + OFF (base wave-uniform, in SGPRs)
+template <int OFF>
+__device__ __forceinline__ void sstore_masks(uint32_t* base, unsigned long long m0, unsigned long long m1) {
+  const u32x4_s q = {(uint32_t)m0, (uint32_t)(m0 >> 32), (uint32_t)m1, (uint32_t)(m1 >> 32)};
+  asm volatile("s_store_dwordx4 %0, %1, %2" ::"s"(q), "s"(base), "n"(OFF) : "memory");
+}
+// position of key `kl` (0..31) of a sub-tile inside its 32 dwords: pair r = (kl & 3) + 4 (kl >> 3), half (kl >> 2) & 1
+__device__ __forceinline__ int mask_slot_of_key(int kl) { return 2 * ((kl & 3) + 4 * (kl >> 3)) + ((kl >> 2) & 1); }
+// x where the lane's bit of the 64-bit lane mask is set, else 0: ONE v_cndmask with the mask as its SGPR-pair operand
+__device__ __forceinline__ float keep_lanes(float x, unsigned long long lane_mask) {
+  float r;
+  asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(x), "s"(lane_mask));
+  return r;
+}
 // workgroup id -> (batch*H + head): ids n and n+8 run on the same XCD and get heads 2p and 2p+1
 __device__ __forceinline__ int pair_remap(int n, int total) {
   const int full = total & ~15;
@@ -159,11 +192,12 @@ __device__ __forceinline__ uint32_t pad_mask_of(const float* __restrict__ kb, in
 // =====================================================================================================
 // forward
 // =====================================================================================================
-template <bool DROP>
+template <bool DROP, bool MASK>
 __global__ __launch_bounds__(1024) void attn_fwd_res_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ kbias,
                                                             const int* __restrict__ kstart, bf16_t* __restrict__ out,
                                                             float* __restrict__ lse, int B, int T, int H, float scale,
-                                                            uint32_t drop_thr, uint32_t drop_key, float drop_scale) {
+                                                            uint32_t drop_thr, uint32_t drop_key, float drop_scale,
+                                                            uint32_t* __restrict__ dmask) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int Tp = (T + 31) & ~31, nblk = Tp >> 5;
   char* imgK = smem;
@@ -226,38 +260,76 @@ __global__ __launch_bounds__(1024) void attn_fwd_res_kernel(const bf16_t* __rest
           st[r] = (c <= lim_len) ? v : -INFINITY;
         }
       }
-      float mx = fmaxf(st[0], st[1]);
-#pragma unroll
-      for (int r = 2; r < 16; ++r) mx = fmaxf(mx, st[r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float sc = interior ? scale2 : 1.0f;      // interior scores are still unscaled
-      // lazy rescale (see attention.hip): the running maximum only moves when some row's maximum grew by more than 2^8
-      const float cand = mx * sc;
-      if (__builtin_amdgcn_ballot_w64(cand > m_run + 8.0f) != 0) {
-        const float m_new = fmaxf(m_run, cand);
+      // Online softmax WITHOUT a row maximum per sub-tile: the exponentials are taken against the running reference
+      // m_run first, and only when some lane's partial sum shows that a score climbed more than ~2^8 above it (or m_run
+      // is still -inf: first sub-tile of the row, the sum is inf / NaN) the wave computes the row maxima, moves m_run,
+      // rescales and redoes the exponentials.  Softmax is shift invariant, so any reference that keeps the terms inside
+      // the fp32 range gives the same result; the 16-way max chain, the lane^32 exchange and the compare that used to
+      // run for EVERY sub-tile (~15 VALU + one LDS round trip of ~125) now run for the first sub-tile of a row and
+      // after rare jumps.  The two halves of a row (lanes l, l^32) must share m_run: the decision is a wave ballot.
+      f32x16 pr;
+      float ps0 = 0.f, ps1 = 0.f;
+      bool renorm = kbk == kb_beg;                     // first sub-tile of the rows: m_run is still -inf
+      if (!renorm) {
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          pr[r] = exp2_fast(fmaf(st[r], sc, -m_run));
+          pr[r + 1] = exp2_fast(fmaf(st[r + 1], sc, -m_run));
+          ps0 += pr[r];
+          ps1 += pr[r + 1];
+        }
+        renorm = __builtin_amdgcn_ballot_w64(!((ps0 + ps1) < 256.0f)) != 0;
+      }
+      if (renorm) {
+        float mx = fmaxf(st[0], st[1]);
+#pragma unroll
+        for (int r = 2; r < 16; ++r) mx = fmaxf(mx, st[r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx * sc);
         const float alpha = exp2_fast(m_run - m_new);   // 2^(-inf) = 0 on the first tile
         l_run *= alpha;
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[r] *= alpha;
         m_run = m_new;
-      }
-      float ps0 = 0.f, ps1 = 0.f;
+        ps0 = 0.f;
+        ps1 = 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; r += 2) {
-        st[r] = exp2_fast(fmaf(st[r], sc, -m_run));
-        st[r + 1] = exp2_fast(fmaf(st[r + 1], sc, -m_run));
-        ps0 += st[r];
-        ps1 += st[r + 1];
+        for (int r = 0; r < 16; r += 2) {
+          pr[r] = exp2_fast(fmaf(st[r], sc, -m_run));
+          pr[r + 1] = exp2_fast(fmaf(st[r + 1], sc, -m_run));
+          ps0 += pr[r];
+          ps1 += pr[r + 1];
+        }
       }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[r] = pr[r];
       l_run += ps0 + ps1;
       if (DROP) {   // attn_dropout on the probabilities (trajectory_gpt2.py:179): the normaliser stays undropped
         const uint32_t g0 = ((uint32_t)(b * H + h) * (uint32_t)T + (uint32_t)q) * (uint32_t)((T + 3) >> 2) +
                             (uint32_t)((k0 + 4 * (lane >> 5)) >> 2);
+        unsigned long long km[16];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {          // registers 4j..4j+3 = keys +8j .. +8j+3: one word
           const uint32_t w = drop_word(g0 + 2 * j, drop_key);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) st[4 * j + e] = drop_byte_keep(w, e, drop_thr) ? st[4 * j + e] : 0.f;
+          for (int e = 0; e < 4; ++e) {
+            const bool keep = drop_byte_keep(w, e, drop_thr);
+            if (MASK) km[4 * j + e] = __builtin_amdgcn_ballot_w64(keep);     // the compare's own SGPR pair
+            st[4 * j + e] = keep ? st[4 * j + e] : 0.f;
+          }
+        }
+        if (MASK) {     // the sub-tile's 16 lane masks -> mask[(b*H+h)][qb][kbk][32 dwords], 8 scalar stores
+          uint32_t* mp = const_cast<uint32_t*>(static_cast<const uint32_t*>(
+              uniform_ptr(dmask + (((long)hb * nblk + qb) * nblk + kbk) * 32)));
+          sstore_masks<0>(mp, km[0], km[1]);
+          sstore_masks<16>(mp, km[2], km[3]);
+          sstore_masks<32>(mp, km[4], km[5]);
+          sstore_masks<48>(mp, km[6], km[7]);
+          sstore_masks<64>(mp, km[8], km[9]);
+          sstore_masks<80>(mp, km[10], km[11]);
+          sstore_masks<96>(mp, km[12], km[13]);
+          sstore_masks<112>(mp, km[14], km[15]);
         }
       }
 #pragma unroll
@@ -279,17 +351,20 @@ __global__ __launch_bounds__(1024) void attn_fwd_res_kernel(const bf16_t* __rest
       if (lane < 32) lse[((long)b * H + h) * T + q] = m_run * LN2 + __logf(l_tot);
     }
   }
+  if (DROP && MASK)   // scalar stores sit in the scalar data cache until written back
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_dcache_wb\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
 // =====================================================================================================
 // backward dQ: lanes own queries (same geometry as forward); images K and V
 // =====================================================================================================
-template <bool DROP>
+template <bool DROP, bool MASK>
 __global__ __launch_bounds__(768) void attn_dq_res_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                            const float* __restrict__ kbias, const int* __restrict__ kstart,
                                                            const float* __restrict__ lse, const bf16_t* __restrict__ outp,
                                                            bf16_t* __restrict__ dqkv, int B, int T, int H, float scale,
-                                                           uint32_t drop_thr, uint32_t drop_key, float drop_scale) {
+                                                           uint32_t drop_thr, uint32_t drop_key, float drop_scale,
+                                                           const uint32_t* __restrict__ dmask) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int Tp = (T + 31) & ~31, nblk = Tp >> 5;
   char* imgK = smem;
@@ -341,6 +416,13 @@ __global__ __launch_bounds__(768) void attn_dq_res_kernel(const bf16_t* __restri
 #pragma unroll
     for (int r = 0; r < 16; ++r) dq[r] = 0.f;
 
+    // lane masks of the forward's keep decisions for this query block, one sub-tile (16 x 64 bit, scalar loads) ahead
+    const const_u64* mrow = reinterpret_cast<const const_u64*>(reinterpret_cast<uintptr_t>(
+        (DROP && MASK) ? uniform_ptr(dmask + ((long)hb * nblk + qb) * nblk * 32) : nullptr));
+    unsigned long long mcur[16], mnext[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mcur[r] = (DROP && MASK) ? mrow[kb_beg * 16 + r] : 0ull;
+
 #pragma unroll 1
     for (int kbk = kb_beg; kbk < kb_end; ++kbk) {
       const int k0 = kbk * 32;
@@ -352,6 +434,13 @@ __global__ __launch_bounds__(768) void attn_dq_res_kernel(const bf16_t* __restri
         st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(imgK, k0, ks, lane), qf[ks], st, 0, 0, 0);
         dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(imgV, k0, ks, lane), dof[ks], dpt, 0, 0, 0);
       }
+      if (DROP && MASK) {       // behind the operand reads of this sub-tile: the loads have a whole sub-tile to land
+        __builtin_amdgcn_sched_barrier(0);
+        const int kn = min(kbk + 1, kb_end - 1);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mnext[r] = mrow[kn * 16 + r];
+        __builtin_amdgcn_sched_barrier(0);
+      }
       // dS^T = P^T o (keep*dP^T - D/s); zero where the score was REPLACED by the causal constant
       const uint32_t g0 = ((uint32_t)(b * H + h) * (uint32_t)T + (uint32_t)q) * (uint32_t)((T + 3) >> 2) +
                           (uint32_t)((k0 + 4 * (lane >> 5)) >> 2);
@@ -360,13 +449,13 @@ __global__ __launch_bounds__(768) void attn_dq_res_kernel(const bf16_t* __restri
         const float nlse = -my_lse;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const uint32_t w = DROP ? drop_word(g0 + 2 * j, drop_key) : 0u;
+          const uint32_t w = (DROP && !MASK) ? drop_word(g0 + 2 * j, drop_key) : 0u;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int r = 4 * j + e;
             const float pv = exp2_fast(fmaf(st[r], scale2, nlse));
             float dpe = dpt[r];
-            if (DROP) dpe = drop_byte_keep(w, e, drop_thr) ? dpe : 0.f;
+            if (DROP) dpe = MASK ? keep_lanes(dpe, mcur[r]) : (drop_byte_keep(w, e, drop_thr) ? dpe : 0.f);
             st[r] = pv * (dpe - my_D);
           }
         }
@@ -375,7 +464,7 @@ __global__ __launch_bounds__(768) void attn_dq_res_kernel(const bf16_t* __restri
         const int lim_len = T - 1 - k0 - 4 * (lane >> 5);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const uint32_t w = DROP ? drop_word(g0 + 2 * j, drop_key) : 0u;
+          const uint32_t w = (DROP && !MASK) ? drop_word(g0 + 2 * j, drop_key) : 0u;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int r = 4 * j + e;
@@ -384,10 +473,14 @@ __global__ __launch_bounds__(768) void attn_dq_res_kernel(const bf16_t* __restri
             const float sv = ldsKb[k0 + c + 4 * (lane >> 5)] + (causal_ok ? st[r] * scale2 : MASK_VAL * LOG2E);
             const float pv = exp2_fast((c <= lim_len) ? sv - my_lse : -INFINITY);      // select, not a branch: 2^-inf = 0
             float dpe = dpt[r];
-            if (DROP) dpe = drop_byte_keep(w, e, drop_thr) ? dpe : 0.f;
+            if (DROP) dpe = MASK ? keep_lanes(dpe, mcur[r]) : (drop_byte_keep(w, e, drop_thr) ? dpe : 0.f);
             st[r] = causal_ok ? pv * (dpe - my_D) : 0.f;
           }
         }
+      }
+      if (DROP && MASK) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mcur[r] = mnext[r];
       }
       // dQ^T += K^T . dS^T
 #pragma unroll
@@ -413,12 +506,13 @@ __global__ __launch_bounds__(768) void attn_dq_res_kernel(const bf16_t* __restri
 // =====================================================================================================
 // backward dK/dV: lanes own keys; images Q and dO, per-query lse and D in LDS
 // =====================================================================================================
-template <bool DROP>
+template <bool DROP, bool MASK>
 __global__ __launch_bounds__(768) void attn_dkv_res_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                             const float* __restrict__ kbias, const float* __restrict__ lse,
                                                             const bf16_t* __restrict__ outp, bf16_t* __restrict__ dqkv, int B,
                                                             int T, int H, float scale, uint32_t drop_thr,
-                                                            uint32_t drop_key, float drop_scale) {
+                                                            uint32_t drop_key, float drop_scale,
+                                                            const uint32_t* __restrict__ dmask) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int Tp = (T + 31) & ~31, nblk = Tp >> 5;
   char* imgQ = smem;
@@ -488,11 +582,23 @@ __global__ __launch_bounds__(768) void attn_dkv_res_kernel(const bf16_t* __restr
     for (int r = 0; r < 16; ++r) { dk[r] = 0.f; dv[r] = 0.f; }
     const int ksh = 8 * (lane & 3);
 
+    // query blocks this key block meets: the masked-and-live ones below the diagonal (qactive), then every block from the
+    // diagonal on.  next_qb() is wave-uniform scalar work; the dropout mask dword of the NEXT visited block (this lane's
+    // key, 32 query bits) is requested one sub-tile ahead.
+    auto next_qb = [&](int from) {
+      int nq = from;
+      while (nq < kbw && !((qactive >> nq) & 1)) ++nq;
+      return nq;
+    };
+    const uint32_t* mcol = (DROP && MASK) ? dmask + ((long)hb * nblk * nblk + kbw) * 32 + mask_slot_of_key(lane & 31) : nullptr;
+    int qb = next_qb(0);
+    uint32_t wnext = (DROP && MASK && qb < nblk) ? mcol[(long)qb * nblk * 32] : 0u;
 #pragma unroll 1
-    for (int qb = 0; qb < nblk; ++qb) {
-      // wave-uniform skip: no query of the block sees a key of this wave causally and none is a masked row
-      if (qb < kbw && !((qactive >> qb) & 1)) continue;
+    while (qb < nblk) {
       const int q0 = qb * 32;
+      const int qb_next = next_qb(qb + 1);
+      const uint32_t wsh = wnext >> (4 * (lane >> 5));          // bit c(r): keep(query q0 + c(r) + 4 (lane / 32), this key)
+      if (DROP && MASK) wnext = mcol[(long)min(qb_next, nblk - 1) * nblk * 32];
       f32x16 st, dpt;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { st[r] = 0.f; dpt[r] = 0.f; }
@@ -504,7 +610,7 @@ __global__ __launch_bounds__(768) void attn_dkv_res_kernel(const bf16_t* __restr
       // dropout words: rows of this sub-tile are registers, the 4 lanes of a quad own the 4 keys of one group -> lane
       // (key & 3) = i hashes rows 4j + i and the quad shares the 16 words by DPP
       uint32_t mine[4] = {0u, 0u, 0u, 0u};
-      if (DROP) {
+      if (DROP && !MASK) {
         const uint32_t gq = ((uint32_t)(b * H + h) * (uint32_t)T + (uint32_t)(q0 + 4 * (lane >> 5) + (lane & 3))) * T4 +
                             (uint32_t)(key >> 2);
 #pragma unroll
@@ -522,9 +628,15 @@ __global__ __launch_bounds__(768) void attn_dkv_res_kernel(const bf16_t* __restr
           const float pv = exp2_fast(fmaf(st[r], scale2, -lse_q));
           float pd = pv, dpe = dpt[r];
           if (DROP) {
-            const bool keep = __builtin_amdgcn_ubfe(quad_bcast(mine[r >> 2], r & 3), ksh, 8) >= drop_thr;
-            pd = keep ? pv : 0.f;
-            dpe = keep ? dpe : 0.f;
+            if (MASK) {
+              const uint32_t km = (uint32_t)__builtin_amdgcn_sbfe((int)wsh, c, 1);      // all ones where kept
+              pd = __uint_as_float(__float_as_uint(pv) & km);
+              dpe = __uint_as_float(__float_as_uint(dpe) & km);
+            } else {
+              const bool keep = __builtin_amdgcn_ubfe(quad_bcast(mine[r >> 2], r & 3), ksh, 8) >= drop_thr;
+              pd = keep ? pv : 0.f;
+              dpe = keep ? dpe : 0.f;
+            }
           }
           st[r] = pd;
           dpt[r] = pv * (dpe - d_q);
@@ -541,9 +653,15 @@ __global__ __launch_bounds__(768) void attn_dkv_res_kernel(const bf16_t* __restr
           const float pv = exp2_fast((c <= lim_len && kvalid) ? sv - lse_q : -INFINITY);        // select: 2^-inf = 0
           float pd = pv, dpe = dpt[r];
           if (DROP) {
-            const bool keep = __builtin_amdgcn_ubfe(quad_bcast(mine[r >> 2], r & 3), ksh, 8) >= drop_thr;   // word of row r
-            pd = keep ? pv : 0.f;
-            dpe = keep ? dpe : 0.f;
+            if (MASK) {
+              const uint32_t km = (uint32_t)__builtin_amdgcn_sbfe((int)wsh, c, 1);
+              pd = __uint_as_float(__float_as_uint(pv) & km);
+              dpe = __uint_as_float(__float_as_uint(dpe) & km);
+            } else {
+              const bool keep = __builtin_amdgcn_ubfe(quad_bcast(mine[r >> 2], r & 3), ksh, 8) >= drop_thr;   // word of row r
+              pd = keep ? pv : 0.f;
+              dpe = keep ? dpe : 0.f;
+            }
           }
           st[r] = pd;                                              // dropped P (for dV)
           dpt[r] = causal_ok ? pv * (dpe - d_q) : 0.f;             // dS        (for dK)
@@ -554,6 +672,7 @@ __global__ __launch_bounds__(768) void attn_dkv_res_kernel(const bf16_t* __restr
         dv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(imgdO, q0, s2, lane), frag_from_acc(st, s2), dv, 0, 0, 0);
         dk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(imgQ, q0, s2, lane), frag_from_acc(dpt, s2), dk, 0, 0, 0);
       }
+      qb = qb_next;
     }
 
     // P and dP were masked but not scaled in the loop (D holds D/s): the survivor scale s is applied once, here
@@ -587,46 +706,58 @@ int allow_lds(K kernel, size_t bytes) {
 
 bool neko_attn_res_applicable(int T, int hd) { return hd == 32 && T >= 1 && T <= 1024; }
 
+// dwords of the dropout keep-mask buffer the head-resident kernels exchange (0 when they do not apply)
+long neko_attn_res_mask_dwords(int B, int T, int H, int hd) {
+  if (!neko_attn_res_applicable(T, hd)) return 0;
+  const long nblk = (T + 31) / 32;
+  return (long)B * H * nblk * nblk * 32;
+}
+
 int neko_attn_fwd_res_impl(const bf16_t* qkv, const float* kbias, const int* kstart, bf16_t* out, float* lse, int B, int T,
-                           int H, int drop_thr, unsigned drop_key, float drop_scale, hipStream_t s) {
+                           int H, int drop_thr, unsigned drop_key, float drop_scale, uint32_t* dmask, hipStream_t s) {
   const int Tp = (T + 31) & ~31, nblk = Tp / 32, nw = min(16, (nblk + 1) / 2);
   const size_t lds = (size_t)Tp * 128 + (size_t)Tp * 4 + 16;
   const float scale = 1.0f / sqrtf(32.0f);
-  static const int once = allow_lds(attn_fwd_res_kernel<true>, 160 * 1024) | allow_lds(attn_fwd_res_kernel<false>, 160 * 1024);
+  static const int once = allow_lds(attn_fwd_res_kernel<true, true>, 160 * 1024) | allow_lds(attn_fwd_res_kernel<true, false>, 160 * 1024) |
+                          allow_lds(attn_fwd_res_kernel<false, false>, 160 * 1024);
   if (once != NEKO_OK) return once;
-  if (drop_thr)
-    hipLaunchKernelGGL((attn_fwd_res_kernel<true>), dim3(B * H), dim3(64 * nw), lds, s, qkv, kbias, kstart, out, lse, B, T, H,
-                       scale, (uint32_t)drop_thr, drop_key, drop_scale);
+  if (drop_thr && dmask)
+    hipLaunchKernelGGL((attn_fwd_res_kernel<true, true>), dim3(B * H), dim3(64 * nw), lds, s, qkv, kbias, kstart, out, lse, B, T,
+                       H, scale, (uint32_t)drop_thr, drop_key, drop_scale, dmask);
+  else if (drop_thr)
+    hipLaunchKernelGGL((attn_fwd_res_kernel<true, false>), dim3(B * H), dim3(64 * nw), lds, s, qkv, kbias, kstart, out, lse, B, T,
+                       H, scale, (uint32_t)drop_thr, drop_key, drop_scale, nullptr);
   else
-    hipLaunchKernelGGL((attn_fwd_res_kernel<false>), dim3(B * H), dim3(64 * nw), lds, s, qkv, kbias, kstart, out, lse, B, T, H,
-                       scale, 0u, drop_key, drop_scale);
+    hipLaunchKernelGGL((attn_fwd_res_kernel<false, false>), dim3(B * H), dim3(64 * nw), lds, s, qkv, kbias, kstart, out, lse, B, T,
+                       H, scale, 0u, drop_key, drop_scale, nullptr);
   NEKO_CHECK_LAUNCH();
   return NEKO_OK;
 }
 
-// D = sum dO.O is formed inside both kernels (the D / qflags workspace of the streaming path is not touched)
+// D = sum dO.O is formed inside both kernels (the D / qflags workspace of the streaming path is not touched).
+// dmask: the keep masks the forward call of the same (qkv, drop_key) wrote, or null (the kernels re-hash the decisions).
 int neko_attn_bwd_res_impl(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const float* kbias, const int* kstart,
                            const float* lse, bf16_t* dqkv, int B, int T, int H, int drop_thr, unsigned drop_key,
-                           float drop_scale, hipStream_t s) {
+                           float drop_scale, const uint32_t* dmask, hipStream_t s) {
   const int Tp = (T + 31) & ~31, nblk = Tp / 32, nw = min(12, (nblk + 1) / 2);
   const size_t lds_q = (size_t)Tp * 128 + (size_t)Tp * 4 + 16, lds_kv = (size_t)Tp * 128 + (size_t)Tp * 8 + 16;
   const float scale = 1.0f / sqrtf(32.0f);
-  static const int once = allow_lds(attn_dq_res_kernel<true>, 160 * 1024) | allow_lds(attn_dq_res_kernel<false>, 160 * 1024) |
-                          allow_lds(attn_dkv_res_kernel<true>, 160 * 1024) | allow_lds(attn_dkv_res_kernel<false>, 160 * 1024);
+  static const int once = allow_lds(attn_dq_res_kernel<true, true>, 160 * 1024) | allow_lds(attn_dq_res_kernel<true, false>, 160 * 1024) |
+                          allow_lds(attn_dq_res_kernel<false, false>, 160 * 1024) | allow_lds(attn_dkv_res_kernel<true, true>, 160 * 1024) |
+                          allow_lds(attn_dkv_res_kernel<true, false>, 160 * 1024) | allow_lds(attn_dkv_res_kernel<false, false>, 160 * 1024);
   if (once != NEKO_OK) return once;
-  if (drop_thr) {
-    hipLaunchKernelGGL((attn_dkv_res_kernel<true>), dim3(B * H), dim3(64 * nw), lds_kv, s, qkv, dout, kbias, lse, out, dqkv, B, T,
-                       H, scale, (uint32_t)drop_thr, drop_key, drop_scale);
-    NEKO_CHECK_LAUNCH();
-    hipLaunchKernelGGL((attn_dq_res_kernel<true>), dim3(B * H), dim3(64 * nw), lds_q, s, qkv, dout, kbias, kstart, lse, out, dqkv,
-                       B, T, H, scale, (uint32_t)drop_thr, drop_key, drop_scale);
-  } else {
-    hipLaunchKernelGGL((attn_dkv_res_kernel<false>), dim3(B * H), dim3(64 * nw), lds_kv, s, qkv, dout, kbias, lse, out, dqkv, B,
-                       T, H, scale, 0u, drop_key, drop_scale);
-    NEKO_CHECK_LAUNCH();
-    hipLaunchKernelGGL((attn_dq_res_kernel<false>), dim3(B * H), dim3(64 * nw), lds_q, s, qkv, dout, kbias, kstart, lse, out, dqkv,
-                       B, T, H, scale, 0u, drop_key, drop_scale);
-  }
+#define NEKO_BWD_RES(DROPV, MASKV, THR, MP)                                                                                       \
+  do {                                                                                                                            \
+    hipLaunchKernelGGL((attn_dkv_res_kernel<DROPV, MASKV>), dim3(B * H), dim3(64 * nw), lds_kv, s, qkv, dout, kbias, lse, out,  \
+                       dqkv, B, T, H, scale, (uint32_t)(THR), drop_key, drop_scale, MP);                                         \
+    NEKO_CHECK_LAUNCH();                                                                                                          \
+    hipLaunchKernelGGL((attn_dq_res_kernel<DROPV, MASKV>), dim3(B * H), dim3(64 * nw), lds_q, s, qkv, dout, kbias, kstart, lse,  \
+                       out, dqkv, B, T, H, scale, (uint32_t)(THR), drop_key, drop_scale, MP);                                    \
+  } while (0)
+  if (drop_thr && dmask) NEKO_BWD_RES(true, true, drop_thr, dmask);
+  else if (drop_thr) NEKO_BWD_RES(true, false, drop_thr, nullptr);
+  else NEKO_BWD_RES(false, false, 0, nullptr);
+#undef NEKO_BWD_RES
   NEKO_CHECK_LAUNCH();
   return NEKO_OK;
 }

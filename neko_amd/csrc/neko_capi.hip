@@ -52,15 +52,16 @@ int neko_mask_bias(const float* mask, float* kbias, int* kstart, int B, int T, v
   return neko_mask_bias_impl(mask, kbias, kstart, B, T, S(stream));
 }
 int neko_attn_fwd(const uint16_t* qkv, const float* kbias, const int* kstart, uint16_t* out, float* lse, int B, int T,
-                  int H, int hd, int drop_thr, unsigned drop_key, float drop_scale, void* stream) {
-  return neko_attn_fwd_impl(qkv, kbias, kstart, out, lse, B, T, H, hd, drop_thr, drop_key, drop_scale, S(stream));
+                  int H, int hd, int drop_thr, unsigned drop_key, float drop_scale, uint32_t* drop_mask, void* stream) {
+  return neko_attn_fwd_impl(qkv, kbias, kstart, out, lse, B, T, H, hd, drop_thr, drop_key, drop_scale, drop_mask, S(stream));
 }
+long neko_attn_mask_dwords(int B, int T, int H, int hd) { return neko_attn_mask_dwords_impl(B, T, H, hd); }
 int neko_attn_set_path(int mode) { return neko_attn_set_path_impl(mode); }
 int neko_attn_bwd(const uint16_t* qkv, const uint16_t* out, const uint16_t* dout, const float* kbias,
                   const int* kstart, const float* lse, float* D, int* qflags, uint16_t* dqkv, int B, int T, int H,
-                  int hd, int drop_thr, unsigned drop_key, float drop_scale, void* stream) {
+                  int hd, int drop_thr, unsigned drop_key, float drop_scale, const uint32_t* drop_mask, void* stream) {
   return neko_attn_bwd_impl(qkv, out, dout, kbias, kstart, lse, D, qflags, dqkv, B, T, H, hd, drop_thr, drop_key, drop_scale,
-                            S(stream));
+                            drop_mask, S(stream));
 }
 
 int neko_gemv_bf16(const uint16_t* x, long ldx, const uint16_t* W, long ldw, int b_kstrided, int M, int N, int K,

@@ -68,6 +68,7 @@ class DropSites:
 class LayerCtx:
     x: torch.Tensor = None; a1: torch.Tensor = None; mean1: torch.Tensor = None; rstd1: torch.Tensor = None
     qkv: torch.Tensor = None; o: torch.Tensor = None; lse: torch.Tensor = None
+    dmask: object = None      # attention-dropout keep masks of the forward (tensor, list per segment, or None)
     x1: torch.Tensor = None; a2: torch.Tensor = None; mean2: torch.Tensor = None; rstd2: torch.Tensor = None
     pre: torch.Tensor = None; h: torch.Tensor = None; gate: torch.Tensor = None
 
@@ -190,30 +191,36 @@ def _seg_drop(drop: Optional[ops.Drop], si: int) -> Optional[ops.Drop]:
     return d2
 
 
-def _attn_fwd_segs(qkv, segs: List[Segment], H: int, hd: int, drop):
+def _attn_fwd_segs(qkv, segs: List[Segment], H: int, hd: int, drop, save: bool = False):
+    """-> (o, lse, keep masks).  With `save` and dropout on, the forward also hands back the keep decisions it made (one
+    buffer per attention call) so that the backward does not re-hash them in both of its kernels."""
     if len(segs) == 1 and segs[0].B * segs[0].T == qkv.shape[0]:
         sg = segs[0]
-        return ops.attn_fwd(qkv, sg.kbias, sg.kstart, sg.B, sg.T, H, hd, drop=drop)
+        return ops.attn_fwd(qkv, sg.kbias, sg.kstart, sg.B, sg.T, H, hd, drop=drop, want_mask=True) if save else \
+            ops.attn_fwd(qkv, sg.kbias, sg.kstart, sg.B, sg.T, H, hd, drop=drop) + (None,)
     o = torch.empty(qkv.shape[0], H * hd, dtype=BF16, device=qkv.device)
     o[segs[-1].row0 + segs[-1].B * segs[-1].T:].zero_()      # alignment rows behind the last segment (all padding)
-    lses = []
+    lses, masks = [], []
     for si, sg in enumerate(segs):
         r0, r1 = sg.row0, sg.row0 + sg.B * sg.T
-        _, lse = ops.attn_fwd(qkv[r0:r1], sg.kbias, sg.kstart, sg.B, sg.T, H, hd, drop=_seg_drop(drop, si), out=o[r0:r1])
+        _, lse, mk = ops.attn_fwd(qkv[r0:r1], sg.kbias, sg.kstart, sg.B, sg.T, H, hd, drop=_seg_drop(drop, si), out=o[r0:r1],
+                                  want_mask=True) if save else \
+            ops.attn_fwd(qkv[r0:r1], sg.kbias, sg.kstart, sg.B, sg.T, H, hd, drop=_seg_drop(drop, si), out=o[r0:r1]) + (None,)
         lses.append(lse)
-    return o, lses
+        masks.append(mk)
+    return o, lses, masks
 
 
-def _attn_bwd_segs(qkv, o, d_o, lse, segs: List[Segment], H: int, hd: int, drop):
+def _attn_bwd_segs(qkv, o, d_o, lse, segs: List[Segment], H: int, hd: int, drop, dmask=None):
     if len(segs) == 1 and segs[0].B * segs[0].T == qkv.shape[0]:
         sg = segs[0]
-        return ops.attn_bwd(qkv, o, d_o, sg.kbias, sg.kstart, lse, sg.B, sg.T, H, hd, drop=drop)
+        return ops.attn_bwd(qkv, o, d_o, sg.kbias, sg.kstart, lse, sg.B, sg.T, H, hd, drop=drop, mask=dmask)
     dqkv = torch.empty_like(qkv)
     dqkv[segs[-1].row0 + segs[-1].B * segs[-1].T:].zero_()
     for si, sg in enumerate(segs):
         r0, r1 = sg.row0, sg.row0 + sg.B * sg.T
         ops.attn_bwd(qkv[r0:r1], o[r0:r1], d_o[r0:r1], sg.kbias, sg.kstart, lse[si], sg.B, sg.T, H, hd,
-                     drop=_seg_drop(drop, si), dqkv=dqkv[r0:r1])
+                     drop=_seg_drop(drop, si), dqkv=dqkv[r0:r1], mask=dmask[si] if dmask is not None else None)
     return dqkv
 
 
@@ -251,7 +258,7 @@ def stack_forward(P: StackParams, x: torch.Tensor, mask: torch.Tensor, save: boo
         ops.layernorm_fwd(x, lp.ln1_w, lp.ln1_b, y16=a1, mean=mean1, rstd=rstd1, eps=P.eps)
         qkv = torch.empty(M, 3 * d, dtype=BF16, device=dev)
         ops.gemm(a1, lp.w_qkv, M, 3 * d, d, b_kstrided=True, bias=lp.b_qkv, out_bf16=qkv)
-        o, lse = _attn_fwd_segs(qkv, segs, H, hd, dr.attn[li] if dr else None)
+        o, lse, dmask = _attn_fwd_segs(qkv, segs, H, hd, dr.attn[li] if dr else None, save=save)
         x1 = torch.empty(M, d, dtype=F32, device=dev)
         ops.gemm(o, lp.w_o, M, d, d, b_kstrided=True, bias=lp.b_o, resid=x, out_f32=x1,
                  drop=dr.resid_attn[li] if dr else None)
@@ -267,7 +274,7 @@ def stack_forward(P: StackParams, x: torch.Tensor, mask: torch.Tensor, save: boo
         ops.gemm(h, lp.w_pr, M, d, 4 * d, b_kstrided=True, bias=lp.b_pr, resid=x1, out_f32=x2,
                  drop=dr.resid_mlp[li] if dr else None)
         if save:
-            ctx.layers.append(LayerCtx(x=x, a1=a1, mean1=mean1, rstd1=rstd1, qkv=qkv, o=o, lse=lse, x1=x1, a2=a2,
+            ctx.layers.append(LayerCtx(x=x, a1=a1, mean1=mean1, rstd1=rstd1, qkv=qkv, o=o, lse=lse, dmask=dmask, x1=x1, a2=a2,
                                        mean2=mean2, rstd2=rstd2, pre=pre, h=h, gate=gate))
         x = x2
     hf16 = torch.empty(M, d, dtype=BF16, device=dev) if want_bf16 else None
@@ -334,7 +341,7 @@ def stack_backward(P: StackParams, ctx: StackCtx, dhf: torch.Tensor,
         ops.gemm(g1_16, lp.w_o, M, d, d, ldb=d, out_bf16=d_o)
         SideStream.fork(lambda c=c, lp=lp, g1_16=g1_16: (_wgrad(c.o, g1_16, d, d, M, lp.g_w_o),
                                                           ops.colsum_bf16(g1_16, M, d, lp.g_b_o)), g1_16)
-        dqkv = _attn_bwd_segs(c.qkv, c.o, d_o, c.lse, ctx.segs, H, hd, dr.attn[i] if dr else None)
+        dqkv = _attn_bwd_segs(c.qkv, c.o, d_o, c.lse, ctx.segs, H, hd, dr.attn[i] if dr else None, dmask=c.dmask)
         d_a1 = _dgrad_to_ln(dqkv, lp.w_qkv, M, d, 3 * d, 3 * d)
         SideStream.fork(lambda c=c, lp=lp, dqkv=dqkv: (_wgrad(c.a1, dqkv, d, 3 * d, M, lp.g_w_qkv),
                                                       ops.colsum_bf16(dqkv, M, 3 * d, lp.g_b_qkv)), dqkv)

@@ -174,8 +174,10 @@ def attn_set_path(mode: int) -> int:
     return int(_lib.load().neko_attn_set_path(int(mode)))
 
 
-def attn_fwd(qkv, kbias, kstart, B, T, H, hd, drop=None, out=None):
-    """out (optional): a contiguous [B*T, H*hd] bf16 row range to write into (ragged groups share one buffer)."""
+def attn_fwd(qkv, kbias, kstart, B, T, H, hd, drop=None, out=None, want_mask=False):
+    """out (optional): a contiguous [B*T, H*hd] bf16 row range to write into (ragged groups share one buffer).
+    want_mask: with dropout on, also return the keep-mask buffer the backward of this call can reuse (int32 tensor, or
+    None when the schedule in use does not exchange masks): (out, lse, mask) instead of (out, lse)."""
     _chk(qkv, BF16, "qkv")
     assert qkv.is_contiguous() and qkv.shape[0] == B * T
     if out is None:
@@ -183,12 +185,18 @@ def attn_fwd(qkv, kbias, kstart, B, T, H, hd, drop=None, out=None):
     else:
         _chk(out, BF16, "out"); assert out.is_contiguous() and out.shape == (B * T, H * hd)
     lse = torch.empty(B, H, T, dtype=torch.float32, device=qkv.device)
-    _lib.call("neko_attn_fwd", _p(qkv), _p(kbias), _p(kstart), _p(out), _p(lse), B, T, H, hd, *_drop(drop), _stream())
-    return out, lse
+    mask = None
+    if want_mask and drop is not None and drop.thr > 0:
+        n = int(_lib.load().neko_attn_mask_dwords(B, T, H, hd))
+        if n > 0:
+            mask = torch.empty(n, dtype=torch.int32, device=qkv.device)
+    _lib.call("neko_attn_fwd", _p(qkv), _p(kbias), _p(kstart), _p(out), _p(lse), B, T, H, hd, *_drop(drop), _p(mask), _stream())
+    return (out, lse, mask) if want_mask else (out, lse)
 
 
-def attn_bwd(qkv, out, dout, kbias, kstart, lse, B, T, H, hd, drop=None, dqkv=None):
-    """dqkv (optional): a contiguous [B*T, 3*H*hd] bf16 row range to write into."""
+def attn_bwd(qkv, out, dout, kbias, kstart, lse, B, T, H, hd, drop=None, dqkv=None, mask=None):
+    """dqkv (optional): a contiguous [B*T, 3*H*hd] bf16 row range to write into.
+    mask: the keep-mask buffer attn_fwd(..., want_mask=True) returned for the SAME call (or None: decisions are re-hashed)."""
     _chk(dout, BF16, "dout")
     dev = qkv.device
     assert qkv.is_contiguous() and out.is_contiguous() and dout.is_contiguous() and qkv.shape[0] == B * T
@@ -198,8 +206,11 @@ def attn_bwd(qkv, out, dout, kbias, kstart, lse, B, T, H, hd, drop=None, dqkv=No
         dqkv = torch.empty(B * T, 3 * H * hd, dtype=BF16, device=dev)
     else:
         _chk(dqkv, BF16, "dqkv"); assert dqkv.is_contiguous() and dqkv.shape == (B * T, 3 * H * hd)
+    if mask is not None:
+        _chk(mask, torch.int32, "mask")
+        assert mask.numel() == int(_lib.load().neko_attn_mask_dwords(B, T, H, hd)), "mask buffer of another call / schedule"
     _lib.call("neko_attn_bwd", _p(qkv), _p(out), _p(dout), _p(kbias), _p(kstart), _p(lse), _p(D), _p(qflags),
-              _p(dqkv), B, T, H, hd, *_drop(drop), _stream())
+              _p(dqkv), B, T, H, hd, *_drop(drop), _p(mask), _stream())
     return dqkv
 
 

@@ -120,12 +120,50 @@ def _attention_dropout_case(ops, B, T, H, hd):
     o_ref.backward(do)
     kb, ks = ops.mask_bias(mask.to(DEV))
     qd = qkv.view(B * T, 3 * d).to(torch.bfloat16).to(DEV).contiguous()
-    out, lse = ops.attn_fwd(qd, kb, ks, B, T, H, hd, drop=drop)
+    out, lse, kept = ops.attn_fwd(qd, kb, ks, B, T, H, hd, drop=drop, want_mask=True)
     sc = float(o_ref.detach().abs().max())
     assert float((out.view(B, T, d).float().cpu() - o_ref.detach()).abs().max()) < 1e-2 * sc
-    dqkv = ops.attn_bwd(qd, out, do.view(B * T, d).to(torch.bfloat16).to(DEV).contiguous(), kb, ks, lse, B, T, H, hd, drop=drop)
+    dod = do.view(B * T, d).to(torch.bfloat16).to(DEV).contiguous()
+    dqkv = ops.attn_bwd(qd, out, dod, kb, ks, lse, B, T, H, hd, drop=drop)              # decisions re-hashed
     gs = float(leaf.grad.abs().max())
     assert float((dqkv.view(B, T, 3 * d).float().cpu() - leaf.grad).abs().max()) < 2e-2 * gs
+    if kept is not None:        # head-resident schedule: the backward reuses the forward's stored keep masks -- same bits
+        dqkv2 = ops.attn_bwd(qd, out, dod, kb, ks, lse, B, T, H, hd, drop=drop, mask=kept)
+        assert torch.equal(dqkv2, dqkv)
+    else:
+        assert hd != 32 or ops.attn_set_path(-1) == 1
+
+
+@pytest.mark.parametrize("B,T,H,pad", [(2, 1024, 3, 0), (3, 1000, 2, 77), (2, 33, 2, 5), (1, 512, 4, 0)])
+def test_attention_backward_with_stored_keep_masks_is_bit_identical(B, T, H, pad):
+    """The forward's compares (hash byte >= threshold) are stored as 64-bit lane masks by scalar stores and applied by
+    dQ (scalar loads, one v_cndmask per element) and dK/dV (one dword per key, bit tests): the gradients must be the
+    very bits the re-hashing kernels produce, at the metric length, with left padding (masked query rows that see
+    every key) and with a ragged last block; a second forward into the same buffer must leave no stale decision."""
+    from neko_amd import ops
+    g = torch.Generator().manual_seed(T + pad)
+    hd, d = 32, H * 32
+    qkv = (torch.randn(B * T, 3 * d, generator=g) * 0.7).to(torch.bfloat16).to(DEV)
+    do = torch.randn(B * T, d, generator=g).to(torch.bfloat16).to(DEV)
+    mask = torch.ones(B, T)
+    if pad:
+        mask[0, :pad] = 0
+        do.view(B, T, d)[0, :3] = 1.0          # a masked query row with a live gradient: it reaches every key
+    kb, ks = ops.mask_bias(mask.to(DEV))
+    kept = None
+    for key in (0x1234567, 0x7654321):          # second round overwrites the first round's masks
+        drop = ops.Drop(0.1, key)
+        out_ref, lse_ref = ops.attn_fwd(qkv, kb, ks, B, T, H, hd, drop=drop)
+        if kept is None:
+            out, lse, kept = ops.attn_fwd(qkv, kb, ks, B, T, H, hd, drop=drop, want_mask=True)
+        else:
+            from neko_amd import _lib
+            _lib.call("neko_attn_fwd", ops._p(qkv), ops._p(kb), ops._p(ks), ops._p(out), ops._p(lse), B, T, H, hd,
+                      *ops._drop(drop), ops._p(kept), ops._stream())
+        assert kept is not None and torch.equal(out, out_ref) and torch.equal(lse, lse_ref)
+        ref = ops.attn_bwd(qkv, out, do, kb, ks, lse, B, T, H, hd, drop=drop)
+        got = ops.attn_bwd(qkv, out, do, kb, ks, lse, B, T, H, hd, drop=drop, mask=kept)
+        assert torch.equal(got, ref), float((got.float() - ref.float()).abs().max())
 
 
 def test_policy_with_dropout_matches_oracle_with_same_masks():

@@ -17,14 +17,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_abi_exports_every_declared_symbol():
     from neko_amd import _lib
     hdr = open(os.path.join(ROOT, "include", "neko_hip.h")).read()
-    declared = set(re.findall(r"^\s*(?:int|const char\*)\s+(neko_\w+)\s*\(", hdr, flags=re.M))
+    declared = set(re.findall(r"^\s*(?:int|long|const char\*)\s+(neko_\w+)\s*\(", hdr, flags=re.M))
     assert len(declared) >= 23, declared
     lib = _lib.load()
     for name in declared:
         assert hasattr(lib, name), f"libneko_hip.so lacks {name}"
     # every binding in _lib.SIGNATURES is a declared symbol and vice versa (status_string is bound separately)
     assert set(_lib.SIGNATURES) | {"neko_status_string"} == declared
-    assert lib.neko_abi_version() == 9
+    assert lib.neko_abi_version() == 10
     assert lib.neko_status_string(-1).decode().startswith("invalid argument")
 
 

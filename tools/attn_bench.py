@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--drop", type=float, default=0.0, help="attention dropout probability")
     ap.add_argument("--path", type=int, default=0, help="0 auto (head-resident when applicable), 1 streaming")
+    ap.add_argument("--no-mask", action="store_true", help="backward re-hashes the dropout decisions instead of reusing the forward's")
     a = ap.parse_args()
     ops.attn_set_path(a.path)
     B, T, H, hd = a.B, a.T, a.H, a.hd
@@ -35,7 +36,9 @@ def main():
         mask[:, :a.pad] = 0
     kb, ks = ops.mask_bias(mask)
     drop = ops.Drop(a.drop, 0x1234567) if a.drop > 0 else None
-    out, lse = ops.attn_fwd(qkv, kb, ks, B, T, H, hd, drop=drop)
+    out, lse, mask = ops.attn_fwd(qkv, kb, ks, B, T, H, hd, drop=drop, want_mask=True)
+    if a.no_mask:
+        mask = None
     fl = 4.0 * T * T / 2 * hd * H * B
 
     def timeit(fn, name, flops):
@@ -51,9 +54,9 @@ def main():
         print(f"{name:10s} {us:9.1f} us  {flops / us / 1e6:7.1f} TFLOP/s (useful, causal)")
 
     if "bwd" not in a.only:
-        timeit(lambda: ops.attn_fwd(qkv, kb, ks, B, T, H, hd, drop=drop), "attn fwd", fl)
+        timeit(lambda: ops.attn_fwd(qkv, kb, ks, B, T, H, hd, drop=drop, want_mask=not a.no_mask), "attn fwd", fl)
     if "fwd" not in a.only:
-        timeit(lambda: ops.attn_bwd(qkv, out, do, kb, ks, lse, B, T, H, hd, drop=drop), "attn bwd", 2.5 * fl)
+        timeit(lambda: ops.attn_bwd(qkv, out, do, kb, ks, lse, B, T, H, hd, drop=drop, mask=mask), "attn bwd", 2.5 * fl)
 
 
 if __name__ == "__main__":
