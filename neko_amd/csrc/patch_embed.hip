@@ -27,6 +27,19 @@ constexpr float GN_EPS = 1e-5f;
 constexpr int OFF_W1 = 0, OFF_B1 = 128 * 27, OFF_GW = OFF_B1 + 128, OFF_GB = OFF_GW + 128, OFF_W2 = OFF_GB + 128,
               OFF_B2 = OFF_W2 + 3 * 128 * 9, PART_USED = OFF_B2 + 3, PART_STRIDE = (PART_USED + 63) / 64 * 64;
 
+// Sum over the 32 lanes that share lane >> 5, by DPP: quad_perm xor 1 / xor 2, row_half_mirror, row_mirror (every lane of a
+// 16-lane row then holds its row's total), row_bcast15 into rows 1 and 3.  The total is valid in lanes 16..31 and 48..63
+// (callers store from lane 31 / 63).  Five VALU adds with ~8-cycle latency each; the __shfl_xor butterfly this replaces is
+// five ds_bpermute round trips through the LDS crossbar (~100+ cycles each), 64 of them per patch in the statistics alone.
+__device__ __forceinline__ float half_sum32_dpp(float v) {
+  v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
+  v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
+  v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x141, 0xf, 0xf, true));   // row_half_mirror
+  v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x140, 0xf, 0xf, true));   // row_mirror
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xa, 0xf, false));   // row_bcast15 -> rows 1, 3
+  return v;
+}
+
 // ---- MFMA forward -------------------------------------------------------------------------------------------------
 // Both 3x3 convolutions are dense contractions over (input channel, tap) and run on v_mfma_f32_32x32x16_bf16 with bf16
 // operands and fp32 accumulation (the reference runs them in bf16 under autocast):
@@ -181,10 +194,9 @@ __global__ __launch_bounds__(256, 2) void resblock_fwd_kernel(const void* __rest
               const float x = acc[t][pt][4 * qq + e];
               v = pass == 0 ? v + x : fmaf(x, x, v);
             }
-#pragma unroll
-          for (int m = 1; m < 32; m <<= 1) v += __shfl_xor(v, m, 64);
-          if (l32 == 0) s.red[pass][8 * t + 2 * qq + h][wave] = v;
-          if (qq == 3) __builtin_amdgcn_sched_barrier(0);     // bound the live shuffle chains (register pressure)
+          v = half_sum32_dpp(v);
+          if (l32 == 31) s.red[pass][8 * t + 2 * qq + h][wave] = v;
+          if (qq == 3) __builtin_amdgcn_sched_barrier(0);     // bound the live reduction chains (register pressure)
         }
       __syncthreads();
 #pragma unroll
@@ -308,6 +320,20 @@ __device__ __forceinline__ bf16x8_v tr_frag32(const bf16_t* tile, int rowbase, i
 // v[0..31] summed over the 32 lanes that share lane>>5: afterwards lane l32 holds the total of index l32.
 // Recursive template so that every v[] index is a literal (a `half >>= 1` loop is not unrolled by hipcc and turned the
 // register array into 32-way select chains: 7,700 v_cmp/v_cndmask pairs).
+// value of lane (lane ^ HALF): DPP where the pattern exists inside a 16-lane row (xor 1, 2: quad_perm; xor 8 = rotate by 8;
+// xor 4 = rotate by 4 one way or the other), the LDS crossbar (ds_bpermute) only for the cross-row xor 16
+template <int HALF>
+__device__ __forceinline__ float xor_lane(float x, int l32) {
+  const int xi = __float_as_int(x);
+  if constexpr (HALF == 1) return __int_as_float(__builtin_amdgcn_mov_dpp(xi, 0xB1, 0xf, 0xf, true));
+  else if constexpr (HALF == 2) return __int_as_float(__builtin_amdgcn_mov_dpp(xi, 0x4E, 0xf, 0xf, true));
+  else if constexpr (HALF == 8) return __int_as_float(__builtin_amdgcn_mov_dpp(xi, 0x128, 0xf, 0xf, true));     // row_ror:8
+  else if constexpr (HALF == 4) {
+    const int up = __builtin_amdgcn_mov_dpp(xi, 0x12C, 0xf, 0xf, true);      // row_ror:12: lane i <- lane (i + 4) % 16
+    const int dn = __builtin_amdgcn_mov_dpp(xi, 0x124, 0xf, 0xf, true);      // row_ror:4 : lane i <- lane (i - 4) % 16
+    return __int_as_float((l32 & 4) ? dn : up);
+  } else return __shfl_xor(x, HALF, 64);
+}
 template <int HALF>
 __device__ __forceinline__ void reduce_scatter_step(float (&v)[32], int l32) {
   const bool up = (l32 & HALF) != 0;
@@ -315,7 +341,7 @@ __device__ __forceinline__ void reduce_scatter_step(float (&v)[32], int l32) {
   for (int i = 0; i < HALF; ++i) {
     const float keep = up ? v[HALF + i] : v[i];
     const float send = up ? v[i] : v[HALF + i];
-    v[i] = keep + __shfl_xor(send, HALF, 64);
+    v[i] = keep + xor_lane<HALF>(send, l32);
   }
   if constexpr (HALF > 1) reduce_scatter_step<HALF / 2>(v, l32);
 }
@@ -444,9 +470,8 @@ __global__ __launch_bounds__(256, 2) void resblock_bwd_kernel(const float* __res
               const float x = acc[pt][4 * qq + e];
               v = pass == 0 ? v + x : fmaf(x, x, v);
             }
-#pragma unroll
-          for (int m = 1; m < 32; m <<= 1) v += __shfl_xor(v, m, 64);
-          if (l32 == 0) s.red[pass][2 * qq + h][wave] = v;
+          v = half_sum32_dpp(v);
+          if (l32 == 31) s.red[pass][2 * qq + h][wave] = v;
         }
         __syncthreads();
 #pragma unroll
