@@ -197,6 +197,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dropout", type=float, default=0.1, help="attention/residual dropout (reference default 0.1)")
     ap.add_argument("--no-optimizer", action="store_true", help="time fwd+bwd(+all-reduce) only")
+    ap.add_argument("--capture", action="store_true",
+                    help="run the step as ONE replayed HIP graph per batch structure (neko_amd/training/captured.py; "
+                         "single rank): the lever for the README batch sizes (c2 / c3 / c4), where the host enqueue is the step")
     args = ap.parse_args()
     global D, L, H
     if args.model == "gato-1.2b":
@@ -287,7 +290,16 @@ def main():
         opt.zero_grad()
         return loss
 
-    for i in range(args.warmup):
+    cap = None
+    if args.capture:
+        assert world == 1 and not args.no_optimizer, "--capture: single rank, full step"
+        from neko_amd.training.captured import CapturedTrainStep
+        cap = CapturedTrainStep(model, opt, None, grad_norm_clip=1.0)
+        eager_step = step
+
+        def step(i):                               # noqa: F811  (the captured step replaces the eager one)
+            return cap.step(batches[i % len(batches)])[0]
+    for i in range(max(args.warmup, 3 if cap else 0)):
         loss = step(i)
     torch.cuda.synchronize()
     if world > 1:
@@ -311,6 +323,10 @@ def main():
     # the reference's metric is forward+backward (+ all-reduce); `value` above includes clip + AdamW, the
     # fwd+bwd(+all-reduce)-only rate is timed separately over the same number of steps and reported next to it
     el_fb = None
+    if cap is not None:
+        step = eager_step
+        cap_stats = {"graphs": len(cap.entries), "replays": cap.replays, "eager_steps": cap.eager_steps}
+        cap.close()
     if not args.no_optimizer:
         def step_fb(i):
             _, l = model.forward(inputs=batches[i % len(batches)], compute_loss=True, return_logits=False)
@@ -401,6 +417,7 @@ def main():
             "rccl_ranks_seen": ranks_seen,
             "exposed_comm_ms_per_step": exposed_comm_ms,
             "dp_payload": (dp.payload if dp is not None else None),
+            "captured_step": (cap_stats if args.capture else None),
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

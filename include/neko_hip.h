@@ -33,7 +33,7 @@ extern "C" {
 #define NEKO_ERR_UNSUPPORTED (-2)
 #define NEKO_ERR_LAUNCH (-3)
 
-#define NEKO_ABI_VERSION 10
+#define NEKO_ABI_VERSION 11
 
 int neko_abi_version(void);
 /* human-readable text for a return code (static storage) */
@@ -178,13 +178,20 @@ int neko_tokenize_continuous(const float* x, int* ids, long n, int use_mu_law, f
  *                        (sqrt(*gnorm_sq)+1e-6)) read on device (gnorm_sq null = no clipping);
  *                        *grad_scale (may be null) multiplies g; step = device int32 counter of the
  *                        range (bias correction); *active == 0 (may be null) skips the range the way
- *                        torch skips parameters whose grad is None; p16 (may be null) gets bf16(p).
+ *                        torch skips parameters whose grad is None; p16 (may be null) gets bf16(p);
+ *                        lr_dev (may be null) = the learning rate in device memory, used instead of `lr` --
+ *                        a captured (HIP-graph) step cannot change a kernel argument between replays.
  * ------------------------------------------------------------------------------------------- */
 /* Dropout (nn.Dropout sites of the path: embd :541,707; attention :179; residual :254,278).  Counter-based:
  * element idx is kept iff top byte of hash(idx ^ key) >= thr with thr = round(p*256) in [0,255] (0 = off), survivors
  * scaled by scale = 256/(256-thr); forward and backward regenerate the same mask from (idx, key), no mask tensor.
  * neko_dropout_f32: y = keep ? x*scale : 0 on a flat fp32 array (embedding dropout and its backward). */
 int neko_dropout_f32(const float* x, float* y, long n, int thr, unsigned key, float scale, void* stream);
+/* Captured (HIP-graph) training steps freeze every kernel argument, site keys included.  neko_set_drop_salt registers ONE
+ * device uint32 (or null = off, the default) that every kernel with a dropout site ADDS to its site key at entry; the
+ * captured step advances it once per replay, so the masks of every site differ from step to step.  Process-wide, set
+ * outside of any capture (it is a blocking copy into the library's device globals). */
+int neko_set_drop_salt(const uint32_t* salt);
 int neko_cast_f32_bf16(const float* x, uint16_t* y, long n, void* stream);
 /* loss-position selection (gato_policy.py:183-185): dst[r,:] = r < n ? src[idx[r],:] : 0 (bf16 rows, d % 8 == 0);
  * and its adjoint dst[idx[r],:] = src[r,:] (f32 rows, dst pre-zeroed, idx unique). */
@@ -201,7 +208,7 @@ int neko_geglu_bwd(const uint16_t* dh, const uint16_t* pre, const uint16_t* gate
                    long n, void* stream);
 int neko_adamw_step(float* p, const float* g, float* m, float* v, uint16_t* p16, long n, float lr, float beta1,
                     float beta2, float eps, float weight_decay, const double* gnorm_sq, float max_norm,
-                    const float* grad_scale, int* step, const int* active, void* stream);
+                    const float* grad_scale, int* step, const int* active, const float* lr_dev, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Image patch embedding -- ImageEmbedding.forward / ResidualBlock_V2 / PatchPosEncoding

@@ -41,7 +41,8 @@ SIGNATURES = {
     "neko_sqnorm_f32": [_vp, _l, _vp, _vp],
     "neko_geglu_fwd": [_vp, _vp, _l, _vp],
     "neko_geglu_bwd": [_vp, _vp, _vp, _vp, _vp, _l, _vp],
-    "neko_adamw_step": [_vp, _vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _vp, _f, _vp, _vp, _vp, _vp],
+    "neko_adamw_step": [_vp, _vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _vp, _f, _vp, _vp, _vp, _vp, _vp],
+    "neko_set_drop_salt": [_vp],
     "neko_patch_resblock_fwd": [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp],
     "neko_patch_resblock_bwd": [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
                                 _vp, _vp],

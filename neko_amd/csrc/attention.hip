@@ -311,6 +311,7 @@ __global__ __launch_bounds__(NT, (HD <= 32 ? NEKO_FWD_WAVES : (HD <= 64 ? 3 : 2)
   // one workgroup = a heavy and a light causal tile (G-1-p and p): every workgroup walks the same number of
   // 64-row tiles.  With one tile per workgroup the whole grid was co-resident and the kernel lasted as long as its
   // heaviest workgroup (16 tile iterations at T = 1024 against an average of 9).
+  if (DROP) drop_key += neko_drop_salt();
   const int G = (T + 127) / 128, p = rotated_tile();
   const int first = G - 1 - p, second = p;
   attn_fwd_tile<HD, DROP>(qkv, kbias, kstart, out, lse, B, T, H, scale, drop_thr, drop_key, drop_scale, first);
@@ -517,6 +518,7 @@ __global__ __launch_bounds__(NT, (HD <= 32 ? 4 : (HD <= 64 ? 2 : 1))) void attn_
   // one workgroup = a heavy and a light causal tile (G-1-p and p): every workgroup walks the same number of
   // 64-row tiles.  With one tile per workgroup the whole grid was co-resident and the kernel lasted as long as its
   // heaviest workgroup (16 tile iterations at T = 1024 against an average of 9).
+  if (DROP) drop_key += neko_drop_salt();
   const int G = (T + 127) / 128, p = rotated_tile();
   const int first = G - 1 - p, second = p;
   attn_bwd_dq_tile<HD, DROP>(qkv, dout, kbias, kstart, lse, Dv, dqkv, B, T, H, scale, drop_thr, drop_key, drop_scale, first);
@@ -713,6 +715,7 @@ __global__ __launch_bounds__(NT, (HD <= 32 ? NEKO_DKV_WAVES : (HD <= 64 ? 2 : 1)
   // one workgroup = a heavy and a light causal tile (G-1-p and p): every workgroup walks the same number of
   // 64-row tiles.  With one tile per workgroup the whole grid was co-resident and the kernel lasted as long as its
   // heaviest workgroup (16 tile iterations at T = 1024 against an average of 9).
+  if (DROP) drop_key += neko_drop_salt();
   const int G = (T + 127) / 128, p = rotated_tile();
   const int first = p, second = G - 1 - p;
   attn_bwd_dkv_tile<HD, DROP>(qkv, dout, kbias, lse, Dv, qflags, dqkv, B, T, H, scale, drop_thr, drop_key, drop_scale, first);
@@ -812,3 +815,5 @@ int neko_attn_bwd_impl(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout,
     default: return NEKO_ERR_UNSUPPORTED;
   }
 }
+
+NEKO_DEFINE_SALT_SETTER(attention)

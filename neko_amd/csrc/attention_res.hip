@@ -199,6 +199,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_res_kernel(const bf16_t* __rest
                                                             uint32_t drop_thr, uint32_t drop_key, float drop_scale,
                                                             uint32_t* __restrict__ dmask) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  if (DROP) drop_key += neko_drop_salt();
   const int Tp = (T + 31) & ~31, nblk = Tp >> 5;
   char* imgK = smem;
   char* imgV = smem + Tp * 64;
@@ -366,6 +367,7 @@ __global__ __launch_bounds__(768) void attn_dq_res_kernel(const bf16_t* __restri
                                                            uint32_t drop_thr, uint32_t drop_key, float drop_scale,
                                                            const uint32_t* __restrict__ dmask) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  if (DROP) drop_key += neko_drop_salt();
   const int Tp = (T + 31) & ~31, nblk = Tp >> 5;
   char* imgK = smem;
   char* imgV = smem + Tp * 64;
@@ -514,6 +516,7 @@ __global__ __launch_bounds__(768) void attn_dkv_res_kernel(const bf16_t* __restr
                                                             uint32_t drop_key, float drop_scale,
                                                             const uint32_t* __restrict__ dmask) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  if (DROP) drop_key += neko_drop_salt();
   const int Tp = (T + 31) & ~31, nblk = Tp >> 5;
   char* imgQ = smem;
   char* imgdO = smem + Tp * 64;
@@ -761,3 +764,5 @@ int neko_attn_bwd_res_impl(const bf16_t* qkv, const bf16_t* out, const bf16_t* d
   NEKO_CHECK_LAUNCH();
   return NEKO_OK;
 }
+
+NEKO_DEFINE_SALT_SETTER(attention_res)

@@ -10,6 +10,7 @@ namespace {
 
 __global__ __launch_bounds__(256) void dropout_f32_kernel(const float* __restrict__ x, float* __restrict__ y, long n,
                                                           uint32_t thr, uint32_t key, float scale) {
+  key += neko_drop_salt();
   const long stride = (long)gridDim.x * blockDim.x * 4;
   for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
     if (i + 4 <= n) {
@@ -34,3 +35,5 @@ int neko_dropout_f32_impl(const float* x, float* y, long n, int thr, unsigned ke
   NEKO_CHECK_LAUNCH();
   return NEKO_OK;
 }
+
+NEKO_DEFINE_SALT_SETTER(dropout)

@@ -132,6 +132,7 @@ struct AdamArgs {
   const float* grad_scale;    // optional extra multiplier on g (e.g. 1/world) or null
   int* step;                  // device step counter of this range (already incremented for this step)
   const int* active;          // null = always
+  const float* lr_dev;        // optional: the learning rate in device memory (captured steps: kernel arguments are frozen)
 };
 __global__ void adam_step_inc_kernel(int* step, const int* active) {
   if (!active || *active) *step += 1;
@@ -146,6 +147,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
     coef = fminf(1.f, a.max_norm / (nrm + 1e-6f)) * gs;
   }
   const int t = *a.step;
+  if (a.lr_dev) a.lr = *a.lr_dev;
   const float bc1 = 1.f - powf(a.beta1, (float)t);
   const float bc2 = 1.f - powf(a.beta2, (float)t);
   const float step_size = a.lr / bc1;
@@ -315,12 +317,12 @@ int neko_sqnorm_f32_impl(const float* g, long n, double* out_accum, hipStream_t 
 
 int neko_adamw_step_impl(float* p, const float* g, float* m, float* v, bf16_t* p16, long n, float lr, float beta1,
                          float beta2, float eps, float wd, const double* gnorm_sq, float max_norm,
-                         const float* grad_scale, int* step, const int* active, hipStream_t s) {
+                         const float* grad_scale, int* step, const int* active, const float* lr_dev, hipStream_t s) {
   if (n <= 0) return NEKO_OK;
   if (!p || !g || !m || !v || !step) return NEKO_ERR_ARG;
   hipLaunchKernelGGL(adam_step_inc_kernel, dim3(1), dim3(1), 0, s, step, active);
   NEKO_CHECK_LAUNCH();
-  AdamArgs a{p, g, m, v, p16, n, lr, beta1, beta2, eps, wd, max_norm, gnorm_sq, grad_scale, step, active};
+  AdamArgs a{p, g, m, v, p16, n, lr, beta1, beta2, eps, wd, max_norm, gnorm_sq, grad_scale, step, active, lr_dev};
   hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n, 8)), dim3(256), 0, s, a);
   NEKO_CHECK_LAUNCH();
   return NEKO_OK;

@@ -117,6 +117,7 @@ __device__ __forceinline__ bf16x8_v frag_ks(const char* lds, int rowbase, int ks
 
 template <bool A_KC, bool B_KC, bool SAFE_T>
 __global__ __launch_bounds__(NT) void gemm_bf16_kernel(GemmArgs p) {
+  if (p.drop_thr) p.drop_key += neko_drop_salt();
   __shared__ __attribute__((aligned(16))) char smem[4 * OP_BYTES];
   auto ldsA = [&](int buf) -> char* { return smem + buf * 2 * OP_BYTES; };
   auto ldsB = [&](int buf) -> char* { return smem + (buf * 2 + 1) * OP_BYTES; };
@@ -282,3 +283,5 @@ int neko_gemm_bf16_full(GemmArgs a, int a_kstrided, int b_kstrided, int safe_tra
   if (rc != NEKO_OK || !a.splitk_ws || a.M <= 0 || a.N <= 0 || a.K <= 0) return rc;
   return neko_splitk_reduce_impl(a.splitk_ws, a.splitk, a.M, a.N, a.Cf, a.ldcf, a.accumulate, s);
 }
+
+NEKO_DEFINE_SALT_SETTER(gemm_bf16)

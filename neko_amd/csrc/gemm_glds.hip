@@ -490,6 +490,7 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, f32x16 (&acc)[C::TM]
 
 template <bool A_KC, bool B_KC, class C>
 __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void gemm_glds_kernel(GemmArgs p) {
+  if (p.drop_thr) p.drop_key += neko_drop_salt();
   constexpr int NSTAGE = C::RING_BYTES / C::STAGE_BYTES, BM = C::BM, BN = C::BN, TM = C::TM, TN = C::TN;
   constexpr int GLDS_PER_STAGE = C::GLDS_PER_STAGE;
   __shared__ __attribute__((aligned(1024))) char smem[C::LDS_BYTES];   // ring of [A|B] stages, then epilogue slabs
@@ -772,3 +773,5 @@ int neko_gemm_glds_try(const GemmArgs& a, int a_kstrided, int b_kstrided, hipStr
   if (b_kstrided) return launch<true, false>(a, s);
   return launch<true, true>(a, s);
 }
+
+NEKO_DEFINE_SALT_SETTER(gemm_glds)

@@ -83,6 +83,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
                                                      float* __restrict__ dx, bf16_t* __restrict__ dx16,
                                                      float* __restrict__ part, int M, int d, uint32_t drop_thr,
                                                      uint32_t drop_key, float drop_scale) {
+  if (drop_thr) drop_key += neko_drop_salt();
   extern __shared__ __attribute__((aligned(16))) float lds[];  // [4][2][d]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nvec = d >> 2;
@@ -297,3 +298,5 @@ int neko_layernorm_bwd_impl(const void* dy, int dy16, const float* x, const floa
   NEKO_CHECK_LAUNCH();
   return NEKO_OK;
 }
+
+NEKO_DEFINE_SALT_SETTER(layernorm)

@@ -125,9 +125,18 @@ int neko_sqnorm_f32(const float* g, long n, double* out_accum, void* stream) {
 }
 int neko_adamw_step(float* p, const float* g, float* m, float* v, uint16_t* p16, long n, float lr, float beta1,
                     float beta2, float eps, float weight_decay, const double* gnorm_sq, float max_norm,
-                    const float* grad_scale, int* step, const int* active, void* stream) {
+                    const float* grad_scale, int* step, const int* active, const float* lr_dev, void* stream) {
   return neko_adamw_step_impl(p, g, m, v, p16, n, lr, beta1, beta2, eps, weight_decay, gnorm_sq, max_norm, grad_scale,
-                              step, active, S(stream));
+                              step, active, lr_dev, S(stream));
+}
+int neko_set_drop_salt(const uint32_t* salt) {
+  int rc = neko_set_drop_salt_dropout(salt);
+  if (rc == NEKO_OK) rc = neko_set_drop_salt_layernorm(salt);
+  if (rc == NEKO_OK) rc = neko_set_drop_salt_gemm_bf16(salt);
+  if (rc == NEKO_OK) rc = neko_set_drop_salt_gemm_glds(salt);
+  if (rc == NEKO_OK) rc = neko_set_drop_salt_attention(salt);
+  if (rc == NEKO_OK) rc = neko_set_drop_salt_attention_res(salt);
+  return rc;
 }
 
 int neko_patch_resblock_fwd(const void* images, int images_are_u8, int n, int H, int W, const float* w1,

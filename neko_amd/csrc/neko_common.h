@@ -102,6 +102,20 @@ __device__ __forceinline__ uint32_t drop_word(uint32_t g, uint32_t key) {
   h ^= h >> 16;
   return h;
 }
+// Device-side key offset for captured (HIP-graph) training steps: kernel arguments are frozen at capture time, so the per-step
+// variation of every dropout site comes from ONE uint32 in device memory that the captured step itself advances.  Each kernel
+// with a dropout site adds neko_drop_salt() to its site key once, at entry (0 when no salt is registered: eager mode).
+// One copy of the pointer per translation unit (the library is built without relocatable device code); neko_set_drop_salt()
+// in neko_capi.hip sets them all.
+static __device__ const uint32_t* g_neko_drop_salt = nullptr;
+__device__ __forceinline__ uint32_t neko_drop_salt() {
+  const uint32_t* p = g_neko_drop_salt;
+  return p ? *p : 0u;
+}
+#define NEKO_DEFINE_SALT_SETTER(tag)                                                                              \
+  int neko_set_drop_salt_##tag(const uint32_t* p) {                                                               \
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_neko_drop_salt), &p, sizeof(p)) == hipSuccess ? NEKO_OK : NEKO_ERR_LAUNCH; \
+  }
 __device__ __forceinline__ bool drop_byte_keep(uint32_t word, int i, uint32_t thr) { return ((word >> (8 * i)) & 0xffu) >= thr; }
 __device__ __forceinline__ bool drop_keep(uint32_t idx, uint32_t key, uint32_t thr) {
   return ((drop_word(idx >> 2, key) >> (8 * (idx & 3u))) & 0xffu) >= thr;

@@ -84,7 +84,14 @@ int neko_mask_bias_impl(const float* mask, float* kbias, int* kstart, int B, int
 int neko_sqnorm_f32_impl(const float* g, long n, double* out_accum, hipStream_t s);
 int neko_adamw_step_impl(float* p, const float* g, float* m, float* v, bf16_t* p16, long n, float lr, float beta1,
                          float beta2, float eps, float wd, const double* gnorm_sq, float max_norm,
-                         const float* grad_scale, int* step, const int* active, hipStream_t s);
+                         const float* grad_scale, int* step, const int* active, const float* lr_dev, hipStream_t s);
+// per-translation-unit setters of the device-side dropout key offset (neko_common.h), fanned out by neko_set_drop_salt
+int neko_set_drop_salt_dropout(const uint32_t* p);
+int neko_set_drop_salt_layernorm(const uint32_t* p);
+int neko_set_drop_salt_gemm_bf16(const uint32_t* p);
+int neko_set_drop_salt_gemm_glds(const uint32_t* p);
+int neko_set_drop_salt_attention(const uint32_t* p);
+int neko_set_drop_salt_attention_res(const uint32_t* p);
 int neko_patch_resblock_fwd_impl(const void* images, int images_are_u8, int n, int H, int W, const float* w1,
                                  const float* b1, const float* gn_w, const float* gn_b, const float* w2,
                                  const float* b2, int mid_channels, int num_groups, bf16_t* y16, float* x_patches,

@@ -548,7 +548,7 @@ def lm_head_loss(Hp: HeadParams, hf16: torch.Tensor, target: torch.Tensor, sel: 
         ops.gemm(hf16[r0:r1], Hp.w, n, Hp.Vpad, d, ldb=d, out_bf16=z, ldcb=Hp.Vpad)
         ops.ce_bf16_inplace(z, Hp.V, Hp.Vpad, target[r0:r1], weight[r0:r1], loss_row=loss_rows[r0:r1],
                             want_grad=want_grad)
-    loss = torch.dot(loss_rows, weight)
+    loss = (loss_rows * weight).sum()       # (not torch.dot: a BLAS call inside a captured step)
     return loss, (dlogits if want_grad else None)
 
 

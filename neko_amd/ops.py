@@ -321,10 +321,22 @@ def sqnorm_f32(g, out_accum):
     _lib.call("neko_sqnorm_f32", _p(g), g.numel(), _p(out_accum), _stream())
 
 
-def adamw_step(p, g, m, v, p16, lr, beta1, beta2, eps, wd, gnorm_sq, max_norm, grad_scale, step, active):
+def adamw_step(p, g, m, v, p16, lr, beta1, beta2, eps, wd, gnorm_sq, max_norm, grad_scale, step, active, lr_dev=None):
     _lib.call("neko_adamw_step", _p(p), _p(g), _p(m), _p(v), _p(p16), p.numel(), float(lr), float(beta1),
               float(beta2), float(eps), float(wd), _p(gnorm_sq), float(max_norm), _p(grad_scale), _p(step),
-              _p(active), _stream())
+              _p(active), _p(lr_dev), _stream())
+
+
+_salt_holder = [None]
+
+
+def set_drop_salt(salt: Optional[torch.Tensor]) -> None:
+    """Register (or, with None, remove) the device uint32 every dropout site adds to its key (neko_set_drop_salt): the
+    per-step variation of the masks inside a captured training step.  The tensor is kept alive here."""
+    if salt is not None:
+        assert salt.is_cuda and salt.dtype == torch.int32 and salt.numel() == 1
+    _lib.call("neko_set_drop_salt", _p(salt))
+    _salt_holder[0] = salt
 
 
 def patch_resblock_fwd(images, w1, b1, gw, gb, w2, b2, mid, groups, want_x=True):

@@ -180,12 +180,10 @@ class ImageEmbedding(nn.Module):
             self._stager = HostStager()
         return self._stager.upload(t, dev)
 
-    def forward_many(self, xs):
-        """The reference embeds one example's images per call (gato_policy.py:221-233), drawing the patch positions
-        once per call.  Same semantics here -- positions are drawn per example, in example order, so the host RNG
-        sequence is the reference's -- but examples whose images share (H, W, dtype) go through the kernels as ONE
-        batch (one launch chain and one partial-gradient reduce instead of one per example).
-        Returns a list of (n_i * n_h * n_w, embed_dim) tensors, one per input."""
+    def prepare_many(self, xs):
+        """Host half of forward_many: patch positions drawn per example (reference RNG order), examples of equal image
+        shape grouped, every group's images and position indices on the device.  Returns a list of groups
+        (X (n,3,H,W) device, pos int32 [2, P] device, example indices, patches per example)."""
         if self._flat is None:
             raise RuntimeError("ImageEmbedding must be owned by a GatoPolicy (flat parameter storage)")
         dev = self._flat.device
@@ -202,8 +200,7 @@ class ImageEmbedding(nn.Module):
             wpos = np.broadcast_to(wp.numpy().astype(np.int32).reshape(1, 1, nw), (n, nh, nw)).reshape(-1)
             prepared.append((x, hpos, wpos, n * nh * nw))
             groups.setdefault((H, W, x.dtype), []).append(i)
-        params = [self._flat.param_of[nm] for nm in self.used_param_names(self._prefix)]
-        outs = [None] * len(xs)
+        out = []
         for idxs in groups.values():
             on_dev = [prepared[i][0] for i in idxs if prepared[i][0].is_cuda]
             on_cpu = [prepared[i][0] for i in idxs if not prepared[i][0].is_cuda]
@@ -218,8 +215,24 @@ class ImageEmbedding(nn.Module):
                 X = on_dev[0] if len(on_dev) == 1 else torch.cat(on_dev, dim=0)
             pos = np.stack([np.concatenate([prepared[i][1] for i in idxs]), np.concatenate([prepared[i][2] for i in idxs])])
             pos = self._upload(torch.from_numpy(np.ascontiguousarray(pos)), dev)
-            hpos, wpos = pos[0], pos[1]
-            out = _ImageEmbedFn.apply(self, X, hpos, wpos, *params)
-            for i, o in zip(idxs, torch.split(out, [prepared[i][3] for i in idxs], dim=0)):
+            out.append((X, pos, list(idxs), [prepared[i][3] for i in idxs]))
+        return out
+
+    def embed_groups(self, groups, n_examples: int):
+        """Device half of forward_many: one launch chain per image-shape group.  Returns one (n_i * n_h * n_w, embed_dim)
+        tensor per example, in example order."""
+        params = [self._flat.param_of[nm] for nm in self.used_param_names(self._prefix)]
+        outs = [None] * n_examples
+        for X, pos, idxs, counts in groups:
+            out = _ImageEmbedFn.apply(self, X, pos[0], pos[1], *params)
+            for i, o in zip(idxs, torch.split(out, counts, dim=0)):
                 outs[i] = o
         return outs
+
+    def forward_many(self, xs):
+        """The reference embeds one example's images per call (gato_policy.py:221-233), drawing the patch positions
+        once per call.  Same semantics here -- positions are drawn per example, in example order, so the host RNG
+        sequence is the reference's -- but examples whose images share (H, W, dtype) go through the kernels as ONE
+        batch (one launch chain and one partial-gradient reduce instead of one per example).
+        Returns a list of (n_i * n_h * n_w, embed_dim) tensors, one per input."""
+        return self.embed_groups(self.prepare_many(xs), len(xs))

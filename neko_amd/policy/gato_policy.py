@@ -315,6 +315,30 @@ class _PackInfo:
         self.loss_idx, self.n_loss, self.segments, self.order, self.rows = loss_idx, n_loss, segments, order, rows
 
 
+class _Prepared:
+    """A batch after the host half of tokenize_input_dicts (GatoPolicy._prepare): nothing but device tensors and the
+    host-known structure.  `tensors()` lists the device inputs in a fixed order (a captured step copies them into its
+    static twins), `signature()` is what must be equal for two batches to share one captured graph."""
+
+    def __init__(self):
+        self.B = self.T = 0
+        self.desc = self.cont = self.disc = None
+        self.img_order, self.img_ids, self.img_groups, self.given = [], [], [], []
+        self.pack: Optional[_PackInfo] = None
+
+    def tensors(self) -> List[torch.Tensor]:
+        ts = [self.desc, self.pack.loss_idx]
+        ts += [t for t in (self.cont, self.disc) if t is not None]
+        for X, pos, _, _ in self.img_groups:
+            ts += [X, pos]
+        return ts + list(self.given)
+
+    def signature(self):
+        return (self.B, self.T, self.pack.n_loss, tuple(self.pack.segments or ()), tuple(self.img_order), tuple(self.img_ids),
+                tuple((tuple(t.shape), str(t.dtype)) for t in self.tensors()),
+                tuple((tuple(idxs), tuple(cnt)) for _, _, idxs, cnt in self.img_groups))
+
+
 class _StubTokenizer:
     def __init__(self, vocab_size):
         self.vocab_size = vocab_size
@@ -505,9 +529,11 @@ class GatoPolicy(nn.Module):
         token_masks (B,T) f32) like the reference; the work is one descriptor upload + HIP kernels."""
         return self._tokenize(inputs, 0)[:4]
 
-    def _tokenize(self, inputs: list, ragged_groups: int):
-        """tokenize_input_dicts, optionally in the length-bucketed layout: returns (x, tokens, target masks, pad masks,
-        pack info) -- (B,T,.) tensors, or (1,M,.) tensors with pack.segments = [(row0, B_k, T_k)]."""
+    def _prepare(self, inputs: list, ragged_groups: int) -> "_Prepared":
+        """Host half of tokenize_input_dicts: the descriptor table (numpy), the concatenated value buffers, the image
+        groups with their patch positions and the loss-row indices, all on the device when this returns.  No kernel of
+        the model runs here, so a captured step (training/captured.py) can replay its graph on a `_Prepared` whose
+        tensors were copied into the graph's static inputs."""
         dev = self._dev()
         if dev.type != "cuda":
             raise RuntimeError("neko_amd.GatoPolicy computes on the GPU only (no CPU fallback)")
@@ -518,24 +544,19 @@ class GatoPolicy(nn.Module):
                 bool(np.isin(pb.desc[:, 0], (K_TOKEN, K_DEVID)).any()):
             raise RuntimeError("text tokens in a batch, but the data-parallel reducer was told that the text rows of "
                                "embed_token never receive gradients (GradReducer.declare_unused_rows)")
-        desc = self.image_embedding._upload(torch.from_numpy(pb.desc), dev)
-        cont = self._gather_values(pb.cont, torch.float32, dev)
-        disc = self._gather_values(pb.disc, torch.int32, dev)
-        img_emb = None
-        if pb.img_order:
-            # positions drawn per example (in order), kernels batched per image shape
-            img_ids = [idx for kind, idx in pb.img_order if kind == "img"]
-            embedded = dict(zip(img_ids, self.image_embedding.forward_many([pb.images[i] for i in img_ids])))
-            parts = []
-            for kind, idx in pb.img_order:
-                e = embedded[idx] if kind == "img" else pb.given_img_emb[idx].to(dev, torch.float32)
-                parts.append(e.reshape(-1, self.embed_dim))
-            img_emb = parts[0] if len(parts) == 1 else torch.cat(parts, dim=0)
-        params = [self._flat.param_of[n] for n in self._frontend_names()]
-        x, tokens, tmask, pmask = _PackEmbedV2.apply(self, desc, cont, disc, img_emb, pb.B * pb.T, *params)
-        B, T, d = pb.B, pb.T, self.embed_dim
+        pr = _Prepared()
+        pr.B, pr.T = pb.B, pb.T
+        pr.desc = self.image_embedding._upload(torch.from_numpy(pb.desc), dev)
+        pr.cont = self._gather_values(pb.cont, torch.float32, dev)
+        pr.disc = self._gather_values(pb.disc, torch.int32, dev)
+        pr.img_order = list(pb.img_order)
+        pr.img_ids = [idx for kind, idx in pb.img_order if kind == "img"]
+        # positions drawn per example (in order), kernels batched per image shape
+        pr.img_groups = self.image_embedding.prepare_many([pb.images[i] for i in pr.img_ids]) if pr.img_ids else []
+        pr.given = [e.to(dev, torch.float32) for e in pb.given_img_emb]
         # loss positions are known on the host (gato_policy.py:176-183): row (b,t) is selected when position t is
         # real and position t+1 is a target.  Uploaded once; lets the LM head run on the selected rows only.
+        B, T = pb.B, pb.T
         selm = np.zeros(B * T, dtype=bool)
         for (r0, Bk, Tk) in (pb.segments or [(0, B, T)]):
             dk = pb.desc[r0:r0 + Bk * Tk].reshape(Bk, Tk, 4)
@@ -544,9 +565,37 @@ class GatoPolicy(nn.Module):
             selm[r0:r0 + Bk * Tk] = sk.reshape(-1)
         sel_idx = np.flatnonzero(selm).astype(np.int32)
         idx_dev = self.image_embedding._upload(torch.from_numpy(sel_idx if sel_idx.size else np.zeros(1, np.int32)), dev)
-        pack = _PackInfo(idx_dev, int(sel_idx.size), pb.segments, pb.order, B * T)
-        self.last_pack = pack
-        return x.view(B, T, d), tokens.view(B, T), tmask.view(B, T), pmask.view(B, T), pack
+        pr.pack = _PackInfo(idx_dev, int(sel_idx.size), pb.segments, pb.order, B * T)
+        return pr
+
+    def _embed_prepared(self, pr: "_Prepared"):
+        """Device half: patch embedding of the image groups and the packing kernel.  Returns (x, tokens, target masks,
+        pad masks, pack info) -- (B,T,.) tensors, or (1,M,.) tensors with pack.segments = [(row0, B_k, T_k)]."""
+        img_emb = None
+        if pr.img_order:
+            embedded = dict(zip(pr.img_ids, self.image_embedding.embed_groups(pr.img_groups, len(pr.img_ids)))) if pr.img_ids else {}
+            parts = []
+            for kind, idx in pr.img_order:
+                e = embedded[idx] if kind == "img" else pr.given[idx]
+                parts.append(e.reshape(-1, self.embed_dim))
+            img_emb = parts[0] if len(parts) == 1 else torch.cat(parts, dim=0)
+        params = [self._flat.param_of[n] for n in self._frontend_names()]
+        x, tokens, tmask, pmask = _PackEmbedV2.apply(self, pr.desc, pr.cont, pr.disc, img_emb, pr.B * pr.T, *params)
+        B, T, d = pr.B, pr.T, self.embed_dim
+        self.last_pack = pr.pack
+        return x.view(B, T, d), tokens.view(B, T), tmask.view(B, T), pmask.view(B, T), pr.pack
+
+    def _tokenize(self, inputs: list, ragged_groups: int):
+        """tokenize_input_dicts, optionally in the length-bucketed layout."""
+        return self._embed_prepared(self._prepare(inputs, ragged_groups))
+
+    def _loss_from_prepared(self, pr: "_Prepared"):
+        """The training call `forward(inputs, compute_loss=True, return_logits=False)` on an already prepared batch."""
+        x, tokens, tmask, pmask, pack = self._embed_prepared(pr)
+        names = self.transformer._param_names() + ["predict_token.weight"]
+        params = [self._flat.param_of[n] for n in names]
+        _, loss = _PolicyCoreFn.apply(self, x, pmask.to(torch.float32), tokens, tmask, True, False, pack, *params)
+        return loss
 
     # ---- forward (gato_policy.py:156-192) -------------------------------------------------------------
     def forward(self, inputs: Optional[list] = None, compute_loss=False, **kwargs):

@@ -114,6 +114,7 @@ class TrainingArgs:
     save_dir: str = "models"
 
     # neko_amd extras
+    capture_step: bool = False             # one replayed HIP graph per batch structure (training/captured.py; single rank)
     text_vocab_size: int = 50257           # used when the gpt2 tokenizer cannot be downloaded
     seed: int = 1234
 

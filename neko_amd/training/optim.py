@@ -37,6 +37,9 @@ class NekoAdamW(torch.optim.Optimizer):
         self._last_act = None      # flags currently in `self.active`
         self.gnorm_sq = torch.zeros(1, dtype=torch.float64, device=dev)
         self._pending_clip: Optional[float] = None
+        #: optional 1-element fp32 device tensor holding the learning rate: when set, the AdamW kernel reads it instead of
+        #: the `lr` kernel argument (a captured step cannot change an argument between replays, training/captured.py)
+        self.lr_dev: Optional[torch.Tensor] = None
         self.grad_scale: Optional[torch.Tensor] = None    # set by the DP reducer (1/world)
         self.flags_reduce = None                          # DP: callable(active tensor) -> union over ranks
 
@@ -88,6 +91,9 @@ class NekoAdamW(torch.optim.Optimizer):
         # the flags rarely change from step to step: upload them only when they do (with a reducer attached the device
         # copy is overwritten by the MAX over ranks every step, so it is refreshed every step)
         if act != self._last_act or self.flags_reduce is not None:
+            if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("NekoAdamW.step inside a graph capture needs the 'range active' flags already on the "
+                                   "device: run one eager step on a batch of the same structure first")
             if self.active.is_cuda:
                 if self._stager is None:
                     from ..utils.utils import HostStager
@@ -105,7 +111,7 @@ class NekoAdamW(torch.optim.Optimizer):
             a, b = f.group_ranges[g]
             ops.adamw_step(f.data[a:b], f.grad[a:b], self.m[a:b], self.v[a:b], f.shadow[a:b], lr, b1, b2, eps, wd,
                            self.gnorm_sq if clip is not None else None, clip if clip is not None else 0.0,
-                           self.grad_scale, self.steps[g], self.active[i:i + 1])
+                           self.grad_scale, self.steps[g], self.active[i:i + 1], lr_dev=self.lr_dev)
         self._pending_clip = None
         f.mark_shadow_fresh()
 

@@ -37,6 +37,13 @@ class Trainer:
         # micro-batch whose loss is scaled by 1/k in backward; clip / optimiser / scheduler / zero_grad -- and the
         # data-parallel all-reduce -- only run on every k-th call
         self.accum_steps = max(1, int(getattr(args, "gradient_accumulation_steps", 1) or 1))
+        self.captured = None
+        if getattr(args, "capture_step", False):
+            if dp is not None or self.accum_steps > 1:
+                raise SystemExit("--capture_step: single rank, no gradient accumulation (the captured graph holds one whole step)")
+            from .captured import CapturedTrainStep
+            self.captured = CapturedTrainStep(model, optimizer, scheduler,
+                                              None if args.disable_grad_clip else args.grad_norm_clip)
         self._micro = 0
         self.start_time = None
         self.is_main = (not torch.distributed.is_initialized()) or torch.distributed.get_rank() == 0
@@ -138,6 +145,9 @@ class Trainer:
         t0 = time.time()
         batch = self.sample_batch()
         logs["time/sample_batch"] = time.time() - t0
+        if self.captured is not None:          # forward, backward, clip, AdamW, scheduler step, zero_grad: one graph replay
+            loss, _ = self.captured.step(batch)
+            return loss, logs
         _, loss = self.model.forward(inputs=batch, compute_loss=True, return_logits=False)
         self._micro += 1
         sync = self._micro % self.accum_steps == 0
