@@ -187,7 +187,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=32, help="sequences per GPU per step")
+    ap.add_argument("--batch", type=int, default=None,
+                    help="sequences per GPU per step; default 64 for the T = 1024 workloads, 32 (the README's) for c2 / c3 / c4.  64 x 1024 tokens = the reference's default global batch of 512 "
+                         "(arguments.py:62) spread over the 8 GPUs of a node; 18 GB of the 288 GB at 768d.  Round 1 ran 32: "
+                         "the optimiser tail, the weight-gradient split-K reductions and the launch tails amortise over twice "
+                         "the tokens (+5 % tokens/s; sweep 32 / 64 / 96 / 128 in DESIGN.md section 5)")
     ap.add_argument("--workload", default="m-mix", choices=["m-mix", "m-text", "c2", "c3", "c4", "c5-mix"])
     ap.add_argument("--model", default="768d", choices=["768d", "gato-1.2b"],
                     help="768d = the metric's 768d x 6L x 24H (hd=32); gato-1.2b = BASELINE configs[4], 2048d x 24L x 16H "
@@ -267,7 +271,7 @@ def main():
             dp.declare_unused_rows("embed_token.weight", 0, model.text_tokens)
             dp.no_text_declared = True
 
-    B = args.batch
+    B = args.batch if args.batch is not None else (32 if args.workload in ("c2", "c3", "c4") else 64)
     batches = [make_batch(args.workload, B, 1234 + rank + 100 * i, dev) for i in range(2)]
     Tlen = {"c2": 240, "c3": 240, "c4": 494}.get(args.workload, T)
 
