@@ -1,13 +1,15 @@
 #!/usr/bin/env python
 """gpurun_out/pmcL1 (FETCH_SIZE pass) + gpurun_out/pmcL2 (WRITE_SIZE pass) of tools/pmc_lmhead.sh ->
-profiles/r01_lmhead_traffic.json: HBM bytes per launch of the LM-head logits GEMM, corrected with the calibration
+gpurun_out/<tag>_lmhead_traffic.json (copied to profiles/): HBM bytes per launch of the LM-head logits GEMM, corrected with the calibration
 kernel of known byte count that runs in the same passes (MI355X_MICROARCH.md, HBM section)."""
 import collections
 import csv
 import glob
 import json
 import os
+import sys
 
+tag = sys.argv[1] if len(sys.argv) > 1 else "rXX"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 res = {}
 for d, cn in [("pmcL1", "FETCH_SIZE"), ("pmcL2", "WRITE_SIZE")]:
@@ -40,5 +42,5 @@ out = {
     "traffic_bytes_per_launch": round(fetch + write),
     "algorithmic_bytes_per_launch": M * K * 2 + VP * K * 2 + M * VP * 2,
 }
-json.dump(out, open(os.path.join(root, "profiles", "r01_lmhead_traffic.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(root, "gpurun_out", f"{tag}_lmhead_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))

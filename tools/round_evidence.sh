@@ -1,0 +1,32 @@
+#!/bin/bash
+# Everything the round's DESIGN / profiles cite, from ONE box: bench lines (m-mix default, m-mix B=32, m-text), rocprofv3
+# kernel-trace tables of both workloads (single stream), per-kernel PMC passes of the step (FETCH / WRITE / SQ), the LM-head
+# traffic calibration, GEMM and attention SQ counters.   tools/round_evidence.sh <tag>   -> gpurun_out/<tag>_*
+tag=${1:-rXX}
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+python3 bench.py > gpurun_out/${tag}_mmix_bench.json 2> gpurun_out/${tag}_bench.err
+python3 bench.py --batch 32 --no-cpu-baseline > gpurun_out/${tag}_mmix_b32_bench.json 2>> gpurun_out/${tag}_bench.err
+python3 bench.py --workload m-text --no-cpu-baseline > gpurun_out/${tag}_mtext_bench.json 2>> gpurun_out/${tag}_bench.err
+for w in c2 c3 c4; do python3 bench.py --workload $w --no-cpu-baseline > gpurun_out/${tag}_${w}_bench.json 2>> gpurun_out/${tag}_bench.err; done
+for w in m-mix m-text; do
+  s=${w#m-}
+  rm -rf gpurun_out/prof_${tag}_$s
+  NEKO_WGRAD_STREAM=0 rocprofv3 --kernel-trace -d gpurun_out/prof_${tag}_$s -o $s -- python3 bench.py --workload $w --steps 3 --warmup 10 --no-cpu-baseline > gpurun_out/prof_${tag}_$s.log 2>&1
+  db=$(find gpurun_out/prof_${tag}_$s -name "*.db" | head -1)
+  { echo "# NEKO_WGRAD_STREAM=0 (one stream: kernels do not overlap; the bench lines of this round use the default two streams); B = 64 x T = 1024 per step"; python3 tools/rocpd_stats.py $db 45; } > gpurun_out/${tag}_m${s}_kernel_stats.txt 2>&1
+  rm -rf gpurun_out/prof_${tag}_$s
+done
+bash tools/pmc_step.sh $tag > gpurun_out/${tag}_pmc_step.log 2>&1
+bash tools/pmc_lmhead.sh > gpurun_out/${tag}_pmc_lmhead.log 2>&1
+python3 tools/pmc_lmhead_summarise.py $tag > /dev/null 2>> gpurun_out/${tag}_pmc_lmhead.log
+rm -rf gpurun_out/pmcL1 gpurun_out/pmcL2
+bash tools/pmc_gemm.sh > gpurun_out/${tag}_gemm_counters_raw.txt 2>&1
+rm -rf gpurun_out/pmcG_*
+bash tools/pmc_attn.sh $tag 0.1 > /dev/null 2>&1
+python3 tools/gemm_bench.py --iters 30 > gpurun_out/${tag}_gemm_bench.txt 2>&1
+python3 tools/attn_bench.py --drop 0.1 --iters 30 > gpurun_out/${tag}_attn_bench.txt 2>&1
+python3 tools/attn_bench.py --iters 30 >> gpurun_out/${tag}_attn_bench.txt 2>&1
+python3 tools/decode_bench.py > gpurun_out/${tag}_decode_bench.txt 2>&1
+python3 tools/capture_probe.py c2 > gpurun_out/${tag}_capture_probe.txt 2>&1
+echo done
