@@ -201,6 +201,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dropout", type=float, default=0.1, help="attention/residual dropout (reference default 0.1)")
     ap.add_argument("--no-optimizer", action="store_true", help="time fwd+bwd(+all-reduce) only")
+    ap.add_argument("--force-dp", action="store_true",
+                    help="one rank, but with the data-parallel reducer attached and every collective issued through RCCL "
+                         "(world of one: sums are identities) -- the only way to execute the RCCL path on a one-GPU box")
     ap.add_argument("--capture", action="store_true",
                     help="run the step as ONE replayed HIP graph per batch structure (neko_amd/training/captured.py; "
                          "single rank): the lever for the README batch sizes (c2 / c3 / c4), where the host enqueue is the step")
@@ -237,7 +240,12 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    if world > 1 or args.force_dp:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29511")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             torch.distributed.init_process_group("nccl", device_id=dev)
         else:
@@ -260,8 +268,8 @@ def main():
     opt = NekoAdamW(model, lr=1e-4, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.1)
     dp = None
     ranks_seen = 1
-    if world > 1:
-        dp = GradReducer(model._flat, payload=os.environ.get("NEKO_DP_PAYLOAD", "fp32"))
+    if world > 1 or args.force_dp:
+        dp = GradReducer(model._flat, payload=os.environ.get("NEKO_DP_PAYLOAD", "fp32"), force_collectives=args.force_dp)
         dp.broadcast_parameters()
         t = torch.ones(1, device=dev)
         torch.distributed.all_reduce(t)              # a real collective: how many ranks RCCL actually connected
@@ -426,7 +434,7 @@ def main():
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or args.force_dp:
         torch.distributed.destroy_process_group()
 
 

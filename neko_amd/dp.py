@@ -22,7 +22,7 @@ import torch.distributed as dist
 
 
 class GradReducer:
-    def __init__(self, flat, bucket_bytes: int = 64 << 20, group=None, payload: str = "fp32"):
+    def __init__(self, flat, bucket_bytes: int = 64 << 20, group=None, payload: str = "fp32", force_collectives: bool = False):
         """payload: "fp32" (default: what DDP sends for the reference's fp32 master gradients) or "bf16" -- every bucket is
         rounded to bf16 into a staging buffer, summed over the ranks in bf16 and widened back into the fp32 gradient:
         half the bytes on each xGMI link (249 instead of 498 MB per step at 768d) for one extra rounding of each rank's
@@ -30,6 +30,9 @@ class GradReducer:
         train.py."""
         assert payload in ("fp32", "bf16"), payload
         self.payload = payload
+        #: issue every collective even in a world of ONE rank (a sum over one rank is the identity): the only way to run
+        #: the reducer's RCCL calls, streams and events on a one-GPU box (tests/test_dp_gpu.py, bench.py --force-dp)
+        self.force = bool(force_collectives)
         self.flat = flat
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -47,7 +50,7 @@ class GradReducer:
 
     def broadcast_parameters(self, src: int = 0) -> None:
         """One-time parameter broadcast rank0 -> all (DDP constructor semantics)."""
-        if self.world > 1:
+        if self.world > 1 or self.force:
             dist.broadcast(self.flat.data, src=src, group=self.group)
 
     #: ranges that do not take part in every step on every rank (no image in the batch, embeddings
@@ -57,13 +60,13 @@ class GradReducer:
 
     def group_ready(self, gname: str) -> None:
         """All gradient kernels of flat group `gname` are enqueued: launch its all-reduce(s)."""
-        if self.world == 1 or not self.sync or gname not in self.flat.group_ranges or gname in self.DEFERRED:
+        if (self.world == 1 and not self.force) or not self.sync or gname not in self.flat.group_ranges or gname in self.DEFERRED:
             return
         self._reduce(gname)
 
     def flush(self) -> None:
         """After backward: reduce the ranges that are not guaranteed to be touched on every rank."""
-        if self.world == 1 or not self.sync:
+        if (self.world == 1 and not self.force) or not self.sync:
             return
         for g in self.DEFERRED:
             if g in self.flat.group_ranges:
@@ -124,7 +127,7 @@ class GradReducer:
                     self.handles.append((dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True), None, g))
 
     def reduce_flags(self, flags: torch.Tensor) -> None:
-        if self.world > 1:   # stream-ordered (NCCL: the current stream waits on the comm stream, the host does not)
+        if self.world > 1 or self.force:   # stream-ordered (NCCL: the current stream waits on the comm stream, the host does not)
             dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=self.group)
 
     def finish(self) -> None:

@@ -109,3 +109,65 @@ def test_dp_two_ranks_match_single_process_average():
     assert abs(float(gn) - gn0) < 1e-4 * gn0
     for k, v in r0.items():
         assert torch.allclose(v, ref[k], rtol=2e-4, atol=2e-6), (k, float((v - ref[k]).abs().max()))
+
+
+def _rccl_worker(port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        from neko_amd.dp import GradReducer
+        from neko_amd.training.optim import NekoAdamW
+        res = {}
+        for payload in ("fp32", "bf16", None):                 # None: no reducer at all (the reference run)
+            m = _make()
+            opt = NekoAdamW(m, lr=1e-2, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.1)
+            dp = None
+            if payload is not None:
+                dp = GradReducer(m._flat, bucket_bytes=32 * 1024, payload=payload, force_collectives=True)
+                dp.broadcast_parameters()
+                dp.attach(m, opt)
+            losses = []
+            for b in (_to_dev(_batches()[0]), _to_dev(_batches()[1])):
+                _, loss = m.forward(inputs=b, compute_loss=True, return_logits=False)
+                loss.backward()
+                if dp is not None:
+                    dp.flush()
+                    dp.finish()
+                opt.clip_grad_norm_(0.5)
+                opt.step()
+                opt.zero_grad()
+                losses.append(float(loss.detach()))
+            torch.cuda.synchronize()
+            res[str(payload)] = (losses, {k: v.detach().cpu() for k, v in m.state_dict().items()
+                                          if v.dtype == torch.float32 and 4096 <= v.numel() < 70000})
+        out["res"] = res
+        out["backend"] = dist.get_backend()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_reducer_collectives_execute_on_rccl_in_a_world_of_one():
+    """The pool has one GPU per box, so RCCL cannot reduce across ranks here -- but it can RUN: with
+    force_collectives=True the reducer issues its broadcast, its per-range all-reduces from inside backward (fp32 and
+    bf16 payload), the deferred ranges and the flag reduction through the nccl (= RCCL) backend on its communication
+    stream.  A sum over one rank is the identity, so training must equal the run without a reducer (exactly for fp32,
+    to bf16 rounding of the gradients for the bf16 payload)."""
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as mgr:
+        out = mgr.dict()
+        p = ctx.Process(target=_rccl_worker, args=(port, out))
+        p.start()
+        p.join(timeout=600)
+        assert p.exitcode == 0, f"worker exit code {p.exitcode}"
+        res, backend = out["res"], out["backend"]
+    assert backend == "nccl"
+    l32, w32 = res["fp32"]
+    l16, w16 = res["bf16"]
+    lref, wref = res["None"]
+    assert l32 == lref
+    for k in wref:
+        assert torch.allclose(w32[k], wref[k], rtol=1e-6, atol=1e-7), k      # (atomics in the embedding scatter)
+        assert float((w16[k] - wref[k]).norm()) <= 2e-2 * float(wref[k].norm()) + 1e-6, k
+    assert abs(l16[1] - lref[1]) < 1e-3 * abs(lref[1])
