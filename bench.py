@@ -431,7 +431,7 @@ def main():
             "dp_payload": (dp.payload if dp is not None else None),
             "captured_step": (cap_stats if args.capture else None),
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # rank 0 at N = 1 only (the other ranks would idle behind it)
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1 or args.force_dp:

@@ -33,7 +33,7 @@ extern "C" {
 #define NEKO_ERR_UNSUPPORTED (-2)
 #define NEKO_ERR_LAUNCH (-3)
 
-#define NEKO_ABI_VERSION 11
+#define NEKO_ABI_VERSION 12
 
 int neko_abi_version(void);
 /* human-readable text for a return code (static storage) */
@@ -73,21 +73,24 @@ int neko_gemm_bf16(const uint16_t* A, long lda, int a_kstrided, const uint16_t* 
  * fwd: x f32 [M,d] -> y16 (bf16, may be null) and/or y32 (f32, may be null); mean/rstd f32 [M] (may be null).
  * bwd: dy f32 [M,d]; g_in (may be null) is the residual-stream gradient added to the result;
  *      dx f32 and/or dx16 bf16 (either may be null); dgamma/dbeta f32 [d] (+= when accumulate);
- *      workspace: neko_layernorm_bwd_blocks(M) * 2 * d floats.  drop_thr != 0: dx16 (only) additionally carries the
+ *      workspace: neko_layernorm_bwd_blocks(M) * 3 * d floats.  drop_thr != 0: dx16 (only) additionally carries the
  *      dropout mask of the residual-dropout site whose Linear consumes it (element index row*d + col).
+ *      dcolsum16 (may be null; needs dx16): f32 [d] += column sums of the dx16 values as stored = the bias gradient of
+ *      the Conv1D that consumes dx16 (trajectory_gpt2.py:253,277), folded into this pass.
  * ------------------------------------------------------------------------------------------- */
 int neko_layernorm_fwd(const float* x, const float* gamma, const float* beta, uint16_t* y16, float* y32,
                        float* mean, float* rstd, int M, int d, float eps, void* stream);
 int neko_layernorm_bwd_blocks(int M);
 int neko_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                        const float* g_in, float* dx, uint16_t* dx16, float* dgamma, float* dbeta, int accumulate,
-                       float* workspace, int M, int d, int drop_thr, unsigned drop_key, float drop_scale, void* stream);
+                       float* workspace, int M, int d, int drop_thr, unsigned drop_key, float drop_scale,
+                       float* dcolsum16, void* stream);
 /* same with dy as bf16 [M,d] (the dgrad GEMM's bf16 output, as autocast leaves it in the reference: the gradient of a
  * bf16 addmm input is bf16, trajectory_gpt2.py:274-277): half the bytes written by the GEMM and read here */
 int neko_layernorm_bwd_bf16dy(const uint16_t* dy, const float* x, const float* gamma, const float* mean,
                               const float* rstd, const float* g_in, float* dx, uint16_t* dx16, float* dgamma,
                               float* dbeta, int accumulate, float* workspace, int M, int d, int drop_thr,
-                              unsigned drop_key, float drop_scale, void* stream);
+                              unsigned drop_key, float drop_scale, float* dcolsum16, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Attention -- Attention._attn + split_heads/merge_heads (trajectory_gpt2.py:163-201,222-226,252)

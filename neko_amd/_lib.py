@@ -22,8 +22,8 @@ SIGNATURES = {
     "neko_scatter_rows_f32": [_vp, _vp, _vp, _i, _i, _vp],
     "neko_layernorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp],
     "neko_layernorm_bwd_blocks": [_i],
-    "neko_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, C.c_uint, _f, _vp],
-    "neko_layernorm_bwd_bf16dy": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, C.c_uint, _f, _vp],
+    "neko_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, C.c_uint, _f, _vp, _vp],
+    "neko_layernorm_bwd_bf16dy": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, C.c_uint, _f, _vp, _vp],
     "neko_mask_bias": [_vp, _vp, _vp, _i, _i, _vp],
     "neko_attn_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, C.c_uint, _f, _vp, _vp],
     "neko_attn_mask_dwords": [_i, _i, _i, _i],

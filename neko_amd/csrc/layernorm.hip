@@ -82,19 +82,23 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
                                                      const float* __restrict__ rstd, const float* __restrict__ g_in,
                                                      float* __restrict__ dx, bf16_t* __restrict__ dx16,
                                                      float* __restrict__ part, int M, int d, uint32_t drop_thr,
-                                                     uint32_t drop_key, float drop_scale) {
+                                                     uint32_t drop_key, float drop_scale, int want_colsum) {
   if (drop_thr) drop_key += neko_drop_salt();
-  extern __shared__ __attribute__((aligned(16))) float lds[];  // [4][2][d]
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // [4][3][d]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nvec = d >> 2;
   const float4* g4 = reinterpret_cast<const float4*>(gamma);
-  float4 gm[NV], dg[NV], db[NV];
+  // dc: column sums of the bf16 copy this kernel emits (dx16, after its dropout mask) = the bias gradient of the Linear
+  // that consumes it (Conv1D c_proj of the MLP / of the attention): folded in here, the separate colsum pass over the
+  // [M, d] bf16 matrix (12 launches and 2 x 50 MB of reads per layer pair at B*T = 32768) is gone
+  float4 gm[NV], dg[NV], db[NV], dc[NV];
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = lane + 64 * i;
     gm[i] = (c < nvec) ? g4[c] : make_float4(0.f, 0.f, 0.f, 0.f);
     dg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     db[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    dc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   const float inv_d = 1.0f / (float)d;
   // Software-pipelined over rows: the three input rows (x, dy, residual-stream gradient) of row r + stride are requested
@@ -177,6 +181,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
           pk.x = pack_bf16x2(o.x, o.y);
           pk.y = pack_bf16x2(o.z, o.w);
           reinterpret_cast<uint2*>(dx16 + (long)row * d)[c] = pk;
+          if (want_colsum) {       // sums of the ROUNDED values: what the separate pass over dx16 added up
+            dc[i].x += __uint_as_float(pk.x << 16); dc[i].y += __uint_as_float(pk.x & 0xffff0000u);
+            dc[i].z += __uint_as_float(pk.y << 16); dc[i].w += __uint_as_float(pk.y & 0xffff0000u);
+          }
         }
       }
     }
@@ -187,19 +195,21 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
   for (int i = 0; i < NV; ++i) {
     const int c = lane + 64 * i;
     if (c < nvec) {
-      l4[(wave * 2 + 0) * nvec + c] = dg[i];
-      l4[(wave * 2 + 1) * nvec + c] = db[i];
+      l4[(wave * 3 + 0) * nvec + c] = dg[i];
+      l4[(wave * 3 + 1) * nvec + c] = db[i];
+      l4[(wave * 3 + 2) * nvec + c] = dc[i];
     }
   }
   __syncthreads();
-  for (int idx = threadIdx.x; idx < 2 * nvec; idx += 256) {
+  const int nrow = want_colsum ? 3 : 2;
+  for (int idx = threadIdx.x; idx < nrow * nvec; idx += 256) {
     float4 a = l4[idx];
 #pragma unroll
     for (int w = 1; w < 4; ++w) {
-      const float4 b = l4[w * 2 * nvec + idx];
+      const float4 b = l4[w * 3 * nvec + idx];
       a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
     }
-    reinterpret_cast<float4*>(part + (long)blockIdx.x * 2 * d)[idx] = a;   // [block][2][d]
+    reinterpret_cast<float4*>(part + (long)blockIdx.x * 3 * d)[idx] = a;   // [block][3][d]
   }
 }
 
@@ -207,13 +217,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
 // block = 64 columns x 4 row slices (256 threads); 4 independent loads in flight per thread.
 __global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float* __restrict__ part, int nblk, int d,
                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                              int accumulate) {
+                                                              float* __restrict__ dcol, int accumulate) {
   __shared__ float red[4][64];
   const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
+  const int ncol = (dcol ? 3 : 2) * d;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  if (c < 2 * d) {
-    const long ld = 2L * d;
+  if (c < ncol) {
+    const long ld = 3L * d;
     int b = sl;
     for (; b + 12 < nblk; b += 16) {
       s0 += part[(long)b * ld + c];
@@ -225,10 +236,14 @@ __global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float* __res
   }
   red[sl][cl] = (s0 + s1) + (s2 + s3);
   __syncthreads();
-  if (sl == 0 && c < 2 * d) {
+  if (sl == 0 && c < ncol) {
     const float s = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
-    float* dst = (c < d) ? (dgamma + c) : (dbeta + (c - d));
-    *dst = accumulate ? (*dst + s) : s;
+    if (c >= 2 * d) {
+      dcol[c - 2 * d] += s;          // a bias gradient: always accumulated, like neko_colsum_bf16(accumulate = 1)
+    } else {
+      float* dst = (c < d) ? (dgamma + c) : (dbeta + (c - d));
+      *dst = accumulate ? (*dst + s) : s;
+    }
   }
 }
 
@@ -242,13 +257,13 @@ int fwd_launch(const float* x, const float* g, const float* b, bf16_t* y16, floa
 template <int NV>
 int bwd_launch(const void* dy, int dy16, const float* x, const float* g, const float* mean, const float* rstd,
                const float* g_in, float* dx, bf16_t* dx16, float* part, int nblk, int M, int d, int thr, unsigned key,
-               float scale, hipStream_t s) {
+               float scale, int want_colsum, hipStream_t s) {
   if (dy16)
-    hipLaunchKernelGGL((ln_bwd_kernel<NV, true>), dim3(nblk), dim3(256), (size_t)8 * d * sizeof(float), s, dy, x, g, mean,
-                       rstd, g_in, dx, dx16, part, M, d, (uint32_t)thr, key, scale);
+    hipLaunchKernelGGL((ln_bwd_kernel<NV, true>), dim3(nblk), dim3(256), (size_t)12 * d * sizeof(float), s, dy, x, g, mean,
+                       rstd, g_in, dx, dx16, part, M, d, (uint32_t)thr, key, scale, want_colsum);
   else
-    hipLaunchKernelGGL((ln_bwd_kernel<NV, false>), dim3(nblk), dim3(256), (size_t)8 * d * sizeof(float), s, dy, x, g, mean,
-                       rstd, g_in, dx, dx16, part, M, d, (uint32_t)thr, key, scale);
+    hipLaunchKernelGGL((ln_bwd_kernel<NV, false>), dim3(nblk), dim3(256), (size_t)12 * d * sizeof(float), s, dy, x, g, mean,
+                       rstd, g_in, dx, dx16, part, M, d, (uint32_t)thr, key, scale, want_colsum);
   NEKO_CHECK_LAUNCH();
   return NEKO_OK;
 }
@@ -269,7 +284,7 @@ int neko_layernorm_fwd_impl(const float* x, const float* gamma, const float* bet
   return fwd_launch<16>(x, gamma, beta, y16, y32, mean, rstd, M, d, eps, s);
 }
 
-// number of partial rows the backward writes for a given M (workspace = nblk*2*d floats)
+// number of partial rows the backward writes for a given M (workspace = nblk*3*d floats)
 int neko_layernorm_bwd_blocks_impl(int M) {
   static const int cap = [] { const char* e = getenv("NEKO_LN_BWD_BLOCKS"); return e ? atoi(e) : 256; }();   // one block per CU measured best (tools/ln_bench.py: 88 us vs 99 at 512)
   int nb = (M + 3) / 4;
@@ -279,22 +294,24 @@ int neko_layernorm_bwd_blocks_impl(int M) {
 int neko_layernorm_bwd_impl(const void* dy, int dy16, const float* x, const float* gamma, const float* mean,
                             const float* rstd, const float* g_in, float* dx, bf16_t* dx16, float* dgamma,
                             float* dbeta, int accumulate, float* workspace, int M, int d, int drop_thr,
-                            unsigned drop_key, float drop_scale, hipStream_t s) {
+                            unsigned drop_key, float drop_scale, float* dcolsum16, hipStream_t s) {
   if (M <= 0) return NEKO_OK;
   if (!dy || !x || !gamma || !mean || !rstd || !workspace || !dgamma || !dbeta) return NEKO_ERR_ARG;
+  if (dcolsum16 && !dx16) return NEKO_ERR_ARG;
+  const int wc = dcolsum16 ? 1 : 0;
   if ((d & 3) || d > 256 * LN_MAXV) return NEKO_ERR_UNSUPPORTED;
   const int nblk = neko_layernorm_bwd_blocks_impl(M);
   const int nv = (d / 4 + 63) / 64;
   int rc;
-  if (nv <= 1) rc = bwd_launch<1>(dy, dy16, x, gamma, mean, rstd, g_in, dx, dx16, workspace, nblk, M, d, drop_thr, drop_key, drop_scale, s);
-  else if (nv <= 2) rc = bwd_launch<2>(dy, dy16, x, gamma, mean, rstd, g_in, dx, dx16, workspace, nblk, M, d, drop_thr, drop_key, drop_scale, s);
-  else if (nv <= 3) rc = bwd_launch<3>(dy, dy16, x, gamma, mean, rstd, g_in, dx, dx16, workspace, nblk, M, d, drop_thr, drop_key, drop_scale, s);
-  else if (nv <= 4) rc = bwd_launch<4>(dy, dy16, x, gamma, mean, rstd, g_in, dx, dx16, workspace, nblk, M, d, drop_thr, drop_key, drop_scale, s);
-  else if (nv <= 8) rc = bwd_launch<8>(dy, dy16, x, gamma, mean, rstd, g_in, dx, dx16, workspace, nblk, M, d, drop_thr, drop_key, drop_scale, s);
-  else rc = bwd_launch<16>(dy, dy16, x, gamma, mean, rstd, g_in, dx, dx16, workspace, nblk, M, d, drop_thr, drop_key, drop_scale, s);
+  if (nv <= 1) rc = bwd_launch<1>(dy, dy16, x, gamma, mean, rstd, g_in, dx, dx16, workspace, nblk, M, d, drop_thr, drop_key, drop_scale, wc, s);
+  else if (nv <= 2) rc = bwd_launch<2>(dy, dy16, x, gamma, mean, rstd, g_in, dx, dx16, workspace, nblk, M, d, drop_thr, drop_key, drop_scale, wc, s);
+  else if (nv <= 3) rc = bwd_launch<3>(dy, dy16, x, gamma, mean, rstd, g_in, dx, dx16, workspace, nblk, M, d, drop_thr, drop_key, drop_scale, wc, s);
+  else if (nv <= 4) rc = bwd_launch<4>(dy, dy16, x, gamma, mean, rstd, g_in, dx, dx16, workspace, nblk, M, d, drop_thr, drop_key, drop_scale, wc, s);
+  else if (nv <= 8) rc = bwd_launch<8>(dy, dy16, x, gamma, mean, rstd, g_in, dx, dx16, workspace, nblk, M, d, drop_thr, drop_key, drop_scale, wc, s);
+  else rc = bwd_launch<16>(dy, dy16, x, gamma, mean, rstd, g_in, dx, dx16, workspace, nblk, M, d, drop_thr, drop_key, drop_scale, wc, s);
   if (rc != NEKO_OK) return rc;
-  hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * d + 63) / 64), dim3(256), 0, s, workspace, nblk, d, dgamma,
-                     dbeta, accumulate);
+  hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(((wc ? 3 : 2) * d + 63) / 64), dim3(256), 0, s, workspace, nblk, d, dgamma,
+                     dbeta, dcolsum16, accumulate);
   NEKO_CHECK_LAUNCH();
   return NEKO_OK;
 }

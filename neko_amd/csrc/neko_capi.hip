@@ -35,17 +35,19 @@ int neko_layernorm_fwd(const float* x, const float* gamma, const float* beta, ui
 int neko_layernorm_bwd_blocks(int M) { return neko_layernorm_bwd_blocks_impl(M); }
 int neko_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                        const float* g_in, float* dx, uint16_t* dx16, float* dgamma, float* dbeta, int accumulate,
-                       float* workspace, int M, int d, int drop_thr, unsigned drop_key, float drop_scale, void* stream) {
+                       float* workspace, int M, int d, int drop_thr, unsigned drop_key, float drop_scale, float* dcolsum16,
+                       void* stream) {
   if (drop_thr < 0 || drop_thr > 255) return NEKO_ERR_ARG;
   return neko_layernorm_bwd_impl(dy, 0, x, gamma, mean, rstd, g_in, dx, dx16, dgamma, dbeta, accumulate, workspace, M, d,
-                                 drop_thr, drop_key, drop_scale, S(stream));
+                                 drop_thr, drop_key, drop_scale, dcolsum16, S(stream));
 }
 int neko_layernorm_bwd_bf16dy(const uint16_t* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                        const float* g_in, float* dx, uint16_t* dx16, float* dgamma, float* dbeta, int accumulate,
-                       float* workspace, int M, int d, int drop_thr, unsigned drop_key, float drop_scale, void* stream) {
+                       float* workspace, int M, int d, int drop_thr, unsigned drop_key, float drop_scale, float* dcolsum16,
+                       void* stream) {
   if (drop_thr < 0 || drop_thr > 255) return NEKO_ERR_ARG;
   return neko_layernorm_bwd_impl(dy, 1, x, gamma, mean, rstd, g_in, dx, dx16, dgamma, dbeta, accumulate, workspace, M, d,
-                                 drop_thr, drop_key, drop_scale, S(stream));
+                                 drop_thr, drop_key, drop_scale, dcolsum16, S(stream));
 }
 
 int neko_mask_bias(const float* mask, float* kbias, int* kstart, int B, int T, void* stream) {

@@ -42,7 +42,7 @@ int neko_layernorm_bwd_blocks_impl(int M);
 int neko_layernorm_bwd_impl(const void* dy, int dy_is_bf16, const float* x, const float* gamma, const float* mean,
                             const float* rstd, const float* g_in, float* dx, bf16_t* dx16, float* dgamma,
                             float* dbeta, int accumulate, float* workspace, int M, int d, int drop_thr,
-                            unsigned drop_key, float drop_scale, hipStream_t s);
+                            unsigned drop_key, float drop_scale, float* dcolsum16, hipStream_t s);
 int neko_dropout_f32_impl(const float* x, float* y, long n, int thr, unsigned key, float scale, hipStream_t s);
 int neko_attn_fwd_impl(const bf16_t* qkv, const float* kbias, const int* kstart, bf16_t* out, float* lse, int B, int T,
                        int H, int hd, int drop_thr, unsigned drop_key, float drop_scale, uint32_t* dmask, hipStream_t s);

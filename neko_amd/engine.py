@@ -304,8 +304,10 @@ def stack_backward(P: StackParams, ctx: StackCtx, dhf: torch.Tensor,
     L = len(P.layers)
     # the bf16 gradient copy that enters layer i from above is consumed by its MLP c_proj: it carries that
     # site's residual-dropout mask; the fp32 residual-stream gradient never does
+    # (every LayerNorm backward also leaves the column sums of its bf16 output = the bias gradient of the projection that
+    # consumes it: b_pr of the layer above for ln_f / ln_1, b_o of the same layer for ln_2)
     ops.layernorm_bwd(dhf, ctx.xf, P.lnf_w, ctx.meanf, ctx.rstdf, P.g_lnf_w, P.g_lnf_b, g_in=None, dx=g, dx16=g16,
-                      drop=dr.resid_mlp[L - 1] if dr else None)
+                      drop=dr.resid_mlp[L - 1] if dr else None, colsum16=P.layers[L - 1].g_b_pr)
     if on_layer_done:
         on_layer_done(len(P.layers))
     for i in range(len(P.layers) - 1, -1, -1):
@@ -318,8 +320,7 @@ def stack_backward(P: StackParams, ctx: StackCtx, dhf: torch.Tensor,
         else:                                                                                 # GEGLU: h = gelu(pre) * gate
             ops.gemm(g16, lp.w_pr, M, 4 * d, d, ldb=d, out_bf16=d_pre)                        # d_h
             d_pre, d_gate = ops.geglu_bwd(d_pre, c.pre, c.gate)
-        SideStream.fork(lambda c=c, lp=lp, g16=g16: (_wgrad(c.h, g16, 4 * d, d, M, lp.g_w_pr),
-                                                    ops.colsum_bf16(g16, M, d, lp.g_b_pr)), g16)
+        SideStream.fork(lambda c=c, lp=lp, g16=g16: _wgrad(c.h, g16, 4 * d, d, M, lp.g_w_pr), g16)
         # gradients wrt the LayerNorm outputs leave their dgrad GEMMs as bf16, as autocast leaves them in the reference
         # (the gradient of a bf16 addmm input is bf16): half the bytes out of the GEMM and into the LayerNorm backward
         if d_gate is None:
@@ -335,12 +336,11 @@ def stack_backward(P: StackParams, ctx: StackCtx, dhf: torch.Tensor,
         g1 = torch.empty(M, d, dtype=F32, device=dev)
         g1_16 = torch.empty(M, d, dtype=BF16, device=dev)
         ops.layernorm_bwd(d_a2, c.x1, lp.ln2_w, c.mean2, c.rstd2, lp.g_ln2_w, lp.g_ln2_b, g_in=g, dx=g1, dx16=g1_16,
-                          drop=dr.resid_attn[i] if dr else None)
+                          drop=dr.resid_attn[i] if dr else None, colsum16=lp.g_b_o)
         # ---- attention: x1 = x + attn(a1 Wqkv + bqkv) Wo + bo -----------------------------------------
         d_o = torch.empty(M, d, dtype=BF16, device=dev)
         ops.gemm(g1_16, lp.w_o, M, d, d, ldb=d, out_bf16=d_o)
-        SideStream.fork(lambda c=c, lp=lp, g1_16=g1_16: (_wgrad(c.o, g1_16, d, d, M, lp.g_w_o),
-                                                          ops.colsum_bf16(g1_16, M, d, lp.g_b_o)), g1_16)
+        SideStream.fork(lambda c=c, lp=lp, g1_16=g1_16: _wgrad(c.o, g1_16, d, d, M, lp.g_w_o), g1_16)
         dqkv = _attn_bwd_segs(c.qkv, c.o, d_o, c.lse, ctx.segs, H, hd, dr.attn[i] if dr else None, dmask=c.dmask)
         d_a1 = _dgrad_to_ln(dqkv, lp.w_qkv, M, d, 3 * d, 3 * d)
         SideStream.fork(lambda c=c, lp=lp, dqkv=dqkv: (_wgrad(c.a1, dqkv, d, 3 * d, M, lp.g_w_qkv),
@@ -348,7 +348,8 @@ def stack_backward(P: StackParams, ctx: StackCtx, dhf: torch.Tensor,
         g0 = torch.empty(M, d, dtype=F32, device=dev)
         g0_16 = torch.empty(M, d, dtype=BF16, device=dev) if i > 0 else None
         ops.layernorm_bwd(d_a1, c.x, lp.ln1_w, c.mean1, c.rstd1, lp.g_ln1_w, lp.g_ln1_b, g_in=g1, dx=g0, dx16=g0_16,
-                          drop=dr.resid_mlp[i - 1] if (dr and i > 0) else None)
+                          drop=dr.resid_mlp[i - 1] if (dr and i > 0) else None,
+                          colsum16=P.layers[i - 1].g_b_pr if i > 0 else None)
         g, g16 = g0, g0_16
         if on_layer_done:
             on_layer_done(i)

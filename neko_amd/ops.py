@@ -147,14 +147,18 @@ def layernorm_fwd(x, gamma, beta, y16=None, y32=None, mean=None, rstd=None, eps:
               float(eps), _stream())
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, g_in=None, dx=None, dx16=None, accumulate=True, drop=None):
-    """dy fp32 or bf16 [M,d] (neko_layernorm_bwd / neko_layernorm_bwd_bf16dy)."""
+def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, g_in=None, dx=None, dx16=None, accumulate=True, drop=None,
+                  colsum16=None):
+    """dy fp32 or bf16 [M,d] (neko_layernorm_bwd / neko_layernorm_bwd_bf16dy).  colsum16: fp32 [d] that receives (+=) the
+    column sums of dx16 -- the bias gradient of the Linear that consumes dx16."""
     assert dy.is_cuda and dy.dtype in (torch.float32, BF16) and dy.is_contiguous(), "dy must be a contiguous f32 / bf16 device tensor"
     M, d = x.shape[0], x.shape[1]
     nblk = _lib.load().neko_layernorm_bwd_blocks(M)
-    ws = torch.empty(nblk * 2 * d, dtype=torch.float32, device=x.device)
+    ws = torch.empty(nblk * 3 * d, dtype=torch.float32, device=x.device)
+    if colsum16 is not None:
+        _chk(colsum16, torch.float32, "colsum16"); assert dx16 is not None and colsum16.numel() >= d
     _lib.call("neko_layernorm_bwd_bf16dy" if dy.dtype == BF16 else "neko_layernorm_bwd", _p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(g_in), _p(dx), _p(dx16),
-              _p(dgamma), _p(dbeta), int(accumulate), _p(ws), M, d, *_drop(drop), _stream())
+              _p(dgamma), _p(dbeta), int(accumulate), _p(ws), M, d, *_drop(drop), _p(colsum16), _stream())
 
 
 def mask_bias(mask: torch.Tensor):

@@ -55,6 +55,7 @@ class CapturedTrainStep:
         optimizer.lr_dev = torch.full((1,), float(optimizer.param_groups[0]["lr"]), dtype=torch.float32, device=dev)
         ops.set_drop_salt(self.salt)                 # eager steps of this model read the same salt: one code path
         self._eager_active = optimizer.active        # the optimiser's own flag tensor (eager steps rewrite it)
+        self._flat = model._flat                     # the graphs hold pointers into this storage
         self.replays = self.eager_steps = 0
 
     def close(self) -> None:
@@ -79,6 +80,9 @@ class CapturedTrainStep:
         """Returns (loss, pre-clip gradient norm or None) as device tensors (no host sync)."""
         m = self.model
         assert m.training, "CapturedTrainStep.step is the training step (model.train())"
+        if m._flat is not self._flat:
+            raise RuntimeError("CapturedTrainStep: the model's flat parameter storage was rebuilt (a .to() / .cuda() that really "
+                               "moved parameters) -- the captured graphs point into the old one; build a new CapturedTrainStep")
         rg = m.ragged_groups if ragged_groups is None else ragged_groups
         pr = m._prepare(batch, rg if len(batch) > 1 else 0)
         lr = float(self.sch.get_last_lr()[0]) if self.sch is not None else float(self.opt.param_groups[0]["lr"])

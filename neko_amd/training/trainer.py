@@ -54,6 +54,9 @@ class Trainer:
         logs = {}
         for i in range(iters):
             logs = self.train_iteration(self.args.log_eval_freq, i)
+        if self.captured is not None:      # back to plain eager state (dropout salt unregistered, lr from the param group)
+            self.captured.close()
+            self.captured = None
         if self.args.save_model and self.args.save_mode == "last" and self.is_main:
             from ..utils.utils import save_model
             save_model(self.model, self.exp_dir, f"checkpoint_{self.steps}", self.args, self.optimizer, self.scheduler)

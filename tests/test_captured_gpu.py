@@ -120,3 +120,19 @@ def test_eager_path_is_untouched_after_close():
     m2.load_state_dict(m.state_dict())
     _, l2 = m2.forward(inputs=b, compute_loss=True, return_logits=False)
     assert abs(float(l1) - float(l2)) < 2e-6 * abs(float(l2))
+
+
+def test_train_py_with_capture_step(tmp_path, monkeypatch):
+    """train.py --capture_step end to end: synthetic halfcheetah-shaped control + text, 12 steps, three batch structures at
+    most; the trainer's loop runs on replayed graphs and leaves the process in eager mode when it is done."""
+    import train
+    from neko_amd import ops
+    from neko_amd.training.arguments import parse_args
+    monkeypatch.chdir(tmp_path)
+    a = parse_args(["--embed_dim", "64", "--layers", "2", "--heads", "2", "--sequence_length", "96", "--batch_size", "6",
+                    "--training_steps", "12", "--log_eval_freq", "6", "--warmup_steps", "2", "--text_prop", "0.5",
+                    "--text_vocab_size", "128", "--resid_mid_channels", "128", "--capture_step", "--dropout", "0.1"])
+    try:
+        train.main(a)
+    finally:
+        ops.set_drop_salt(None)

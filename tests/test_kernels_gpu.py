@@ -184,8 +184,11 @@ def test_layernorm_fwd_bwd(ops, M, d, dy_bf16):
     close(y16, y, 2 ** -8, 1e-5, "ln fwd bf16")
     dg = torch.ones(d, device=DEV); db = torch.ones(d, device=DEV)       # accumulate onto ones
     dx = torch.empty(M, d, device=DEV); dx16 = torch.empty(M, d, dtype=torch.bfloat16, device=DEV)
+    cs = torch.full((d,), 2.0, device=DEV)                               # the folded column sums accumulate too
     ops.layernorm_bwd(bf(dy) if dy_bf16 else dy.to(DEV), xd, w.to(DEV), mean, rstd, dg, db, g_in=gin.to(DEV), dx=dx,
-                      dx16=dx16)
+                      dx16=dx16, colsum16=cs)
+    # column sums of the bf16 output as stored (the bias gradient of the Linear behind it): fp32 summation noise only
+    close(cs, dx16.float().sum(dim=0).cpu() + 2, 1e-5, 1e-4 * M ** 0.5, "ln colsum16")
     close(dx, xr.grad + gin, 1e-4, 1e-4, "ln dx")
     close(dx16, xr.grad + gin, 2 ** -8, 1e-4, "ln dx16")
     close(dg, wr.grad + 1, 1e-4, 1e-3, "ln dgamma")
