@@ -639,7 +639,14 @@ __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void gemm_glds_kernel(Gem
       mfma_step(a0, b0, 0, false);
       // tile kt+1 landed everywhere (only tile kt+2 of this wave's requests may be outstanding); every wave has consumed
       // tile kt-1, whose slot the pieces below refill with tile kt+NSTAGE-1
+#if NEKO_GEMM_DIAG == 11      // ablation (wrong results): block barrier only on every other k-tile, the DMA wait stays
+      if (kt & 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 3) * GLDS_PER_STAGE) : "memory");
+      else wait_dma_only_and_barrier<(NSTAGE - 3) * GLDS_PER_STAGE>();
+#elif NEKO_GEMM_DIAG == 12    // ablation (wrong results): no block barrier at all in the main loop
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 3) * GLDS_PER_STAGE) : "memory");
+#else
       wait_dma_only_and_barrier<(NSTAGE - 3) * GLDS_PER_STAGE>();
+#endif
       load_frags(kt + 1, 0, a0, b0);
       mfma_step(a1, b1, kt + NSTAGE - 1, true);
     }
