@@ -741,6 +741,17 @@ int launch(const GemmArgs& a, hipStream_t s) {
     // prefer ONE 8-wave 256x256 block per CU over two 4-wave 256x128 blocks on some CUs (+16..19 %).
     // (the 2048d geometry agrees where it overlaps: N = 2048 dgrads at 8192 rows are exactly one round of 256x256 tiles
     // and gain 13..15 % on them; its K >= 2048 forward shapes keep 256x256 even at one round)
+    // Round 2, 65536 rows (64 x 1024 tokens per step; profiles/r02_gemm_tile_sweep_65536.txt): the N = 768 dgrads are
+    // 768 tiles of 256x256 = exactly three rounds of 256 CUs there, and one 8-wave 256x256 block per CU then beats two
+    // 4-wave 256x128 blocks by 15-18 % (dgrad fc 363 -> 315 us, dgrad qkv 278 -> 238, dgrad o 92 -> 85); at 32768 rows the
+    // same choice is 1.5 rounds and loses.  Likewise the forward attention projection (N = K = 768) on 256x128: three full
+    // rounds of 512 slots at 65536 rows (161 -> 140 us), 1.5 at 32768.  Hence: fill of the last round decides.
+    auto fill = [&](int bm, int bn, int slots) {
+      const long t = (long)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn) * (a.splitk > 1 ? a.splitk : 1);
+      return (double)t / (double)(((t + slots - 1) / slots) * slots);
+    };
+    if (A_KC && B_KC && cfg == 2 && a.N % 256 == 0 && a.N <= 1024 && fill(256, 256, 256) >= 0.9) cfg = 3;
+    if (A_KC && !B_KC && cfg == 0 && big_out && a.N % 128 == 0 && a.N <= 1024 && fill(256, 128, 512) >= 0.9) cfg = 2;
     const long t3n = (long)((a.M + 255) / 256) * ((a.N + 255) / 256) * (a.splitk > 1 ? a.splitk : 1);
     const bool wide = a.N > 2048;
     if (A_KC) {
