@@ -1,9 +1,9 @@
 #!/usr/bin/env python
-"""LayerNorm forward / backward at the metric shape (32768 rows x 768): time and effective HBM rate."""
+"""LayerNorm forward / backward at the metric shape (32768 rows x 768, or argv[1] rows): time and effective HBM rate."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from neko_amd import ops
-M, d = 32768, 768
+M, d = (int(sys.argv[1]) if len(sys.argv) > 1 else 32768), 768
 dev = "cuda"
 x = torch.randn(M, d, device=dev); w = torch.randn(d, device=dev); b = torch.randn(d, device=dev)
 dy = torch.randn(M, d, device=dev); gin = torch.randn(M, d, device=dev)

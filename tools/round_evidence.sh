@@ -9,6 +9,9 @@ python3 bench.py > gpurun_out/${tag}_mmix_bench.json 2> gpurun_out/${tag}_bench.
 python3 bench.py --batch 32 --no-cpu-baseline > gpurun_out/${tag}_mmix_b32_bench.json 2>> gpurun_out/${tag}_bench.err
 python3 bench.py --workload m-text --no-cpu-baseline > gpurun_out/${tag}_mtext_bench.json 2>> gpurun_out/${tag}_bench.err
 for w in c2 c3 c4; do python3 bench.py --workload $w --no-cpu-baseline > gpurun_out/${tag}_${w}_bench.json 2>> gpurun_out/${tag}_bench.err; done
+python3 bench.py --model gato-1.2b --workload m-text --batch 8 --steps 10 --warmup 3 > gpurun_out/${tag}_gato1p2b_mtext_b8_bench.json 2>> gpurun_out/${tag}_bench.err
+python3 bench.py --workload c5-mix --batch 32 --no-cpu-baseline > gpurun_out/${tag}_c5mix_pad_bench.json 2>> gpurun_out/${tag}_bench.err
+python3 bench.py --workload c5-mix --batch 32 --ragged-groups 4 --no-cpu-baseline > gpurun_out/${tag}_c5mix_rag4_bench.json 2>> gpurun_out/${tag}_bench.err
 for w in m-mix m-text; do
   s=${w#m-}
   rm -rf gpurun_out/prof_${tag}_$s
