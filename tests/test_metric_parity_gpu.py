@@ -8,7 +8,9 @@ dropout 0 (gato/policy/gato_policy.py:156-192).
              selection at V = 52305 all run here;
   * C5 geom  2048d x 16H (hd = 128, streaming attention kernels), 2 layers, V = 52305, T = 1024, same batch;
   * hd = 64  512d x 8H, 2 layers, small vocabulary, mixed ragged batch;
-  * C5 depth 2048d x 24L x 16H (the full Gato-1.2B stack, 1.2 B transformer parameters) at T = 201, V = 3048.
+  * C5 depth 2048d x 24L x 16H (the full Gato-1.2B stack, 1.2 B transformer parameters) at T = 201, V = 3048;
+  * C2 / C3  the MuJoCo geometries of BASELINE configs[1..2] (halfcheetah / hopper / walker2d token layouts, T = 240) and
+  * C4       the Atari geometry of configs[3] (36 patches + SEP + action per timestep, T = 494), both on the full 768d model.
 
 Gates (SURVEY.md 8(d), bf16 MFMA operands with fp32 accumulation): loss 1e-3 relative, sub-sampled logits 2e-2 of the
 logits scale, every per-parameter gradient L2 norm 2e-2 relative, total gradient norm 5e-3 relative."""
@@ -127,3 +129,29 @@ def test_c5_full_depth_24_layers_2048d_hd128_vs_oracle():
     # measured: loss 4e-5, logits 7e-3, worst per-parameter gradient norm 7e-3, total norm 4e-3 (24 layers of bf16-operand
     # rounding accumulate in the total: its gate is 1e-2 here, the others are the standard ones)
     _compare(cfg, batch, seed=14, row_stride=5, total_tol=1e-2)
+
+
+def _control(n_obs, n_act, n_ts, g):
+    return {"continuous_obs": torch.randn(n_ts, n_obs, generator=g), "continuous_actions": torch.rand(n_ts, n_act, generator=g) * 2 - 1}
+
+
+def test_c2_c3_mujoco_shapes_768d_6L_vs_oracle():
+    """BASELINE configs[1] and [2] at their own geometry and the full model (768d x 6L x 24H, V = 52305): halfcheetah
+    (17 obs + SEP + 6 act) x 10 = 240 tokens, hopper (11 + 1 + 3) x 16 = 240, walker2d (17 + 1 + 6) x 10 = 240, plus one
+    shorter hopper episode (13 timesteps = 195 tokens) that the batch left-pads -- against the CPU oracle."""
+    cfg = O.OracleConfig(embed_dim=768, layers=6, heads=24)
+    g = torch.Generator().manual_seed(21)
+    batch = [_control(17, 6, 10, g), _control(11, 3, 16, g), _control(17, 6, 10, g), _control(11, 3, 13, g),
+             _control(17, 6, 10, g), _control(11, 3, 16, g)]
+    _compare(cfg, batch, seed=15, row_stride=11)
+
+
+def test_c4_atari_shape_768d_6L_vs_oracle():
+    """BASELINE configs[3] at its own geometry: Breakout-like 96 x 96 frames -> 36 patches + SEP + 1 discrete action = 38
+    tokens per timestep, 13 timesteps = 494 positions (sequence length 512), full model, against the CPU oracle (image
+    patch path: MFMA convolutions, GroupNorm, patch positions, 768 -> d projection, all with gradients)."""
+    cfg = O.OracleConfig(embed_dim=768, layers=6, heads=24, context_len=512)
+    g = torch.Generator().manual_seed(22)
+    batch = [{"images": torch.floor(torch.rand(13, 3, 96, 96, generator=g) * 256),
+              "discrete_actions": torch.randint(0, 4, (13, 1), generator=g).to(torch.int32)} for _ in range(2)]
+    _compare(cfg, batch, seed=16, row_stride=13)
