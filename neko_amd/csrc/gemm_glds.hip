@@ -28,14 +28,17 @@
 
 #if NEKO_GEMM_DIAG == 9
 // phase trace (diagnostic builds only): per block 4 x s_memrealtime (100 MHz) = start, first tile landed, k-loop done,
-// epilogue done; buffer set with neko_gemm_diag_trace()
+// epilogue done (and, for the first 32768 blocks, s_memtime at the same points in the second half of the buffer); buffer set with neko_gemm_diag_trace()
 __device__ unsigned long long* g_neko_gemm_trace = nullptr;
 extern "C" int neko_gemm_diag_trace(void* buf) {
   return hipMemcpyToSymbol(HIP_SYMBOL(g_neko_gemm_trace), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
 }
 #define NEKO_TRACE(slot)                                                                                       \
   do {                                                                                                         \
-    if (g_neko_gemm_trace && threadIdx.x == 0) g_neko_gemm_trace[(long)blockIdx.x * 4 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
+    if (g_neko_gemm_trace && threadIdx.x == 0) {                                                               \
+      g_neko_gemm_trace[(long)blockIdx.x * 4 + (slot)] = __builtin_amdgcn_s_memrealtime();                     \
+      if (blockIdx.x < 32768) g_neko_gemm_trace[131072 + (long)blockIdx.x * 4 + (slot)] = __builtin_amdgcn_s_memtime(); \
+    }                                                                                                          \
   } while (0)
 #else
 #define NEKO_TRACE(slot) do { } while (0)
@@ -66,6 +69,35 @@ __device__ __forceinline__ void glds16(const bf16_t* src, char* lds_dst_wave_uni
       : "=&s"(keep)
       : "v"(src), "s"(dst)
       : "memory");
+}
+
+// The in-loop form: wave-uniform 64-bit base in SGPRs + a loop-invariant 32-bit per-lane byte offset, LDS destination
+// handed over IN M0 (register constraint: the compiler writes M0 itself, one s_add, and knows it is live) -- three
+// instructions per piece (s_add m0 / s_nop / global_load_lds) where the generic-pointer form above costs eleven
+// (64-bit VALU address add, generic->LDS cast with its null check, M0 save and restore).  In the 4-wave / 8-wave main
+// loops a wave issues 4-8 of these per k-tile between 16-32 MFMAs: the saved issue slots go to the matrix pipe.
+__device__ __forceinline__ void glds16_s(const bf16_t* base_uniform, unsigned byte_off, unsigned lds_dst_wave_uniform) {
+  asm volatile("s_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+               :
+               : "v"(byte_off), "s"(base_uniform), "{m0}"(lds_dst_wave_uniform)
+               : "memory");
+}
+template <int EXT, int NW>
+__device__ __forceinline__ unsigned piece_off_kc(long ld, int r0, int nrows, int wave, int lane, int i) {
+  constexpr int PER = EXT / 16 / NW;
+  const int row = (wave * PER + i) * 16 + (lane >> 2);
+  const int piece = (lane & 3) ^ ((row >> 2) & 3);
+  const int gr = min(r0 + row, nrows - 1) - r0;
+  return (unsigned)((gr * ld + piece * 8) * 2);
+}
+template <int EXT, int NW>
+__device__ __forceinline__ unsigned piece_off_ks(long ld, int c0, int ncols, int wave, int lane, int i) {
+  constexpr int PER = EXT / 16 / NW;
+  constexpr int PPR = EXT / 8;
+  const int kr = (wave * PER + i) * (64 / PPR) + lane / PPR;
+  const int piece = (lane % PPR) ^ ((kr & 3) << 2);
+  const int gc = min(c0 + piece * 8, ncols - 8);
+  return (unsigned)((kr * ld + gc) * 2);
 }
 
 // ---- staging: EXT/16/NW wave-instructions (1 KiB each) per operand per wave ---------------------------------
@@ -271,17 +303,15 @@ __device__ __forceinline__ void epilogue_fast(const GemmArgs& p, f32x16 (&acc)[C
       if (F & F_GELU) {
         const uint32_t p01 = pack_bf16x2(v[0], v[1]), p23 = pack_bf16x2(v[2], v[3]);     // bf16 pre-activation
         if (F & F_PRE) *reinterpret_cast<uint2*>(ppre) = make_uint2(p01, p23);
-        v[0] = gelu_f(__uint_as_float(p01 << 16));
-        v[1] = gelu_f(__uint_as_float(p01 & 0xffff0000u));
-        v[2] = gelu_f(__uint_as_float(p23 << 16));
-        v[3] = gelu_f(__uint_as_float(p23 & 0xffff0000u));
+        const f32x2_v g01 = gelu2_f((f32x2_v){__uint_as_float(p01 << 16), __uint_as_float(p01 & 0xffff0000u)});
+        const f32x2_v g23 = gelu2_f((f32x2_v){__uint_as_float(p23 << 16), __uint_as_float(p23 & 0xffff0000u)});
+        v[0] = g01.x; v[1] = g01.y; v[2] = g23.x; v[3] = g23.y;
       }
       if (F & F_GELUBWD) {
         const uint2 q = pre_act[st];
-        v[0] *= gelu_grad_f(__uint_as_float(q.x << 16));
-        v[1] *= gelu_grad_f(__uint_as_float(q.x & 0xffff0000u));
-        v[2] *= gelu_grad_f(__uint_as_float(q.y << 16));
-        v[3] *= gelu_grad_f(__uint_as_float(q.y & 0xffff0000u));
+        const f32x2_v g01 = gelu_grad2_f((f32x2_v){__uint_as_float(q.x << 16), __uint_as_float(q.x & 0xffff0000u)});
+        const f32x2_v g23 = gelu_grad2_f((f32x2_v){__uint_as_float(q.y << 16), __uint_as_float(q.y & 0xffff0000u)});
+        v[0] *= g01.x; v[1] *= g01.y; v[2] *= g23.x; v[3] *= g23.y;
       }
       if (F & F_DROP) drop4(v, didx, p.drop_key, p.drop_thr, p.drop_scale);
       if (F & F_RESID) {
@@ -534,6 +564,7 @@ __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void gemm_glds_kernel(Gem
 
   // one piece (wave-instruction) of tile kt's stage: pieces 0..PER_A-1 fill A, the rest B
   constexpr int PER_A = BM / 16 / C::NW, NP = GLDS_PER_STAGE, NM = (BK / 16) * TM * TN;
+#ifdef NEKO_GEMM_FATPIECE
   auto stage_piece = [&](int kt, int pc) {
     const int k0 = kbeg + kt * BK;
     char* la = smem + (kt % NSTAGE) * C::STAGE_BYTES;
@@ -546,6 +577,27 @@ __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void gemm_glds_kernel(Gem
       else stage_ks_piece<BN, C::NW>(p.B, p.ldb, n0, p.N, k0, lb, wave, lane, pc - PER_A);
     }
   };
+#else
+  constexpr int PER_B = BN / 16 / C::NW;
+  unsigned voffA[PER_A], voffB[PER_B];
+#pragma unroll
+  for (int i = 0; i < PER_A; ++i)
+    voffA[i] = A_KC ? piece_off_kc<BM, C::NW>(p.lda, m0, p.M, wave, lane, i) : piece_off_ks<BM, C::NW>(p.lda, m0, p.M, wave, lane, i);
+#pragma unroll
+  for (int i = 0; i < PER_B; ++i)
+    voffB[i] = B_KC ? piece_off_kc<BN, C::NW>(p.ldb, n0, p.N, wave, lane, i) : piece_off_ks<BN, C::NW>(p.ldb, n0, p.N, wave, lane, i);
+  const bf16_t* const gA0 = A_KC ? p.A + (long)m0 * p.lda + kbeg : p.A + (long)kbeg * p.lda;
+  const bf16_t* const gB0 = B_KC ? p.B + (long)n0 * p.ldb + kbeg : p.B + (long)kbeg * p.ldb;
+  const long gstepA = A_KC ? (long)BK : (long)BK * p.lda, gstepB = B_KC ? (long)BK : (long)BK * p.ldb;
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane(
+      (unsigned)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)smem));
+  const unsigned ldsA = lds0 + wave * PER_A * 1024, ldsB = lds0 + C::A_BYTES + wave * PER_B * 1024;
+  auto stage_piece = [&](int kt, int pc) {
+    const unsigned slot = (unsigned)(kt % NSTAGE) * C::STAGE_BYTES;
+    if (pc < PER_A) glds16_s(gA0 + kt * gstepA, voffA[pc], ldsA + slot + pc * 1024);
+    else glds16_s(gB0 + kt * gstepB, voffB[pc - PER_A], ldsB + slot + (pc - PER_A) * 1024);
+  };
+#endif
   // k-tile body.  With STAGE the NP DMA pieces of tile kt+NSTAGE-1 are issued BETWEEN the MFMA groups instead of in one
   // burst behind the barrier: a burst makes all waves of the block queue NP 1-KiB requests at once on the CU's single
   // L2->LDS path (16 cycles each), every wave sits in its VMEM issue for up to NP*NW*16 cycles with no MFMA queued, and
@@ -625,6 +677,46 @@ __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void gemm_glds_kernel(Gem
           }
         }
     };
+#ifndef NEKO_GEMM_BURST
+    // the TM + TN fragment reads of the NEXT k-step are spread between this step's MFMAs (one read after every
+    // TM*TN/(TM+TN)-th MFMA; a[0] and every b[j] first: the next step's first MFMAs need them) instead of being issued
+    // as one burst ahead of the step, which made the first MFMAs of every step wait for an LDS round trip (+3..5 %;
+    // -DNEKO_GEMM_BURST rebuilds the burst form for A/B runs)
+    auto step_il = [&](const bf16x8_v (&a)[TM], const bf16x8_v (&b)[TN], bf16x8_v (&an)[TM], bf16x8_v (&bn)[TN],
+                       int kt_load, int ks_load, bool do_load, int kt_stage, bool stage_now) {
+      const char* la = smem + (kt_load % NSTAGE) * C::STAGE_BYTES;
+      const char* lb = la + C::A_BYTES;
+      int pc = 0, lc = 0;
+      constexpr int NL = TM + TN;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+          const int m = i * TN + j;
+#pragma unroll
+          for (int l = 0; l < NL; ++l) {
+            if (l == lc && do_load && m == (l * TM * TN) / NL) {
+              __builtin_amdgcn_sched_barrier(0);
+              // order: a0, b0 .. b(TN-1), a1 .. a(TM-1)
+              if (l == 0) an[0] = A_KC ? frag_kc(la, (wm * TM) * 32, ks_load, lane) : frag_ks<BM>(la, (wm * TM) * 32, ks_load, lane);
+              else if (l <= TN) bn[l - 1] = B_KC ? frag_kc(lb, (wn * TN + l - 1) * 32, ks_load, lane)
+                                                  : frag_ks<BN>(lb, (wn * TN + l - 1) * 32, ks_load, lane);
+              else an[l - TN] = A_KC ? frag_kc(la, (wm * TM + l - TN) * 32, ks_load, lane)
+                                     : frag_ks<BM>(la, (wm * TM + l - TN) * 32, ks_load, lane);
+              __builtin_amdgcn_sched_barrier(0);
+              ++lc;
+            }
+          }
+          if (stage_now && pc < NP && m == ((pc + 1) * TM * TN) / NP - 1) {
+            __builtin_amdgcn_sched_barrier(0);
+            stage_piece(kt_stage, pc);
+            __builtin_amdgcn_sched_barrier(0);
+            ++pc;
+          }
+        }
+    };
+#endif
     bf16x8_v a0[TM], b0[TN], a1[TM], b1[TN];
     if (nkt > 0) {
       // tile 0 visible (tiles 1 .. NSTAGE-2 may still be in flight)
@@ -634,6 +726,13 @@ __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void gemm_glds_kernel(Gem
       load_frags(0, 0, a0, b0);
     }
     const int nmain = max(0, nkt - (NSTAGE - 1));
+#ifndef NEKO_GEMM_BURST
+    for (int kt = 0; kt < nmain; ++kt) {
+      step_il(a0, b0, a1, b1, kt, 1, true, 0, false);
+      wait_dma_only_and_barrier<(NSTAGE - 3) * GLDS_PER_STAGE>();
+      step_il(a1, b1, a0, b0, kt + 1, 0, true, kt + NSTAGE - 1, true);
+    }
+#else
     for (int kt = 0; kt < nmain; ++kt) {
       load_frags(kt, 1, a1, b1);
       mfma_step(a0, b0, 0, false);
@@ -650,6 +749,7 @@ __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void gemm_glds_kernel(Gem
       load_frags(kt + 1, 0, a0, b0);
       mfma_step(a1, b1, kt + NSTAGE - 1, true);
     }
+#endif
     for (int kt = nmain; kt < nkt; ++kt) {      // drain: nothing left to request
       load_frags(kt, 1, a1, b1);
       mfma_step(a0, b0, 0, false);
@@ -699,6 +799,7 @@ using C128s3 = Cfg<2, 2, 2, 2, 3>;
 using C128s4 = Cfg<2, 2, 2, 2, 4>;
 using C256x128 = Cfg<2, 2, 4, 2, 3>;
 using C256x256 = Cfg<2, 4, 4, 2, 4>;
+using C256x256w4 = Cfg<2, 2, 4, 4, 4>;     // 4 waves x (128 x 128), one wave per SIMD, 256 accumulator AGPRs (the vendor kernel's geometry)
 
 template <bool A_KC, bool B_KC, class C>
 int launch_cfg(const GemmArgs& a, hipStream_t s) {
@@ -709,7 +810,7 @@ int launch_cfg(const GemmArgs& a, hipStream_t s) {
   return NEKO_OK;
 }
 
-// tile configuration: NEKO_GEMM_TILE=0..3 forces one (benchmarking); default heuristic below
+// tile configuration: NEKO_GEMM_TILE=0..4 forces one (benchmarking); default heuristic below
 int forced_tile() {
   static const int v = [] { const char* e = getenv("NEKO_GEMM_TILE"); return e ? atoi(e) : -1; }();
   return v;
@@ -766,6 +867,7 @@ int launch(const GemmArgs& a, hipStream_t s) {
     case 1: return launch_cfg<A_KC, B_KC, C128s4>(a, s);
     case 2: return launch_cfg<A_KC, B_KC, C256x128>(a, s);
     case 3: return launch_cfg<A_KC, B_KC, C256x256>(a, s);
+    case 4: return launch_cfg<A_KC, B_KC, C256x256w4>(a, s);
     default: return launch_cfg<A_KC, B_KC, C128s3>(a, s);
   }
 }

@@ -86,6 +86,45 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
   return fmaf(x * 0.39894228040143267794f, e, 0.5f * (1.0f + er));
 }
 
+// Two elements at a time on the packed fp32 pipe (v_pk_fma_f32 / v_pk_mul_f32: two lanes' worth of fp32 per issue slot):
+// the GEMM epilogues with GELU / GELU' are VALU-bound (256 x 256 results x ~16 slots each per tile against a 24-k-tile
+// main loop), and everything in the formulas above except v_rcp / v_exp / the sign transfer packs.  Same series, same
+// constants; gelu is rearranged so that the sign never has to be transferred:
+//   gelu(x)  = x/2 + |x|/2 * m,              m = 1 - poly(t) e   (erf(|z|))
+//   gelu'(x) = 1/2 + copysign(m/2, x) + x e / sqrt(2 pi)
+typedef float f32x2_v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void erf_parts2(f32x2_v x, f32x2_v ax, float pscale, f32x2_v& poly, f32x2_v& e) {
+  const f32x2_v d = __builtin_elementwise_fma(ax, (f32x2_v)(0.70710678118654752440f * 0.3275911f), (f32x2_v)(1.0f));
+  f32x2_v t;
+  t.x = __builtin_amdgcn_rcpf(d.x);
+  t.y = __builtin_amdgcn_rcpf(d.y);
+  const f32x2_v a = (x * x) * (-0.5f * 1.44269504088896340736f);          // -(x/sqrt2)^2 * log2(e)
+  e.x = __builtin_amdgcn_exp2f(a.x);
+  e.y = __builtin_amdgcn_exp2f(a.y);
+  poly = __builtin_elementwise_fma(t, (f32x2_v)(1.061405429f * pscale), (f32x2_v)(-1.453152027f * pscale));
+  poly = __builtin_elementwise_fma(poly, t, (f32x2_v)(1.421413741f * pscale));
+  poly = __builtin_elementwise_fma(poly, t, (f32x2_v)(-0.284496736f * pscale));
+  poly = __builtin_elementwise_fma(poly, t, (f32x2_v)(0.254829592f * pscale));
+  poly *= t;
+}
+__device__ __forceinline__ f32x2_v gelu2_f(f32x2_v x) {
+  const f32x2_v ax = __builtin_elementwise_abs(x);
+  f32x2_v poly, e;
+  erf_parts2(x, ax, -1.0f, poly, e);                                      // poly = -(a1 t + ... + a5 t^5)
+  const f32x2_v m = __builtin_elementwise_fma(poly, e, (f32x2_v)(1.0f));
+  return __builtin_elementwise_fma(ax * 0.5f, m, x * 0.5f);
+}
+__device__ __forceinline__ f32x2_v gelu_grad2_f(f32x2_v x) {
+  const f32x2_v ax = __builtin_elementwise_abs(x);
+  f32x2_v poly, e;
+  erf_parts2(x, ax, -0.5f, poly, e);
+  const f32x2_v hm = __builtin_elementwise_fma(poly, e, (f32x2_v)(0.5f));   // erf(|z|) / 2
+  f32x2_v her;
+  her.x = copysignf(hm.x, x.x);
+  her.y = copysignf(hm.y, x.y);
+  return __builtin_elementwise_fma(x * 0.39894228040143267794f, e, her + 0.5f);
+}
+
 // ---- dropout: counter-based keep decisions (no mask tensor; forward and backward regenerate them) ----------------
 // One 32-bit hash word serves FOUR consecutive elements: element idx keeps iff byte (idx & 3) of
 // drop_word(idx >> 2, site key) >= thr, thr = round(p*256).  The drop rate is quantised to 1/256 (p = 0.1 -> 26/256)

@@ -44,8 +44,18 @@ def main():
         ops.gemm(A, Bm, m, n, k, **kw)
         torch.cuda.synchronize()
         lib.neko_gemm_diag_trace(None)
-        t = trace.cpu().numpy().reshape(-1, 4)
-        t = t[t[:, 0] != 0].astype(np.float64) / 100.0          # us
+        raw = trace.cpu().numpy()
+        t = raw[:131072].reshape(-1, 4)
+        c = raw[131072:].reshape(-1, 4)
+        live = t[:, 0] != 0
+        c = c[live[:len(c)]].astype(np.float64)
+        t = t[live].astype(np.float64) / 100.0          # us
+        if len(c) and c[:, 0].min() > 0:
+            nkt = k // 32
+            cyc = c[:, 2] - c[:, 1]
+            us = (t[:len(c), 2] - t[:len(c), 1])
+            print(f"               s_memtime: k-loop {cyc.mean():9.0f} ticks = {cyc.mean() / nkt:7.1f} per k-tile of 32 "
+                  f"(split-K launches: per slice); ticks per us {np.median(cyc / np.maximum(us, 1e-3)):7.1f}")
         t0 = t[:, 0].min()
         pro, loop, epi = t[:, 1] - t[:, 0], t[:, 2] - t[:, 1], t[:, 3] - t[:, 2]
         print(f"{name:14s} blocks {len(t):5d}  wall {t[:, 3].max() - t0:8.1f} us | prologue {pro.mean():6.2f} (p90 {np.percentile(pro, 90):6.2f})"
