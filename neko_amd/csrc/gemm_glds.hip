@@ -22,6 +22,9 @@
 #include <type_traits>
 #include "neko_kernels.h"
 
+#ifndef NEKO_EPI_ABL
+#define NEKO_EPI_ABL 0     // epilogue ablations for tools/gemm_trace.py (wrong results): 1 no global stores, 2 GELU = identity, 3 no slab writes
+#endif
 #ifndef NEKO_GEMM_DIAG
 #define NEKO_GEMM_DIAG 0   // ablations for tools/gemm_bench.py: 1 no in-loop DMA, 4 no epilogue
 #endif
@@ -252,7 +255,9 @@ __device__ __forceinline__ void epilogue_fast(const GemmArgs& p, f32x16 (&acc)[C
   using E = FastEpi<C>;
   constexpr int TM = C::TM, TN = C::TN, SWP = E::SWP, CPR = E::CPR, RPI = E::RPI;
   float* slab = reinterpret_cast<float*>(smem + wave * E::SLAB_BYTES);
-  float* wbase = slab + 4 * (lane >> 5) * SWP + (lane & 31);             // + ((r&3) + 8(r>>2)) * SWP + 32 j
+  // accumulator layout (operands of the MFMA swapped, see the main loop): lane l holds row l&31 of the 32 x 32 block and
+  // its columns 8q + 4(l>>5) + 0..3 in acc[4q .. 4q+3] -- four consecutive columns per register quad, one ds_write_b128
+  float* wbase = slab + (lane & 31) * SWP + 4 * (lane >> 5);             // + 32 j + 8 q
   const int cchunk = lane % CPR, rsub = lane / CPR;
   const float* rbase = slab + rsub * SWP + cchunk * 4;                   // + s * RPI * SWP
   const int col = n0 + wn * E::SW + cchunk * 4;
@@ -276,7 +281,14 @@ __device__ __forceinline__ void epilogue_fast(const GemmArgs& p, f32x16 (&acc)[C
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) wbase[((r & 3) + 8 * (r >> 2)) * SWP + 32 * j] = acc[i][j][r];
+      for (int q = 0; q < 4; ++q) {
+#if NEKO_EPI_ABL == 3
+        asm volatile("" ::"v"(acc[i][j][4 * q]), "v"(acc[i][j][4 * q + 1]), "v"(acc[i][j][4 * q + 2]), "v"(acc[i][j][4 * q + 3]));
+#else
+        *reinterpret_cast<float4*>(wbase + 32 * j + 8 * q) =
+            make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+#endif
+      }
     // every global INPUT of this pass (GELU' argument, residual, accumulate target) is fetched up front: inside the step
     // loop each load would sit behind the previous step's stores (possible aliasing) and cost a full HBM round trip,
     // 32 of them per tile (the dgrad through the MLP projection spent half its time there)
@@ -302,9 +314,18 @@ __device__ __forceinline__ void epilogue_fast(const GemmArgs& p, f32x16 (&acc)[C
       if (F & F_BIAS) { v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w; }
       if (F & F_GELU) {
         const uint32_t p01 = pack_bf16x2(v[0], v[1]), p23 = pack_bf16x2(v[2], v[3]);     // bf16 pre-activation
+#if NEKO_EPI_ABL == 1
+        if (F & F_PRE) asm volatile("" ::"v"(p01), "v"(p23));
+#else
         if (F & F_PRE) *reinterpret_cast<uint2*>(ppre) = make_uint2(p01, p23);
+#endif
+#if NEKO_EPI_ABL == 2
+        const f32x2_v g01 = (f32x2_v){__uint_as_float(p01 << 16), __uint_as_float(p01 & 0xffff0000u)};
+        const f32x2_v g23 = (f32x2_v){__uint_as_float(p23 << 16), __uint_as_float(p23 & 0xffff0000u)};
+#else
         const f32x2_v g01 = gelu2_f((f32x2_v){__uint_as_float(p01 << 16), __uint_as_float(p01 & 0xffff0000u)});
         const f32x2_v g23 = gelu2_f((f32x2_v){__uint_as_float(p23 << 16), __uint_as_float(p23 & 0xffff0000u)});
+#endif
         v[0] = g01.x; v[1] = g01.y; v[2] = g23.x; v[3] = g23.y;
       }
       if (F & F_GELUBWD) {
@@ -326,7 +347,11 @@ __device__ __forceinline__ void epilogue_fast(const GemmArgs& p, f32x16 (&acc)[C
         }
         *reinterpret_cast<float4*>(pcf) = o;
       }
+#if NEKO_EPI_ABL == 1
+      if (F & F_CB) asm volatile("" ::"v"(pack_bf16x2(v[0], v[1])), "v"(pack_bf16x2(v[2], v[3])));
+#else
       if (F & F_CB) *reinterpret_cast<uint2*>(pcb) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+#endif
       // next RPI rows
       if (F & F_CF) pcf += scf;
       if (F & F_CB) pcb += scb;
@@ -436,8 +461,8 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, f32x16 (&acc)[C::TM]
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int lr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const int lc = j * 32 + (lane & 31);
+        const int lr = lane & 31;                                            // transposed accumulators, see epilogue_fast
+        const int lc = j * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         slab[lr * SW + ((((lc >> 2) ^ (lr & 15)) << 2) | (lc & 3))] = acc[i][j][r];
       }
 #pragma unroll 4
@@ -538,6 +563,12 @@ __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void gemm_glds_kernel(Gem
   }
   const int nkt = (kend - kbeg) / BK;
 
+  // The MFMAs below take (B fragment, A fragment): both fragments have the same register layout (index l&31, k =
+  // 8(l>>5)..+7), so swapping them yields each 32 x 32 block TRANSPOSED -- lane l then holds row l&31 and FOUR CONSECUTIVE
+  // columns per register quad, and the epilogue parks a quad with one ds_write_b128 where the natural layout (a column per
+  // lane, rows down the registers) took four ds_write_b32: 32 -> 8 LDS writes per 32-row pass, a third of the instructions
+  // of a plain bf16 epilogue, which is issue-bound (tools/gemm_trace.py with -DNEKO_EPI_ABL: no stores 3.2 us, no slab
+  // writes 3.5 us, everything 3.9 us per 256 x 256 tile).
   f32x16 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -556,6 +587,12 @@ __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void gemm_glds_kernel(Gem
     else stage_ks<BN, C::NW>(p.B, p.ldb, n0, p.N, k0, lb, wave, lane);
   };
 
+#ifdef NEKO_GEMM_STAGGER      // experiment: every other CU of the first round starts NEKO_GEMM_STAGGER x 10 ns late
+  if (blockIdx.x < 256 && ((blockIdx.x >> 3) & 1)) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)(NEKO_GEMM_STAGGER)) __builtin_amdgcn_s_sleep(8);
+  }
+#endif
   NEKO_TRACE(0);
   // prologue: NSTAGE-1 tiles in flight
 #pragma unroll
@@ -620,7 +657,7 @@ __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void gemm_glds_kernel(Gem
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
           const int m = (ks * TM + i) * TN + j;
           // piece pc goes after MFMA index ((pc+1)*NM)/NP - 1
           if (STAGE && pc < NP && m == ((pc + 1) * NM) / NP - 1) {
@@ -665,7 +702,7 @@ __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void gemm_glds_kernel(Gem
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
           const int m = i * TN + j;
           if (stage_now && pc < NP && m == ((pc + 1) * TM * TN) / NP - 1) {
 #if NEKO_GEMM_DIAG != 1
@@ -692,7 +729,7 @@ __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void gemm_glds_kernel(Gem
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
           const int m = i * TN + j;
 #pragma unroll
           for (int l = 0; l < NL; ++l) {

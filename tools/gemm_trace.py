@@ -21,6 +21,14 @@ SHAPES = [("lm logit16 NT", 4096, 52352, 768, False, False, "bf16"),
           ("dgrad pr NT", 32768, 3072, 768, False, False, "gelubwd,bf16"),
           ("dgrad fc NT", 32768, 768, 3072, False, False, "f32"),
           ("sq8k NT", 8192, 8192, 8192, False, False, "bf16")]
+if os.environ.get("TRACE_EPILOGUES"):      # what the forward-fc epilogue's 10 us are made of
+    SHAPES = [("fc plain", 32768, 3072, 768, False, True, "bf16"),
+              ("fc bias", 32768, 3072, 768, False, True, "bias,bf16"),
+              ("fc gelu nopre", 32768, 3072, 768, False, True, "bias,gelunopre,bf16"),
+              ("fc gelu+pre", 32768, 3072, 768, False, True, "bias,gelu,bf16"),
+              ("fc f32 out", 32768, 3072, 768, False, True, "f32"),
+              ("pr gelubwd", 32768, 3072, 768, False, False, "gelubwd,bf16"),
+              ("pr plain", 32768, 3072, 768, False, False, "bf16")]
 
 
 def main():
@@ -33,6 +41,7 @@ def main():
         kw = dict(a_kstrided=aks, b_kstrided=bks)
         if "bias" in ex: kw["bias"] = torch.randn(n, device=dev)
         if "gelu," in ex: kw["act"] = 1; kw["pre_out"] = torch.empty(m, n, dtype=BF, device=dev)
+        if "gelunopre" in ex: kw["act"] = 1
         if "gelubwd" in ex: kw["act"] = 2; kw["act_in"] = torch.randn(m, n, device=dev).to(BF)
         if "bf16" in ex: kw["out_bf16"] = torch.empty(m, n, dtype=BF, device=dev)
         else: kw["out_f32"] = torch.zeros(m, n, device=dev)
