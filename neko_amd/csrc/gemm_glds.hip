@@ -675,7 +675,10 @@ __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void gemm_glds_kernel(Gem
 #ifndef NEKO_GEMM_PIPE
 #define NEKO_GEMM_PIPE 1
 #endif
-  if constexpr (NSTAGE >= 4 && BK == 32 && (A_KC || B_KC) && NEKO_GEMM_PIPE) {
+#ifndef NEKO_GEMM_PIPE_TN
+#define NEKO_GEMM_PIPE_TN 1   // both operands k-strided too: with the fragment reads interleaved it wins there as well (wgrad -2..6 %)
+#endif
+  if constexpr (NSTAGE >= 4 && BK == 32 && (A_KC || B_KC || NEKO_GEMM_PIPE_TN) && NEKO_GEMM_PIPE) {
     // Pipelined loop (4-stage rings).  The block barrier of tile kt+1 sits in the MIDDLE of tile kt, between its two
     // k-steps, and the operands of a k-step are requested one k-step ahead:
     //     [F1 <- tile kt, k-step 1] [MFMAs k-step 0 on F0] [barrier: tile kt+1 visible, slot of tile kt-1 free]
@@ -685,7 +688,8 @@ __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void gemm_glds_kernel(Gem
     // queued.  A ring slot is refilled half a tile later than in the plain loop (2 tiles of lead instead of 3).
     // Measured against the plain loop on one box: LM-head dH -8 %, 8192^3 NT -2.6 %, forward qkv -4 %, K = 768 GELU shapes
     // +-1 %; with BOTH operands k-strided (weight gradients: two ds_read_b64_tr_b16 per fragment, twice the LDS
-    // instructions in flight) it is 4-7 % slower, so those keep the plain loop.
+    // instructions in flight) it WAS 4-7 % slower with the reads issued as a burst; with the reads interleaved (step_il below) it is 2-6 % faster
+    // there too (weight gradients, LM-head dW), so every 4-stage config now takes this loop.
     auto load_frags = [&](int kt, int ks, bf16x8_v (&a)[TM], bf16x8_v (&b)[TN]) {
       const char* la = smem + (kt % NSTAGE) * C::STAGE_BYTES;
       const char* lb = la + C::A_BYTES;
