@@ -21,7 +21,8 @@ torch.manual_seed(0)
 model = GatoPolicy(dev, bench.D, bench.L, bench.H, 0.1, resid_mid_channels=128, context_len=bench.T, text_tokenizer=bench.V_TEXT)
 model.train()
 opt = NekoAdamW(model, lr=1e-4, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.1)
-batches = [bench.make_batch(wl, 32, 1234 + 100 * i, dev) for i in range(2)]
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+batches = [bench.make_batch(wl, B, 1234 + 100 * i, dev) for i in range(2)]
 
 
 def step(i):
@@ -36,6 +37,13 @@ for i in range(3):
     step(i)
 torch.cuda.synchronize()
 N = 6
+t0 = time.perf_counter()
+for i in range(N):
+    step(i)
+t_host = time.perf_counter() - t0
+torch.cuda.synchronize()
+t_all = time.perf_counter() - t0
+print(f"[no profiler] B = {B}: host enqueue time {1e3 * t_host / N:.2f} ms/step; with final sync {1e3 * t_all / N:.2f} ms/step")
 t0 = time.perf_counter()
 pr = cProfile.Profile()
 pr.enable()
