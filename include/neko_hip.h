@@ -33,7 +33,7 @@ extern "C" {
 #define NEKO_ERR_UNSUPPORTED (-2)
 #define NEKO_ERR_LAUNCH (-3)
 
-#define NEKO_ABI_VERSION 12
+#define NEKO_ABI_VERSION 13
 
 int neko_abi_version(void);
 /* human-readable text for a return code (static storage) */
@@ -67,6 +67,18 @@ int neko_gemm_bf16(const uint16_t* A, long lda, int a_kstrided, const uint16_t* 
                    const uint16_t* act_in, long ldact, uint16_t* pre_out, long ldpre, float* Cf, long ldcf,
                    int accumulate, uint16_t* Cb, long ldcb, int splitk, int k_per_split, float* splitk_ws,
                    int drop_thr, unsigned drop_key, float drop_scale, int safe_transpose, void* stream);
+
+/* Backward of the MLP's first Linear + GELU in one launch (trajectory_gpt2.py:266,274: h = act(c_fc(x)); autograd's
+ * d_pre = (d_h . W_proj^T) * gelu'(pre) and the c_fc bias gradient sum_rows d_pre):
+ *   Cb[M,N] bf16 = (dY[M,K] . W[N,K]^T) * gelu'(act_in[M,N]);   colsum_out[N] (f32) += column sums of that product.
+ * The column sums ride in the GEMM epilogue (per 128-row band partial rows in colsum_ws, added up in band order: bit-
+ * reproducible) whenever M and N are multiples of the tile the launch picks; otherwise a stand-alone pass over the stored
+ * bf16 result computes them (the two differ by the bf16 rounding of the summands).  colsum_ws: at least
+ * neko_gemm_colsum_ws_floats(M, N) floats. */
+long neko_gemm_colsum_ws_floats(int M, int N);
+int neko_gemm_dgrad_gelu_colsum(const uint16_t* dY, long lda, const uint16_t* W, long ldb, int M, int N, int K,
+                                const uint16_t* act_in, long ldact, uint16_t* Cb, long ldcb, float* colsum_ws,
+                                float* colsum_out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * LayerNorm -- nn.LayerNorm(d, eps) ln_1 / ln_2 / ln_f (trajectory_gpt2.py:301,303,323,353,543,779).

@@ -17,6 +17,8 @@ _vp, _i, _l, _f = C.c_void_p, C.c_int, C.c_long, C.c_float
 SIGNATURES = {
     "neko_gemm_bf16": [_vp, _l, _i, _vp, _l, _i, _i, _i, _i, _f, _vp, _vp, _vp, _l, _i, _vp, _l, _vp, _l,
                        _vp, _l, _i, _vp, _l, _i, _i, _vp, _i, C.c_uint, _f, _i, _vp],
+    "neko_gemm_colsum_ws_floats": [_i, _i],
+    "neko_gemm_dgrad_gelu_colsum": [_vp, _l, _vp, _l, _i, _i, _i, _vp, _l, _vp, _l, _vp, _vp, _vp],
     "neko_dropout_f32": [_vp, _vp, _l, _i, C.c_uint, _f, _vp],
     "neko_gather_rows_bf16": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "neko_scatter_rows_f32": [_vp, _vp, _vp, _i, _i, _vp],
@@ -77,6 +79,7 @@ def load() -> C.CDLL:
         fn.argtypes = args
         fn.restype = _i
     lib.neko_attn_mask_dwords.restype = C.c_long
+    lib.neko_gemm_colsum_ws_floats.restype = C.c_long
     lib.neko_status_string.argtypes = [_i]
     lib.neko_status_string.restype = C.c_char_p
     _lib = lib

@@ -239,7 +239,7 @@ struct Cfg {
 // floats: every ds_write_b32 / ds_read_b128 address is lane base + literal offset, no swizzle arithmetic) and walks
 // the output with pointers that advance by a constant row step.
 enum : unsigned { F_BIAS = 1, F_GELU = 2, F_PRE = 4, F_GELUBWD = 8, F_DROP = 16, F_RESID = 32, F_CF = 64, F_ACCUM = 128,
-                  F_CB = 256, F_ALPHA = 512 };
+                  F_CB = 256, F_ALPHA = 512, F_COLSUM = 1024 };
 
 template <class C>
 struct FastEpi {
@@ -276,6 +276,7 @@ __device__ __forceinline__ void epilogue_fast(const GemmArgs& p, f32x16 (&acc)[C
   const long scf = (long)RPI * ldcf_out, scb = (long)RPI * p.ldcb, spre = (long)RPI * p.ldpre, sact = (long)RPI * p.ldact,
              sres = (long)RPI * p.ldr;
   const uint32_t sdrop = (uint32_t)RPI * (uint32_t)p.N;
+  float cs[4] = {0.f, 0.f, 0.f, 0.f};      // F_COLSUM: this lane's 4 columns summed over its rows of the wave's band
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -335,6 +336,7 @@ __device__ __forceinline__ void epilogue_fast(const GemmArgs& p, f32x16 (&acc)[C
         v[0] *= g01.x; v[1] *= g01.y; v[2] *= g23.x; v[3] *= g23.y;
       }
       if (F & F_DROP) drop4(v, didx, p.drop_key, p.drop_thr, p.drop_scale);
+      if (F & F_COLSUM) { cs[0] += v[0]; cs[1] += v[1]; cs[2] += v[2]; cs[3] += v[3]; }
       if (F & F_RESID) {
         const float4 q = pre_res[st];
         v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w;
@@ -361,6 +363,17 @@ __device__ __forceinline__ void epilogue_fast(const GemmArgs& p, f32x16 (&acc)[C
     // the inputs were indexed from the pass base: advance them by the whole pass (32 rows)
     if (F & F_GELUBWD) pact += (long)NST * sact;
     if (F & F_RESID) pres += (long)NST * sres;
+  }
+  if (F & F_COLSUM) {
+    // lanes that share a column chunk differ in lane / CPR: fold them in a fixed order, then one row of the band table per
+    // wave band (32*TM rows): [m0 / 32 / TM + wm][N]; neko_colsum_bands_reduce_impl adds the bands up in index order
+#pragma unroll
+    for (int o = CPR; o < 64; o <<= 1) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) cs[e] += __shfl_xor(cs[e], o, 64);
+    }
+    if (lane < CPR)
+      *reinterpret_cast<float4*>(p.colsum_ws + (long)(m0 / (32 * TM) + wm) * p.N + col) = make_float4(cs[0], cs[1], cs[2], cs[3]);
   }
 }
 
@@ -399,6 +412,7 @@ __device__ __forceinline__ bool try_epilogue_fast(const GemmArgs& p, f32x16 (&ac
   if (Cf_out) f |= F_CF | ((!to_ws && p.accumulate) ? F_ACCUM : 0);
   if (p.Cb) f |= F_CB;
   if (p.alpha != 1.0f || p.alpha_dev) f |= F_ALPHA;
+  if (p.colsum_ws) f |= F_COLSUM;           // the host only passes it on when every tile of the launch takes this path
 #define NEKO_FAST_EPI(MASK)                                                                          \
   case (MASK): epilogue_fast<C, (MASK)>(p, acc, smem, m0, n0, wm, wn, wave, lane, Cf_out, ldcf_out); \
     return true;
@@ -408,6 +422,7 @@ __device__ __forceinline__ bool try_epilogue_fast(const GemmArgs& p, f32x16 (&ac
     NEKO_FAST_EPI(F_BIAS | F_RESID | F_CF)                        // forward proj (dropout off)
     NEKO_FAST_EPI(F_BIAS | F_DROP | F_RESID | F_CF)               // forward proj (residual dropout)
     NEKO_FAST_EPI(F_GELUBWD | F_CB)                               // dgrad through the MLP projection (* GELU')
+    NEKO_FAST_EPI(F_GELUBWD | F_CB | F_COLSUM)                    // ... with the c_fc bias gradient folded in
     NEKO_FAST_EPI(F_CB)                                           // dgrad attention out, LM-head logits
     NEKO_FAST_EPI(F_CF)                                           // dgrad fc / qkv, split-K slices
     NEKO_FAST_EPI(F_CF | F_ALPHA)                                 // LM-head dH (device-side grad_output)
@@ -842,9 +857,19 @@ using C256x128 = Cfg<2, 2, 4, 2, 3>;
 using C256x256 = Cfg<2, 4, 4, 2, 4>;
 using C256x256w4 = Cfg<2, 2, 4, 4, 4>;     // 4 waves x (128 x 128), one wave per SIMD, 256 accumulator AGPRs (the vendor kernel's geometry)
 
+thread_local int t_colsum_bands = 0;
+
 template <bool A_KC, bool B_KC, class C>
-int launch_cfg(const GemmArgs& a, hipStream_t s) {
+int launch_cfg(const GemmArgs& a_in, hipStream_t s) {
+  GemmArgs a = a_in;
   const int nbm = (a.M + C::BM - 1) / C::BM, nbn = (a.N + C::BN - 1) / C::BN;
+  // column sums ride along only when EVERY tile takes the compiled fast epilogue that carries them (interior tiles of a
+  // plain GELU' dgrad); otherwise the caller runs the stand-alone column-sum kernel on the stored result
+  const bool fold = a.colsum_ws && a.M % C::BM == 0 && a.N % C::BN == 0 && a.splitk <= 1 && a.act == 2 && a.Cb && !a.Cf &&
+                    !a.bias && !a.resid && !a.drop_thr && a.alpha == 1.0f && !a.alpha_dev &&
+                    !(((a.ldcb | a.ldact) & 3) || (a.N & 3));
+  if (!fold) a.colsum_ws = nullptr;
+  t_colsum_bands = fold ? a.M / (32 * C::TM) : 0;
   dim3 grid(nbm * nbn * (a.splitk > 1 ? a.splitk : 1));
   hipLaunchKernelGGL((gemm_glds_kernel<A_KC, B_KC, C>), grid, dim3(C::NT), 0, s, a);
   NEKO_CHECK_LAUNCH();
@@ -915,8 +940,33 @@ int launch(const GemmArgs& a, hipStream_t s) {
 
 }  // namespace
 
+int neko_gemm_glds_colsum_bands() { const int b = t_colsum_bands; t_colsum_bands = 0; return b; }   // read-and-clear
+
+// out[N] += sum over the bands of ws[bands][N], bands added in index order (bit-reproducible): 64 columns per block,
+// 4 interleaved band groups per column summed sequentially, the 4 partials combined in a fixed order through LDS
+namespace {
+__global__ __launch_bounds__(256) void colsum_bands_reduce_kernel(const float* __restrict__ ws, int bands, int N,
+                                                                   float* __restrict__ out) {
+  __shared__ float part[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+  float acc = 0.f;
+  if (c < N)
+    for (int b = g; b < bands; b += 4) acc += ws[(long)b * N + c];
+  part[g][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (g == 0 && c < N) out[c] += (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+}  // namespace
+int neko_colsum_bands_reduce_impl(const float* ws, int bands, int N, float* out, hipStream_t s) {
+  if (bands <= 0 || N <= 0) return NEKO_OK;
+  hipLaunchKernelGGL(colsum_bands_reduce_kernel, dim3((N + 63) / 64), dim3(256), 0, s, ws, bands, N, out);
+  NEKO_CHECK_LAUNCH();
+  return NEKO_OK;
+}
+
 // returns 1 if the fast path does not apply (caller falls back), otherwise a neko status code
 int neko_gemm_glds_try(const GemmArgs& a, int a_kstrided, int b_kstrided, hipStream_t s) {
+  t_colsum_bands = 0;
   if (a.K % 64) return 1;
   if (a.splitk > 1 && (a.k_per_split % 64)) return 1;
   // 16-B aligned operands / outputs (all neko_amd buffers are; guards foreign callers)

@@ -28,6 +28,22 @@ int neko_gemm_bf16(const uint16_t* A, long lda, int a_kstrided, const uint16_t* 
   return neko_gemm_bf16_full(a, a_kstrided, b_kstrided, safe_transpose, S(stream));
 }
 
+long neko_gemm_colsum_ws_floats(int M, int N) { return (long)((M + 63) / 64) * (long)N; }
+int neko_gemm_dgrad_gelu_colsum(const uint16_t* dY, long lda, const uint16_t* W, long ldb, int M, int N, int K,
+                                const uint16_t* act_in, long ldact, uint16_t* Cb, long ldcb, float* colsum_ws,
+                                float* colsum_out, void* stream) {
+  if (!Cb || !act_in || !colsum_out) return NEKO_ERR_ARG;
+  GemmArgs a{dY, W, lda, ldb, M, N, K, 1.0f, nullptr, nullptr, nullptr, 0, act_in, ldact, nullptr, 0, 2,
+             nullptr, 0, 0, Cb, ldcb, 1, 0, nullptr, 0, 0u, 1.0f};
+  a.colsum_ws = colsum_ws;
+  (void)neko_gemm_glds_colsum_bands();
+  const int rc = neko_gemm_bf16_full(a, 0, 0, 0, S(stream));
+  if (rc != NEKO_OK || M <= 0 || N <= 0 || K <= 0) return rc;
+  const int bands = neko_gemm_glds_colsum_bands();
+  if (bands > 0) return neko_colsum_bands_reduce_impl(colsum_ws, bands, N, colsum_out, S(stream));
+  return neko_colsum_bf16_impl(Cb, ldcb, M, N, colsum_out, 1, S(stream));
+}
+
 int neko_layernorm_fwd(const float* x, const float* gamma, const float* beta, uint16_t* y16, float* y32, float* mean,
                        float* rstd, int M, int d, float eps, void* stream) {
   return neko_layernorm_fwd_impl(x, gamma, beta, y16, y32, mean, rstd, M, d, eps, S(stream));

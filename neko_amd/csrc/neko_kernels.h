@@ -28,6 +28,8 @@ struct GemmArgs {
   int drop_thr;           // residual dropout on (acc*alpha + bias [act]) before the residual add: 0 = off, else round(p*256)
   unsigned drop_key;      // site key (element index = row*N + col)
   float drop_scale;       // 256/(256-thr)
+  float* colsum_ws;       // optional: per-(32*TM)-row-band column sums of the result (before bf16 rounding), f32 [bands, N];
+                          // written only when the launch can fold them (gemm_glds.hip), see neko_gemm_glds_colsum_bands()
 };
 
 int neko_gemm_bf16_impl(GemmArgs a, int a_kstrided, int b_kstrided, int safe_transpose, hipStream_t s);
@@ -36,6 +38,9 @@ int neko_gather_rows_bf16_impl(const bf16_t* src, const int* idx, bf16_t* dst, i
 int neko_scatter_rows_f32_impl(const float* src, const int* idx, float* dst, int n, int d, hipStream_t s);
 int neko_splitk_reduce_impl(const float* ws, int S, int M, int N, float* C, long ldc, int accumulate, hipStream_t s);
 int neko_gemm_glds_try(const GemmArgs& a, int a_kstrided, int b_kstrided, hipStream_t s);   // 1 = not applicable
+// bands of colsum_ws the last neko_gemm_glds_try() of this thread filled (0: the column sums were not folded into it)
+int neko_gemm_glds_colsum_bands();
+int neko_colsum_bands_reduce_impl(const float* ws, int bands, int N, float* out, hipStream_t s);   // out[N] += sum over bands, fixed order
 int neko_layernorm_fwd_impl(const float* x, const float* gamma, const float* beta, bf16_t* y16, float* y32,
                             float* mean, float* rstd, int M, int d, float eps, hipStream_t s);
 int neko_layernorm_bwd_blocks_impl(int M);

@@ -315,8 +315,8 @@ def stack_backward(P: StackParams, ctx: StackCtx, dhf: torch.Tensor,
         # ---- MLP: x2 = x1 + gelu(a2 Wfc + bfc) Wpr + bpr ------------------------------------------
         d_pre = torch.empty(M, 4 * d, dtype=BF16, device=dev)
         d_gate = None
-        if c.gate is None:
-            ops.gemm(g16, lp.w_pr, M, 4 * d, d, ldb=d, act=2, act_in=c.pre, out_bf16=d_pre)   # dgrad * gelu'
+        if c.gate is None:    # dgrad * gelu', the c_fc bias gradient (column sums of d_pre) folded into its epilogue
+            ops.gemm_dgrad_gelu_colsum(g16, lp.w_pr, M, 4 * d, d, c.pre, d_pre, lp.g_b_fc, ldb=d)
         else:                                                                                 # GEGLU: h = gelu(pre) * gate
             ops.gemm(g16, lp.w_pr, M, 4 * d, d, ldb=d, out_bf16=d_pre)                        # d_h
             d_pre, d_gate = ops.geglu_bwd(d_pre, c.pre, c.gate)
@@ -331,8 +331,9 @@ def stack_backward(P: StackParams, ctx: StackCtx, dhf: torch.Tensor,
             ops.gemm(d_gate, lp.w_gate, M, d, 4 * d, b_kstrided=True, ldb=d, out_f32=d_a2, accumulate=True)
             SideStream.fork(lambda c=c, lp=lp, d_gate=d_gate: (_wgrad(d_gate, c.a2, 4 * d, d, M, lp.g_w_gate),
                                                               ops.colsum_bf16(d_gate, M, 4 * d, lp.g_b_gate)), d_gate)
-        SideStream.fork(lambda c=c, lp=lp, d_pre=d_pre: (_wgrad(c.a2, d_pre, d, 4 * d, M, lp.g_w_fc),
-                                                        ops.colsum_bf16(d_pre, M, 4 * d, lp.g_b_fc)), d_pre)
+        SideStream.fork(lambda c=c, lp=lp, d_pre=d_pre, geglu=d_gate is not None: (
+            _wgrad(c.a2, d_pre, d, 4 * d, M, lp.g_w_fc),
+            ops.colsum_bf16(d_pre, M, 4 * d, lp.g_b_fc) if geglu else None), d_pre)
         g1 = torch.empty(M, d, dtype=F32, device=dev)
         g1_16 = torch.empty(M, d, dtype=BF16, device=dev)
         ops.layernorm_bwd(d_a2, c.x1, lp.ln2_w, c.mean2, c.rstd2, lp.g_ln2_w, lp.g_ln2_b, g_in=g, dx=g1, dx16=g1_16,

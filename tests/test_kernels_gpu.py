@@ -161,6 +161,42 @@ def test_gemm_epilogues(ops):
     close(dW, X.t() @ dYk, 1e-4, 2e-2, "split-K wgrad")
 
 
+@pytest.mark.parametrize("M,N,K", [(1024, 3072, 768), (8192, 768, 192), (300, 256, 192), (512, 3072 + 8, 64)])
+def test_gemm_dgrad_gelu_colsum(ops, M, N, K):
+    """d_pre = (dY @ W^T) * gelu'(pre) with the bias gradient sum_rows d_pre from the same launch
+    (neko_gemm_dgrad_gelu_colsum; trajectory_gpt2.py:266,274 backward): full tiles fold the column sums into the epilogue
+    (first two shapes), ragged M / N take the stand-alone pass over the stored result (last two); `+=` semantics and
+    run-to-run bit-identity either way."""
+    g = torch.Generator().manual_seed(M + N)
+    dY, W = rb(torch.randn(M, K, generator=g)), rb(torch.randn(N, K, generator=g) * 0.1)
+    pre = rb(torch.randn(M, N, generator=g) * 1.5)
+    x = pre
+    gprime = 0.5 * (1 + torch.erf(x / math.sqrt(2))) + x * torch.exp(-0.5 * x * x) / math.sqrt(2 * math.pi)
+    ref = (dY @ W.t()) * gprime
+    base = torch.randn(N, generator=g)
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    cs = base.clone().to(DEV)
+    ops.gemm_dgrad_gelu_colsum(bf(dY), bf(W), M, N, K, bf(pre), out, cs)
+    close(out, ref, 2 ** -8, 2e-3, "d_pre")
+    want = base + ref.sum(0)
+    err = float((cs.cpu() - want).norm() / want.norm())
+    assert err < 2e-3, err
+    worst = float((cs.cpu() - want).abs().max() / ref.abs().sum(0).max())
+    assert worst < 2e-3, worst
+    out2 = torch.empty_like(out)
+    cs2 = base.clone().to(DEV)
+    ops.gemm_dgrad_gelu_colsum(bf(dY), bf(W), M, N, K, bf(pre), out2, cs2)
+    assert torch.equal(out, out2)
+    if M % 256 == 0 and N % 256 == 0:        # folded: band partials added in a fixed order
+        assert torch.equal(cs, cs2)
+    else:                                    # stand-alone column-sum pass: fp32 atomics across row blocks
+        assert float((cs - cs2).abs().max()) <= 1e-4 * float(cs.abs().max())
+    # the plain launch stores the same d_pre
+    out3 = torch.empty_like(out)
+    ops.gemm(bf(dY), bf(W), M, N, K, act=2, act_in=bf(pre), out_bf16=out3)
+    assert torch.equal(out, out3)
+
+
 # ----------------------------------------------------------------------------------------------------
 # LayerNorm
 # ----------------------------------------------------------------------------------------------------
