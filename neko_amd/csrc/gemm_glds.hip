@@ -602,12 +602,6 @@ __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void gemm_glds_kernel(Gem
     else stage_ks<BN, C::NW>(p.B, p.ldb, n0, p.N, k0, lb, wave, lane);
   };
 
-#ifdef NEKO_GEMM_STAGGER      // experiment: every other CU of the first round starts NEKO_GEMM_STAGGER x 10 ns late
-  if (blockIdx.x < 256 && ((blockIdx.x >> 3) & 1)) {
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)(NEKO_GEMM_STAGGER)) __builtin_amdgcn_s_sleep(8);
-  }
-#endif
   NEKO_TRACE(0);
   // prologue: NSTAGE-1 tiles in flight
 #pragma unroll
