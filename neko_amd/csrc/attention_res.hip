@@ -23,6 +23,18 @@ namespace {
 constexpr float MASK_VAL = -10000.0f;
 constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
 __device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }
+// Two fp32 values per issue slot (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32, neko_common.h f32x2_v): these kernels are bound
+// by the VALU issue rate, and everything around the exponential that is plain arithmetic on an accumulator pair packs.
+// bit `bit` of w sign-extended to a dword (all ones / zero) in ONE instruction; written as asm because the compiler turns
+// `x & sbfe(w, bit, 1)` into v_and + v_cmp + v_cndmask
+template <typename T = void>
+__device__ __forceinline__ uint32_t keep_bits(uint32_t w, int bit) {
+  uint32_t r;
+  asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(r) : "v"(w), "n"(bit));
+  return r;
+}
+__device__ __forceinline__ f32x2_v pk2(float a, float b) { return (f32x2_v){a, b}; }
+__device__ __forceinline__ f32x2_v exp2_fast2(f32x2_v x) { return (f32x2_v){__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)}; }
 
 // image: [rows][32 bf16], 64-byte rows; 16-byte piece p of row r is stored at piece p ^ ((r>>2)&3)
 __device__ __forceinline__ int img_off(int row, int piece) { return row * 64 + ((piece ^ ((row >> 2) & 3)) << 4); }
@@ -275,10 +287,11 @@ __global__ __launch_bounds__(1024) void attn_fwd_res_kernel(const bf16_t* __rest
       if (!renorm) {
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
-          pr[r] = exp2_fast(fmaf(st[r], sc, -m_run));
-          pr[r + 1] = exp2_fast(fmaf(st[r + 1], sc, -m_run));
-          ps0 += pr[r];
-          ps1 += pr[r + 1];
+          const f32x2_v pv = exp2_fast2(__builtin_elementwise_fma(pk2(st[r], st[r + 1]), (f32x2_v)(sc), (f32x2_v)(-m_run)));
+          pr[r] = pv.x;
+          pr[r + 1] = pv.y;
+          ps0 += pv.x;
+          ps1 += pv.y;
         }
         renorm = __builtin_amdgcn_ballot_w64(!((ps0 + ps1) < 256.0f)) != 0;
       }
@@ -297,10 +310,11 @@ __global__ __launch_bounds__(1024) void attn_fwd_res_kernel(const bf16_t* __rest
         ps1 = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
-          pr[r] = exp2_fast(fmaf(st[r], sc, -m_run));
-          pr[r + 1] = exp2_fast(fmaf(st[r + 1], sc, -m_run));
-          ps0 += pr[r];
-          ps1 += pr[r + 1];
+          const f32x2_v pv = exp2_fast2(__builtin_elementwise_fma(pk2(st[r], st[r + 1]), (f32x2_v)(sc), (f32x2_v)(-m_run)));
+          pr[r] = pv.x;
+          pr[r + 1] = pv.y;
+          ps0 += pv.x;
+          ps1 += pv.y;
         }
       }
 #pragma unroll
@@ -453,12 +467,17 @@ __global__ __launch_bounds__(768) void attn_dq_res_kernel(const bf16_t* __restri
         for (int j = 0; j < 4; ++j) {
           const uint32_t w = (DROP && !MASK) ? drop_word(g0 + 2 * j, drop_key) : 0u;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
+          for (int e = 0; e < 4; e += 2) {
             const int r = 4 * j + e;
-            const float pv = exp2_fast(fmaf(st[r], scale2, nlse));
-            float dpe = dpt[r];
-            if (DROP) dpe = MASK ? keep_lanes(dpe, mcur[r]) : (drop_byte_keep(w, e, drop_thr) ? dpe : 0.f);
-            st[r] = pv * (dpe - my_D);
+            const f32x2_v pv = exp2_fast2(__builtin_elementwise_fma(pk2(st[r], st[r + 1]), (f32x2_v)(scale2), (f32x2_v)(nlse)));
+            float dp0 = dpt[r], dp1 = dpt[r + 1];
+            if (DROP) {
+              dp0 = MASK ? keep_lanes(dp0, mcur[r]) : (drop_byte_keep(w, e, drop_thr) ? dp0 : 0.f);
+              dp1 = MASK ? keep_lanes(dp1, mcur[r + 1]) : (drop_byte_keep(w, e + 1, drop_thr) ? dp1 : 0.f);
+            }
+            const f32x2_v ds = pv * (pk2(dp0, dp1) - (f32x2_v)(my_D));
+            st[r] = ds.x;
+            st[r + 1] = ds.y;
           }
         }
       } else {
@@ -537,7 +556,7 @@ __global__ __launch_bounds__(768) void attn_dkv_res_kernel(const bf16_t* __restr
   const bf16_t* obase = outp + (long)b * T * d + h * 32;
 
   stage_pair(qbase, ld, dobase, (long)d, imgQ, imgdO, T, Tp, tid, nthr);
-  for (int i = tid; i < Tp; i += nthr) ldsLse[i] = (i < T) ? lse_b[i] * LOG2E : 0.f;
+  for (int i = tid; i < Tp; i += nthr) ldsLse[i] = (i < T) ? -lse_b[i] * LOG2E : 0.f;      // NEGATED: the exponent is fma(s, scale, -lse)
   // D[q] = sum_hd dO.O / s for every query of the head (the streaming kernels take it from a separate pass): four
   // consecutive lanes hold the four 16-byte pieces of a row
   {
@@ -625,24 +644,32 @@ __global__ __launch_bounds__(768) void attn_dkv_res_kernel(const bf16_t* __restr
       const bool interior = (qb > kbw) && (q0 + 31 < T) && keys_plain;
       if (interior) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int c = (r & 3) + 8 * (r >> 2);
-          const float lse_q = lq[c], d_q = dq_[c];
-          const float pv = exp2_fast(fmaf(st[r], scale2, -lse_q));
-          float pd = pv, dpe = dpt[r];
+        for (int r = 0; r < 16; r += 2) {
+          const int c = (r & 3) + 8 * (r >> 2);          // r even: c + 1 is the column of r + 1
+          const f32x2_v nlse_q = pk2(lq[c], lq[c + 1]), d_q = pk2(dq_[c], dq_[c + 1]);
+          const f32x2_v pv = exp2_fast2(__builtin_elementwise_fma(pk2(st[r], st[r + 1]), (f32x2_v)(scale2), nlse_q));
+          f32x2_v ds;
           if (DROP) {
+            // dS = P o (M o dP - D) = (M o P) o dP - P o D: ONE masked quantity (the dropped P that dV needs anyway)
+            // instead of two, and the rest is a packed multiply and a packed fma
+            f32x2_v pd;
             if (MASK) {
-              const uint32_t km = (uint32_t)__builtin_amdgcn_sbfe((int)wsh, c, 1);      // all ones where kept
-              pd = __uint_as_float(__float_as_uint(pv) & km);
-              dpe = __uint_as_float(__float_as_uint(dpe) & km);
+              pd.x = __uint_as_float(__float_as_uint(pv.x) & keep_bits(wsh, c));      // all ones where kept
+              pd.y = __uint_as_float(__float_as_uint(pv.y) & keep_bits(wsh, c + 1));
             } else {
-              const bool keep = __builtin_amdgcn_ubfe(quad_bcast(mine[r >> 2], r & 3), ksh, 8) >= drop_thr;
-              pd = keep ? pv : 0.f;
-              dpe = keep ? dpe : 0.f;
+              pd.x = __builtin_amdgcn_ubfe(quad_bcast(mine[r >> 2], r & 3), ksh, 8) >= drop_thr ? pv.x : 0.f;
+              pd.y = __builtin_amdgcn_ubfe(quad_bcast(mine[r >> 2], (r + 1) & 3), ksh, 8) >= drop_thr ? pv.y : 0.f;
             }
+            ds = __builtin_elementwise_fma(pd, pk2(dpt[r], dpt[r + 1]), -(pv * d_q));
+            st[r] = pd.x;
+            st[r + 1] = pd.y;
+          } else {
+            ds = pv * (pk2(dpt[r], dpt[r + 1]) - d_q);
+            st[r] = pv.x;
+            st[r + 1] = pv.y;
           }
-          st[r] = pd;
-          dpt[r] = pv * (dpe - d_q);
+          dpt[r] = ds.x;
+          dpt[r + 1] = ds.y;
         }
       } else {
         const int lim_causal = q0 + 4 * (lane >> 5) - key;    // key <= query  <=>  -c(r) <= lim_causal
@@ -652,8 +679,8 @@ __global__ __launch_bounds__(768) void attn_dkv_res_kernel(const bf16_t* __restr
           const int c = (r & 3) + 8 * (r >> 2);
           const bool causal_ok = (-c) <= lim_causal;
           const float sv = (causal_ok ? st[r] * scale2 : MASK_VAL * LOG2E) + my_kb;
-          const float lse_q = lq[c], d_q = dq_[c];      // unconditional: a load inside ?: compiles to a branch
-          const float pv = exp2_fast((c <= lim_len && kvalid) ? sv - lse_q : -INFINITY);        // select: 2^-inf = 0
+          const float nlse_q = lq[c], d_q = dq_[c];     // unconditional: a load inside ?: compiles to a branch
+          const float pv = exp2_fast((c <= lim_len && kvalid) ? sv + nlse_q : -INFINITY);       // select: 2^-inf = 0
           float pd = pv, dpe = dpt[r];
           if (DROP) {
             if (MASK) {
