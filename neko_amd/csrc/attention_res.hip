@@ -22,6 +22,10 @@ namespace {
 
 constexpr float MASK_VAL = -10000.0f;
 constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+#ifndef NEKO_ATTN_ABL
+#define NEKO_ATTN_ABL 0      // dK/dV ablations for tools/attn_bench.py (wrong results): 1 no elementwise math in interior
+#endif                       // sub-tiles, 2 operand fragments of one fixed query block (the LDS reads leave the loop)
+#define NEKO_ATTN_Q0(q0) ((NEKO_ATTN_ABL & 2) ? 0 : (q0))
 __device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }
 // Two fp32 values per issue slot (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32, neko_common.h f32x2_v): these kernels are bound
 // by the VALU issue rate, and everything around the exponential that is plain arithmetic on an accumulator pair packs.
@@ -165,11 +169,14 @@ __device__ __forceinline__ float dot8_bf16(const uint4& a, const uint4& b) {
 // stage two [T][32] bf16 matrices (row strides lda / ldb elements) into swizzled images, rows >= T zero
 __device__ __forceinline__ void stage_pair(const bf16_t* __restrict__ a, long lda, const bf16_t* __restrict__ b, long ldb,
                                            char* imgA, char* imgB, int T, int Tp, int tid, int nthr) {
+  // every load of a round is in flight before the first LDS store waits for one: a round is one HBM round trip, and with
+  // one workgroup per CU nothing overlaps it -- 6 pieces per thread make T = 1024 a single round at 768 threads
   const int total = Tp * 4;
-  for (int c0 = 0; c0 < total; c0 += nthr * 4) {
-    uint4 ra[4], rb[4];
+  constexpr int NB = 6;
+  for (int c0 = 0; c0 < total; c0 += nthr * NB) {
+    uint4 ra[NB], rb[NB];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NB; ++i) {
       const int c = c0 + i * nthr + tid, row = c >> 2, p = c & 3;
       ra[i] = make_uint4(0, 0, 0, 0);
       rb[i] = make_uint4(0, 0, 0, 0);
@@ -179,7 +186,7 @@ __device__ __forceinline__ void stage_pair(const bf16_t* __restrict__ a, long ld
       }
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NB; ++i) {
       const int c = c0 + i * nthr + tid, row = c >> 2, p = c & 3;
       if (c < total) {
         *reinterpret_cast<uint4*>(imgA + img_off(row, p)) = ra[i];
@@ -190,13 +197,20 @@ __device__ __forceinline__ void stage_pair(const bf16_t* __restrict__ a, long ld
 }
 // bit j: 32-position block j holds a position with a non-zero key bias (a padded key == a masked query row)
 __device__ __forceinline__ uint32_t pad_mask_of(const float* __restrict__ kb, int T, int nblk, int lane) {
+  // nblk <= 32 here (T <= 1024): the 16 loads are issued together -- as a loop of load / ballot / load they were 16
+  // dependent memory round trips at the head of every workgroup, with nothing else resident on the CU to hide them
+  float v[16];
+#pragma unroll
+  for (int jj = 0; jj < 16; ++jj) {
+    const int i = jj * 64 + lane;
+    v[jj] = (2 * jj < nblk && i < T) ? kb[i] : 0.f;
+  }
   uint32_t m = 0;
-  for (int j = 0; j < nblk; j += 2) {
-    const int i = j * 32 + lane;
-    const float v = (i < T) ? kb[i] : 0.f;
-    const unsigned long long bal = __builtin_amdgcn_ballot_w64(v != 0.f);
-    if ((uint32_t)bal) m |= 1u << j;
-    if ((uint32_t)(bal >> 32)) m |= 2u << j;
+#pragma unroll
+  for (int jj = 0; jj < 16; ++jj) {
+    const unsigned long long bal = __builtin_amdgcn_ballot_w64(v[jj] != 0.f);
+    if ((uint32_t)bal) m |= 1u << (2 * jj);
+    if ((uint32_t)(bal >> 32)) m |= 2u << (2 * jj);
   }
   return m;
 }
@@ -229,9 +243,9 @@ __global__ __launch_bounds__(1024) void attn_fwd_res_kernel(const bf16_t* __rest
 
   stage_pair(qbase + d, ld, qbase + 2 * d, ld, imgK, imgV, T, Tp, tid, nthr);
   for (int i = tid; i < Tp; i += nthr) ldsKb[i] = (i < T) ? kb[i] * LOG2E : 0.f;
-  const uint32_t padmask = pad_mask_of(kb, T, nblk, lane);
   const int kb_first = kstart ? (kstart[b] >> 5) : 0;
   __syncthreads();
+  const uint32_t padmask = pad_mask_of(ldsKb, Tp, nblk, lane);     // from the LDS copy (zero beyond T): no second trip to memory
 
   const float scale2 = scale * LOG2E;
 #pragma unroll 1
@@ -399,9 +413,9 @@ __global__ __launch_bounds__(768) void attn_dq_res_kernel(const bf16_t* __restri
 
   stage_pair(qbase + d, ld, qbase + 2 * d, ld, imgK, imgV, T, Tp, tid, nthr);
   for (int i = tid; i < Tp; i += nthr) ldsKb[i] = (i < T) ? kb[i] * LOG2E : 0.f;
-  const uint32_t padmask = pad_mask_of(kb, T, nblk, lane);
   const int kb_first = kstart ? (kstart[b] >> 5) : 0;
   __syncthreads();
+  const uint32_t padmask = pad_mask_of(ldsKb, Tp, nblk, lane);     // from the LDS copy (zero beyond T): no second trip to memory
 
   const float scale2 = scale * LOG2E;
 #pragma unroll 1
@@ -561,15 +575,27 @@ __global__ __launch_bounds__(768) void attn_dkv_res_kernel(const bf16_t* __restr
   // consecutive lanes hold the four 16-byte pieces of a row
   {
     const float inv_s = DROP ? 1.0f / drop_scale : 1.0f;
-    for (int c0 = 0; c0 < Tp * 4; c0 += nthr) {          // nthr is a multiple of 64: the quad stays together
-      const int c = c0 + tid, row = c >> 2, pc = c & 3;
-      float part = 0.f;
-      if (c < Tp * 4 && row < T)
-        part = dot8_bf16(*reinterpret_cast<const uint4*>(dobase + (long)row * d + pc * 8),
-                         *reinterpret_cast<const uint4*>(obase + (long)row * d + pc * 8));
-      part += __shfl_xor(part, 1, 64);
-      part += __shfl_xor(part, 2, 64);
-      if (c < Tp * 4 && pc == 0) ldsD[row] = part * inv_s;
+    constexpr int NB = 6;                                 // loads of a batch in flight together (see stage_pair)
+    for (int c0 = 0; c0 < Tp * 4; c0 += nthr * NB) {      // nthr is a multiple of 64: the quad stays together
+      uint4 da[NB], oa[NB];
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int c = c0 + i * nthr + tid, row = c >> 2, pc = c & 3;
+        da[i] = make_uint4(0, 0, 0, 0);
+        oa[i] = make_uint4(0, 0, 0, 0);
+        if (c < Tp * 4 && row < T) {
+          da[i] = *reinterpret_cast<const uint4*>(dobase + (long)row * d + pc * 8);
+          oa[i] = *reinterpret_cast<const uint4*>(obase + (long)row * d + pc * 8);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int c = c0 + i * nthr + tid, row = c >> 2, pc = c & 3;
+        float part = dot8_bf16(da[i], oa[i]);
+        part += __shfl_xor(part, 1, 64);
+        part += __shfl_xor(part, 2, 64);
+        if (c < Tp * 4 && pc == 0) ldsD[row] = part * inv_s;
+      }
     }
   }
   const uint32_t padmask = pad_mask_of(kb, T, nblk, lane);   // bit j: query block j holds a masked (padded) row
@@ -626,8 +652,8 @@ __global__ __launch_bounds__(768) void attn_dkv_res_kernel(const bf16_t* __restr
       for (int r = 0; r < 16; ++r) { st[r] = 0.f; dpt[r] = 0.f; }
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(imgQ, q0, ks, lane), kf[ks], st, 0, 0, 0);
-        dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(imgdO, q0, ks, lane), vf[ks], dpt, 0, 0, 0);
+        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(imgQ, NEKO_ATTN_Q0(q0), ks, lane), kf[ks], st, 0, 0, 0);
+        dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(imgdO, NEKO_ATTN_Q0(q0), ks, lane), vf[ks], dpt, 0, 0, 0);
       }
       // dropout words: rows of this sub-tile are registers, the 4 lanes of a quad own the 4 keys of one group -> lane
       // (key & 3) = i hashes rows 4j + i and the quad shares the 16 words by DPP
@@ -642,7 +668,9 @@ __global__ __launch_bounds__(768) void attn_dkv_res_kernel(const bf16_t* __restr
       const float* dq_ = ldsD + q0 + 4 * (lane >> 5);
       // wave-uniform fast path: every query of the block sees every key of this wave, no key is padded or invalid
       const bool interior = (qb > kbw) && (q0 + 31 < T) && keys_plain;
-      if (interior) {
+      if (interior && (NEKO_ATTN_ABL & 1)) {
+        // ablation: no elementwise work at all
+      } else if (interior) {
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
           const int c = (r & 3) + 8 * (r >> 2);          // r even: c + 1 is the column of r + 1
@@ -699,8 +727,8 @@ __global__ __launch_bounds__(768) void attn_dkv_res_kernel(const bf16_t* __restr
       }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
-        dv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(imgdO, q0, s2, lane), frag_from_acc(st, s2), dv, 0, 0, 0);
-        dk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(imgQ, q0, s2, lane), frag_from_acc(dpt, s2), dk, 0, 0, 0);
+        dv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(imgdO, NEKO_ATTN_Q0(q0), s2, lane), frag_from_acc(st, s2), dv, 0, 0, 0);
+        dk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(imgQ, NEKO_ATTN_Q0(q0), s2, lane), frag_from_acc(dpt, s2), dk, 0, 0, 0);
       }
       qb = qb_next;
     }
