@@ -22,9 +22,24 @@ namespace {
 
 constexpr float MASK_VAL = -10000.0f;
 constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+#ifdef NEKO_ATTN_TRACE
+// phase trace of the dK/dV kernel (diagnostic builds, tools/attn_trace.py): per workgroup and wave 4 x 8 bytes =
+// s_memrealtime (100 MHz) at kernel entry, behind the staging barrier, after the wave's last work item; sub-tiles done
+__device__ unsigned long long* g_neko_attn_trace = nullptr;
+extern "C" int neko_attn_diag_trace(void* buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_neko_attn_trace), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
+}
+#define NEKO_ATRACE(slot, val)                                                                                     \
+  do {                                                                                                              \
+    if (g_neko_attn_trace && (threadIdx.x & 63) == 0 && blockIdx.x < 4096)                                          \
+      g_neko_attn_trace[((long)blockIdx.x * 16 + (threadIdx.x >> 6)) * 4 + (slot)] = (val);                         \
+  } while (0)
+#else
+#define NEKO_ATRACE(slot, val) do { } while (0)
+#endif
 #ifndef NEKO_ATTN_ABL
 #define NEKO_ATTN_ABL 0      // dK/dV ablations for tools/attn_bench.py (wrong results): 1 no elementwise math in interior
-#endif                       // sub-tiles, 2 operand fragments of one fixed query block (the LDS reads leave the loop)
+#endif                       // sub-tiles, 2 operand fragments of one fixed query block (the LDS reads leave the loop), 4 no mask loads
 #define NEKO_ATTN_Q0(q0) ((NEKO_ATTN_ABL & 2) ? 0 : (q0))
 __device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }
 // Two fp32 values per issue slot (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32, neko_common.h f32x2_v): these kernels are bound
@@ -195,16 +210,14 @@ __device__ __forceinline__ void stage_pair(const bf16_t* __restrict__ a, long ld
     }
   }
 }
-// bit j: 32-position block j holds a position with a non-zero key bias (a padded key == a masked query row)
-__device__ __forceinline__ uint32_t pad_mask_of(const float* __restrict__ kb, int T, int nblk, int lane) {
-  // nblk <= 32 here (T <= 1024): the 16 loads are issued together -- as a loop of load / ballot / load they were 16
-  // dependent memory round trips at the head of every workgroup, with nothing else resident on the CU to hide them
-  float v[16];
+// the two halves of pad_mask_of below: the loads (issued with the rest of a prologue's loads) and the wave ballots
+__device__ __forceinline__ void pad_mask_load(const float* __restrict__ kb, int T, int nblk, int lane, float (&v)[16]) {
 #pragma unroll
-  for (int jj = 0; jj < 16; ++jj) {
-    const int i = jj * 64 + lane;
-    v[jj] = (2 * jj < nblk && i < T) ? kb[i] : 0.f;
-  }
+  for (int jj = 0; jj < 16; ++jj) v[jj] = kb[min(jj * 64 + lane, T - 1)];        // clamped, unconditional: no branch, no wait
+#pragma unroll
+  for (int jj = 0; jj < 16; ++jj) v[jj] = (2 * jj < nblk && jj * 64 + lane < T) ? v[jj] : 0.f;
+}
+__device__ __forceinline__ uint32_t pad_mask_ballot(const float (&v)[16]) {
   uint32_t m = 0;
 #pragma unroll
   for (int jj = 0; jj < 16; ++jj) {
@@ -213,6 +226,14 @@ __device__ __forceinline__ uint32_t pad_mask_of(const float* __restrict__ kb, in
     if ((uint32_t)(bal >> 32)) m |= 2u << (2 * jj);
   }
   return m;
+}
+// bit j: 32-position block j holds a position with a non-zero key bias (a padded key == a masked query row)
+__device__ __forceinline__ uint32_t pad_mask_of(const float* __restrict__ kb, int T, int nblk, int lane) {
+  // nblk <= 32 here (T <= 1024): the 16 loads are issued together -- as a loop of load / ballot / load they were 16
+  // dependent memory round trips at the head of every workgroup, with nothing else resident on the CU to hide them
+  float v[16];
+  pad_mask_load(kb, T, nblk, lane, v);
+  return pad_mask_ballot(v);
 }
 
 // =====================================================================================================
@@ -391,9 +412,9 @@ template <bool DROP, bool MASK>
 __global__ __launch_bounds__(768) void attn_dq_res_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                            const float* __restrict__ kbias, const int* __restrict__ kstart,
                                                            const float* __restrict__ lse, const bf16_t* __restrict__ outp,
-                                                           bf16_t* __restrict__ dqkv, int B, int T, int H, float scale,
-                                                           uint32_t drop_thr, uint32_t drop_key, float drop_scale,
-                                                           const uint32_t* __restrict__ dmask) {
+                                                           float* __restrict__ Dout, bf16_t* __restrict__ dqkv, int B, int T,
+                                                           int H, float scale, uint32_t drop_thr, uint32_t drop_key,
+                                                           float drop_scale, const uint32_t* __restrict__ dmask) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if (DROP) drop_key += neko_drop_salt();
   const int Tp = (T + 31) & ~31, nblk = Tp >> 5;
@@ -435,6 +456,7 @@ __global__ __launch_bounds__(768) void attn_dq_res_kernel(const bf16_t* __restri
                  dot8_bf16(__builtin_bit_cast(uint4, dof[1]), __builtin_bit_cast(uint4, of[1]));
     my_D += __shfl_xor(my_D, 32, 64);
     if (DROP) my_D *= 1.0f / drop_scale;
+    if (qvalid && lane < 32) Dout[((long)b * H + h) * T + q] = my_D;      // the dK/dV kernel (launched after this one) stages it
     // a masked query row whose dO is exactly zero (the training case: no loss reaches a padded position) has dP = D = 0,
     // hence dS = 0 for every key: the keys beyond the diagonal are then needed by no row of the block
     const bool live_masked = __builtin_amdgcn_ballot_w64(qvalid && ldsKb[q] != 0.f && (frag_nonzero(dof[0]) || frag_nonzero(dof[1]))) != 0;
@@ -544,11 +566,12 @@ __global__ __launch_bounds__(768) void attn_dq_res_kernel(const bf16_t* __restri
 template <bool DROP, bool MASK>
 __global__ __launch_bounds__(768) void attn_dkv_res_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                             const float* __restrict__ kbias, const float* __restrict__ lse,
-                                                            const bf16_t* __restrict__ outp, bf16_t* __restrict__ dqkv, int B,
+                                                            const float* __restrict__ Din, bf16_t* __restrict__ dqkv, int B,
                                                             int T, int H, float scale, uint32_t drop_thr,
                                                             uint32_t drop_key, float drop_scale,
                                                             const uint32_t* __restrict__ dmask) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  NEKO_ATRACE(0, __builtin_amdgcn_s_memrealtime());
   if (DROP) drop_key += neko_drop_salt();
   const int Tp = (T + 31) & ~31, nblk = Tp >> 5;
   char* imgQ = smem;
@@ -556,7 +579,6 @@ __global__ __launch_bounds__(768) void attn_dkv_res_kernel(const bf16_t* __restr
   float* ldsLse = reinterpret_cast<float*>(smem + Tp * 128);
   float* ldsD = ldsLse + Tp;
   int* queue = reinterpret_cast<int*>(ldsD + Tp);
-
   const int tid = threadIdx.x, lane = tid & 63, nthr = blockDim.x;
   if (tid == 0) *queue = 0;
   const int hb = pair_remap(blockIdx.x, B * H);
@@ -567,38 +589,60 @@ __global__ __launch_bounds__(768) void attn_dkv_res_kernel(const bf16_t* __restr
   const bf16_t* dobase = dout + (long)b * T * d + h * 32;
   const float* kb = kbias + (long)b * T;
   const float* lse_b = lse + ((long)b * H + h) * T;
-  const bf16_t* obase = outp + (long)b * T * d + h * 32;
+  const float* D_b = Din + ((long)b * H + h) * T;
 
-  stage_pair(qbase, ld, dobase, (long)d, imgQ, imgdO, T, Tp, tid, nthr);
-  for (int i = tid; i < Tp; i += nthr) ldsLse[i] = (i < T) ? -lse_b[i] * LOG2E : 0.f;      // NEGATED: the exponent is fma(s, scale, -lse)
-  // D[q] = sum_hd dO.O / s for every query of the head (the streaming kernels take it from a separate pass): four
-  // consecutive lanes hold the four 16-byte pieces of a row
+  // Staging: Q and dO images, -lse and D[q] = sum_hd dO.O / s (written by the dQ kernel, which runs first and needs the sum
+  // for its own rows anyway: a third of this prologue's bytes were the O rows read only to form it).  EVERY global load
+  // of the prologue -- two 16-byte pieces per (row, piece) slot, lse, D and the key-bias words behind the padding mask --
+  // is issued before the first one is waited for.  The workgroup is alone on its CU and all 256 CUs stage at the same
+  // time: tools/attn_trace.py measured 16 us from kernel entry to the staging barrier (3 TB/s of 64-byte row pieces).
+  float padv[16];
+  pad_mask_load(kb, T, nblk, lane, padv);
   {
-    const float inv_s = DROP ? 1.0f / drop_scale : 1.0f;
-    constexpr int NB = 6;                                 // loads of a batch in flight together (see stage_pair)
-    for (int c0 = 0; c0 < Tp * 4; c0 += nthr * NB) {      // nthr is a multiple of 64: the quad stays together
-      uint4 da[NB], oa[NB];
+    constexpr int NB = 6;                                  // 6 * nthr slots >= 4 * Tp pieces: one round
+    const int total = Tp * 4;
+    for (int c0 = 0; c0 < total; c0 += nthr * NB) {
+      uint4 rq[NB], rdo[NB];
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
         const int c = c0 + i * nthr + tid, row = c >> 2, pc = c & 3;
-        da[i] = make_uint4(0, 0, 0, 0);
-        oa[i] = make_uint4(0, 0, 0, 0);
-        if (c < Tp * 4 && row < T) {
-          da[i] = *reinterpret_cast<const uint4*>(dobase + (long)row * d + pc * 8);
-          oa[i] = *reinterpret_cast<const uint4*>(obase + (long)row * d + pc * 8);
+        rq[i] = make_uint4(0, 0, 0, 0);
+        rdo[i] = make_uint4(0, 0, 0, 0);
+        if (c < total && row < T) {
+          rq[i] = *reinterpret_cast<const uint4*>(qbase + (long)row * ld + pc * 8);
+          rdo[i] = *reinterpret_cast<const uint4*>(dobase + (long)row * d + pc * 8);
+        }
+      }
+      float lv[2] = {0.f, 0.f}, dvv[2] = {0.f, 0.f};
+      if (c0 == 0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int r = i * nthr + tid;
+          if (r < T) { lv[i] = lse_b[r]; dvv[i] = D_b[r]; }
         }
       }
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
         const int c = c0 + i * nthr + tid, row = c >> 2, pc = c & 3;
-        float part = dot8_bf16(da[i], oa[i]);
-        part += __shfl_xor(part, 1, 64);
-        part += __shfl_xor(part, 2, 64);
-        if (c < Tp * 4 && pc == 0) ldsD[row] = part * inv_s;
+        if (c < total) {
+          *reinterpret_cast<uint4*>(imgQ + img_off(row, pc)) = rq[i];
+          *reinterpret_cast<uint4*>(imgdO + img_off(row, pc)) = rdo[i];
+        }
+      }
+      if (c0 == 0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int r = i * nthr + tid;
+          if (r < Tp) { ldsLse[r] = -lv[i] * LOG2E; ldsD[r] = dvv[i]; }      // -lse: the exponent is fma(s, scale, -lse)
+        }
       }
     }
+    for (int r = 2 * nthr + tid; r < Tp; r += nthr) {      // (Tp > 2 * nthr only)
+      ldsLse[r] = (r < T) ? -lse_b[r] * LOG2E : 0.f;
+      ldsD[r] = (r < T) ? D_b[r] : 0.f;
+    }
   }
-  const uint32_t padmask = pad_mask_of(kb, T, nblk, lane);   // bit j: query block j holds a masked (padded) row
+  const uint32_t padmask = pad_mask_ballot(padv);            // bit j: query block j holds a masked (padded) row
   __syncthreads();
   // bit j of qactive: query block j holds a masked row whose dO is not exactly zero.  Only such rows reach keys beyond
   // their diagonal (dO == 0 gives dP = D = 0, so P^T.dO and dS vanish): in training no loss reaches a padded position
@@ -614,6 +658,8 @@ __global__ __launch_bounds__(768) void attn_dkv_res_kernel(const bf16_t* __restr
 
   const float scale2 = scale * LOG2E;
   const uint32_t T4 = (uint32_t)((T + 3) >> 2);
+  NEKO_ATRACE(1, __builtin_amdgcn_s_memrealtime());
+  unsigned long long ntiles_traced = 0;
 #pragma unroll 1
   for (int kbw = next_item(queue, lane); kbw < nblk; kbw = next_item(queue, lane)) {   // early key blocks are seen by
     const int kw0 = kbw * 32;                                                          // the most queries: heaviest first
@@ -638,15 +684,16 @@ __global__ __launch_bounds__(768) void attn_dkv_res_kernel(const bf16_t* __restr
       while (nq < kbw && !((qactive >> nq) & 1)) ++nq;
       return nq;
     };
+    // keep words of the forward pass for this lane's key: mask[(head, query block, this key block)][mask_slot_of_key], one
+    // dword (32 query bits) per visited block, requested one block ahead.  Measured and not kept (tools/attn_trace.py:
+    // 1.14 us per sub-tile without dropout, 1.58 us with, 1.39 us with the loads ablated): two blocks of lead through two
+    // alternating registers, the same through a per-wave LDS-DMA ring (global_load_lds_dword + counted vmcnt), and a
+    // key-block-major mask layout that makes this kernel's walk sequential -- 1.58 / 1.63 / 1.74 us: it is not latency.
     const uint32_t* mcol = (DROP && MASK) ? dmask + ((long)hb * nblk * nblk + kbw) * 32 + mask_slot_of_key(lane & 31) : nullptr;
-    int qb = next_qb(0);
-    uint32_t wnext = (DROP && MASK && qb < nblk) ? mcol[(long)qb * nblk * 32] : 0u;
-#pragma unroll 1
-    while (qb < nblk) {
+    auto mask_word = [&](int q) { return (DROP && MASK && !(NEKO_ATTN_ABL & 4)) ? mcol[(long)min(q, nblk - 1) * nblk * 32] : 0xFFFFFFFFu; };
+    auto sub_tile = [&](const int qb, const uint32_t wraw) {
       const int q0 = qb * 32;
-      const int qb_next = next_qb(qb + 1);
-      const uint32_t wsh = wnext >> (4 * (lane >> 5));          // bit c(r): keep(query q0 + c(r) + 4 (lane / 32), this key)
-      if (DROP && MASK) wnext = mcol[(long)min(qb_next, nblk - 1) * nblk * 32];
+      const uint32_t wsh = wraw >> (4 * (lane >> 5));           // bit c(r): keep(query q0 + c(r) + 4 (lane / 32), this key)
       f32x16 st, dpt;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { st[r] = 0.f; dpt[r] = 0.f; }
@@ -730,6 +777,18 @@ __global__ __launch_bounds__(768) void attn_dkv_res_kernel(const bf16_t* __restr
         dv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(imgdO, NEKO_ATTN_Q0(q0), s2, lane), frag_from_acc(st, s2), dv, 0, 0, 0);
         dk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(imgQ, NEKO_ATTN_Q0(q0), s2, lane), frag_from_acc(dpt, s2), dk, 0, 0, 0);
       }
+#ifdef NEKO_ATTN_TRACE
+      ++ntiles_traced;
+#endif
+    };
+    int qb = next_qb(0);
+    uint32_t wnext = mask_word(qb);
+#pragma unroll 1
+    while (qb < nblk) {
+      const int qb_next = next_qb(qb + 1);
+      const uint32_t w = wnext;
+      wnext = mask_word(qb_next);
+      sub_tile(qb, w);
       qb = qb_next;
     }
 
@@ -750,6 +809,8 @@ __global__ __launch_bounds__(768) void attn_dkv_res_kernel(const bf16_t* __restr
       }
     }
   }
+  NEKO_ATRACE(2, __builtin_amdgcn_s_memrealtime());
+  NEKO_ATRACE(3, ntiles_traced);
 }
 
 template <typename K>
@@ -792,11 +853,12 @@ int neko_attn_fwd_res_impl(const bf16_t* qkv, const float* kbias, const int* kst
   return NEKO_OK;
 }
 
-// D = sum dO.O is formed inside both kernels (the D / qflags workspace of the streaming path is not touched).
+// D = sum dO.O / s is formed by the dQ kernel for its rows and left in the D workspace for the dK/dV kernel (qflags untouched).
 // dmask: the keep masks the forward call of the same (qkv, drop_key) wrote, or null (the kernels re-hash the decisions).
 int neko_attn_bwd_res_impl(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const float* kbias, const int* kstart,
-                           const float* lse, bf16_t* dqkv, int B, int T, int H, int drop_thr, unsigned drop_key,
+                           const float* lse, float* D, bf16_t* dqkv, int B, int T, int H, int drop_thr, unsigned drop_key,
                            float drop_scale, const uint32_t* dmask, hipStream_t s) {
+  if (!D) return NEKO_ERR_ARG;          // f32 [B*H*T]: the dQ kernel leaves sum_hd dO.O / s there for the dK/dV kernel
   const int Tp = (T + 31) & ~31, nblk = Tp / 32, nw = min(12, (nblk + 1) / 2);
   const size_t lds_q = (size_t)Tp * 128 + (size_t)Tp * 4 + 16, lds_kv = (size_t)Tp * 128 + (size_t)Tp * 8 + 16;
   const float scale = 1.0f / sqrtf(32.0f);
@@ -806,11 +868,11 @@ int neko_attn_bwd_res_impl(const bf16_t* qkv, const bf16_t* out, const bf16_t* d
   if (once != NEKO_OK) return once;
 #define NEKO_BWD_RES(DROPV, MASKV, THR, MP)                                                                                       \
   do {                                                                                                                            \
-    hipLaunchKernelGGL((attn_dkv_res_kernel<DROPV, MASKV>), dim3(B * H), dim3(64 * nw), lds_kv, s, qkv, dout, kbias, lse, out,  \
-                       dqkv, B, T, H, scale, (uint32_t)(THR), drop_key, drop_scale, MP);                                         \
-    NEKO_CHECK_LAUNCH();                                                                                                          \
     hipLaunchKernelGGL((attn_dq_res_kernel<DROPV, MASKV>), dim3(B * H), dim3(64 * nw), lds_q, s, qkv, dout, kbias, kstart, lse,  \
-                       out, dqkv, B, T, H, scale, (uint32_t)(THR), drop_key, drop_scale, MP);                                    \
+                       out, D, dqkv, B, T, H, scale, (uint32_t)(THR), drop_key, drop_scale, MP);                                 \
+    NEKO_CHECK_LAUNCH();                                                                                                          \
+    hipLaunchKernelGGL((attn_dkv_res_kernel<DROPV, MASKV>), dim3(B * H), dim3(64 * nw), lds_kv, s, qkv, dout, kbias, lse, D,    \
+                       dqkv, B, T, H, scale, (uint32_t)(THR), drop_key, drop_scale, MP);                                         \
   } while (0)
   if (drop_thr && dmask) NEKO_BWD_RES(true, true, drop_thr, dmask);
   else if (drop_thr) NEKO_BWD_RES(true, false, drop_thr, nullptr);
