@@ -37,6 +37,9 @@ extern "C" int neko_attn_diag_trace(void* buf) {
 #else
 #define NEKO_ATRACE(slot, val) do { } while (0)
 #endif
+#ifndef NEKO_DKV_WAVES
+#define NEKO_DKV_WAVES 12    // waves per dK/dV workgroup; 16 (4 per SIMD, 128 VGPRs: 60 spilled) measured 347 -> 401 us for the backward
+#endif
 #ifndef NEKO_ATTN_ABL
 #define NEKO_ATTN_ABL 0      // dK/dV ablations for tools/attn_bench.py (wrong results): 1 no elementwise math in interior
 #endif                       // sub-tiles, 2 operand fragments of one fixed query block (the LDS reads leave the loop), 4 no mask loads
@@ -566,7 +569,7 @@ __global__ __launch_bounds__(768) void attn_dq_res_kernel(const bf16_t* __restri
 // backward dK/dV: lanes own keys; images Q and dO, per-query lse and D in LDS
 // =====================================================================================================
 template <bool DROP, bool MASK>
-__global__ __launch_bounds__(768) void attn_dkv_res_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+__global__ __launch_bounds__(NEKO_DKV_WAVES * 64) void attn_dkv_res_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                             const float* __restrict__ kbias, const float* __restrict__ lse,
                                                             const float* __restrict__ Din, bf16_t* __restrict__ dqkv, int B,
                                                             int T, int H, float scale, uint32_t drop_thr,
@@ -861,7 +864,7 @@ int neko_attn_bwd_res_impl(const bf16_t* qkv, const bf16_t* out, const bf16_t* d
                            const float* lse, float* D, bf16_t* dqkv, int B, int T, int H, int drop_thr, unsigned drop_key,
                            float drop_scale, const uint32_t* dmask, hipStream_t s) {
   if (!D) return NEKO_ERR_ARG;          // f32 [B*H*T]: the dQ kernel leaves sum_hd dO.O / s there for the dK/dV kernel
-  const int Tp = (T + 31) & ~31, nblk = Tp / 32, nw = min(12, (nblk + 1) / 2);
+  const int Tp = (T + 31) & ~31, nblk = Tp / 32, nw = min(12, (nblk + 1) / 2), nw_kv = min(NEKO_DKV_WAVES, (nblk + 1) / 2);
   const size_t lds_q = (size_t)Tp * 128 + (size_t)Tp * 4 + 16, lds_kv = (size_t)Tp * 128 + (size_t)Tp * 8 + 16;
   const float scale = 1.0f / sqrtf(32.0f);
   static const int once = allow_lds(attn_dq_res_kernel<true, true>, 160 * 1024) | allow_lds(attn_dq_res_kernel<true, false>, 160 * 1024) |
@@ -873,7 +876,7 @@ int neko_attn_bwd_res_impl(const bf16_t* qkv, const bf16_t* out, const bf16_t* d
     hipLaunchKernelGGL((attn_dq_res_kernel<DROPV, MASKV>), dim3(B * H), dim3(64 * nw), lds_q, s, qkv, dout, kbias, kstart, lse,  \
                        out, D, dqkv, B, T, H, scale, (uint32_t)(THR), drop_key, drop_scale, MP);                                 \
     NEKO_CHECK_LAUNCH();                                                                                                          \
-    hipLaunchKernelGGL((attn_dkv_res_kernel<DROPV, MASKV>), dim3(B * H), dim3(64 * nw), lds_kv, s, qkv, dout, kbias, lse, D,    \
+    hipLaunchKernelGGL((attn_dkv_res_kernel<DROPV, MASKV>), dim3(B * H), dim3(64 * nw_kv), lds_kv, s, qkv, dout, kbias, lse, D, \
                        dqkv, B, T, H, scale, (uint32_t)(THR), drop_key, drop_scale, MP);                                         \
   } while (0)
   if (drop_thr && dmask) NEKO_BWD_RES(true, true, drop_thr, dmask);
