@@ -125,6 +125,20 @@ __device__ __forceinline__ f32x2_v gelu_grad2_f(f32x2_v x) {
   return __builtin_elementwise_fma(x * 0.39894228040143267794f, e, her + 0.5f);
 }
 
+// gelu(x) and gelu'(x) of a pair from one evaluation of the series (the patch kernels' backward needs both)
+__device__ __forceinline__ void gelu_and_grad2_f(f32x2_v x, f32x2_v& g, f32x2_v& gp) {
+  const f32x2_v ax = __builtin_elementwise_abs(x);
+  f32x2_v poly, e;
+  erf_parts2(x, ax, -0.5f, poly, e);
+  const f32x2_v hm = __builtin_elementwise_fma(poly, e, (f32x2_v)(0.5f));   // erf(|z|) / 2
+  f32x2_v her;
+  her.x = copysignf(hm.x, x.x);
+  her.y = copysignf(hm.y, x.y);
+  const f32x2_v cdf = her + 0.5f;
+  g = x * cdf;
+  gp = __builtin_elementwise_fma(x * 0.39894228040143267794f, e, cdf);
+}
+
 // ---- dropout: counter-based keep decisions (no mask tensor; forward and backward regenerate them) ----------------
 // One 32-bit hash word serves FOUR consecutive elements: element idx keeps iff byte (idx & 3) of
 // drop_word(idx >> 2, site key) >= thr, thr = round(p*256).  The drop rate is quantised to 1/256 (p = 0.1 -> 26/256)

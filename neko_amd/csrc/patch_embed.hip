@@ -237,9 +237,12 @@ __global__ __launch_bounds__(256, 2) void resblock_fwd_kernel(const void* __rest
         for (int pt = 0; pt < 2; ++pt) {
           float v[8];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            v[j] = gelu_f(fmaf(acc[t][pt][8 * sidx + j], gwv[j], gbv[j]));
-            if (j == 3) __builtin_amdgcn_sched_barrier(0);     // 4 GELUs in flight at a time (register pressure)
+          for (int j = 0; j < 8; j += 2) {                     // pairs on the packed fp32 pipe (neko_common.h gelu2_f)
+            const f32x2_v g2 = gelu2_f(__builtin_elementwise_fma((f32x2_v){acc[t][pt][8 * sidx + j], acc[t][pt][8 * sidx + j + 1]},
+                                                                 (f32x2_v){gwv[j], gwv[j + 1]}, (f32x2_v){gbv[j], gbv[j + 1]}));
+            v[j] = g2.x;
+            v[j + 1] = g2.y;
+            if (j == 2) __builtin_amdgcn_sched_barrier(0);     // 4 GELUs in flight at a time (register pressure)
           }
           zacc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, pack8_bf16(v), zacc[pt], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
@@ -498,19 +501,22 @@ __global__ __launch_bounds__(256, 2) void resblock_bwd_kernel(const float* __res
       for (int pt = 0; pt < 2; ++pt) {
         float tv[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
+        for (int r = 0; r < 16; r += 2) {                     // channel pairs (c, c + 1) on the packed fp32 pipe
           const int c = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
-          const float xh = acc[pt][r];
-          const float u = fmaf(xh, s.gw[c], s.gb[c]);
-          float er, e;
-          erf_exp_parts(u, er, e);
-          const float cdf = 0.5f * (1.0f + er);
-          tv[r] = u * cdf;                                                       // h2
-          const float du = dacc[pt][r] * fmaf(u * 0.39894228040143267794f, e, cdf);
-          dacc[pt][r] = du;                                                      // d(GN out)
-          sums[r] += du;                       // kind 0: sum du      -> dbeta
-          sums[16 + r] = fmaf(du, xh, sums[16 + r]);       // kind 1: sum du*xhat -> dgamma
-          if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);     // 4 GELUs in flight at a time (register pressure)
+          const f32x2_v xh = {acc[pt][r], acc[pt][r + 1]};
+          const f32x2_v u = __builtin_elementwise_fma(xh, (f32x2_v){s.gw[c], s.gw[c + 1]}, (f32x2_v){s.gb[c], s.gb[c + 1]});
+          f32x2_v h2, gp;
+          gelu_and_grad2_f(u, h2, gp);
+          tv[r] = h2.x;                                                          // h2
+          tv[r + 1] = h2.y;
+          const f32x2_v du = (f32x2_v){dacc[pt][r], dacc[pt][r + 1]} * gp;
+          dacc[pt][r] = du.x;                                                    // d(GN out)
+          dacc[pt][r + 1] = du.y;
+          sums[r] += du.x;                     // kind 0: sum du      -> dbeta
+          sums[r + 1] += du.y;
+          sums[16 + r] = fmaf(du.x, xh.x, sums[16 + r]);   // kind 1: sum du*xhat -> dgamma
+          sums[16 + r + 1] = fmaf(du.y, xh.y, sums[16 + r + 1]);
+          if ((r & 3) == 2) __builtin_amdgcn_sched_barrier(0);     // 4 GELUs in flight at a time (register pressure)
         }
         const int pix = 64 * wave + 32 * pt + l32;
 #pragma unroll
