@@ -7,6 +7,7 @@
 //   W k-contiguous [N][ldw] (the LM-head table): one wave per output column block of rows, 16-B loads along K,
 //       wave reduction.
 #include "neko_kernels.h"
+#include <type_traits>
 
 namespace {
 
@@ -95,28 +96,51 @@ __global__ __launch_bounds__(GV_NT) void gemv_kc_kernel(GemvArgs p) {
   __syncthreads();
   constexpr int COLS_PER_WAVE = 8;
   const int nb = (blockIdx.x * 4 + wave) * COLS_PER_WAVE;
-  for (int j = 0; j < COLS_PER_WAVE; ++j) {
-    const int n = nb + j;
-    if (n >= p.N) break;                                     // wave-uniform
-    const bf16_t* wr = p.W + (long)n * p.ldw;
-    float acc[M];
+  // The weight rows of a batch of columns are requested with unconditional (clamped) loads before the first one is used:
+  // as `for column: for k-chunk: load, use` every 16-byte load was a dependent HBM round trip of its own (8 columns x
+  // 2..6 chunks per wave) in a kernel that is nothing but a weight stream.  K <= 1024 (d = 768 / 1024: qkv, projections,
+  // LM head): all 8 columns x 2 chunks at once; longer rows (the MLP projection): 2 columns x 6 chunks.
+  auto columns = [&](auto cb_tag, auto nkc_tag, int j0) {
+    constexpr int CB = decltype(cb_tag)::value, NKC = decltype(nkc_tag)::value;
+    uint4 w[CB][NKC];
 #pragma unroll
-    for (int m = 0; m < M; ++m) acc[m] = 0.f;
-    for (int k = lane * 8; k < p.K; k += 64 * 8) {
-      const uint4 w = *reinterpret_cast<const uint4*>(wr + k);
-      const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+    for (int j = 0; j < CB; ++j) {
+      const bf16_t* wr = p.W + (long)min(nb + j0 + j, p.N - 1) * p.ldw;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float lo = __uint_as_float(ww[e] << 16), hi = __uint_as_float(ww[e] & 0xffff0000u);
+      for (int c = 0; c < NKC; ++c) w[j][c] = *reinterpret_cast<const uint4*>(wr + min(lane * 8 + c * 512, p.K - 8));
+    }
 #pragma unroll
-        for (int m = 0; m < M; ++m) acc[m] = fmaf(xs[m][k + 2 * e + 1], hi, fmaf(xs[m][k + 2 * e], lo, acc[m]));
+    for (int j = 0; j < CB; ++j) {
+      const int n = nb + j0 + j;
+      if (n >= p.N) break;                                   // wave-uniform
+      float acc[M];
+#pragma unroll
+      for (int m = 0; m < M; ++m) acc[m] = 0.f;
+#pragma unroll
+      for (int c = 0; c < NKC; ++c) {
+        const int k = lane * 8 + c * 512;
+        if (k < p.K) {
+          const uint32_t ww[4] = {w[j][c].x, w[j][c].y, w[j][c].z, w[j][c].w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float lo = __uint_as_float(ww[e] << 16), hi = __uint_as_float(ww[e] & 0xffff0000u);
+#pragma unroll
+            for (int m = 0; m < M; ++m) acc[m] = fmaf(xs[m][k + 2 * e + 1], hi, fmaf(xs[m][k + 2 * e], lo, acc[m]));
+          }
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        const float v = wave_sum(acc[m]);
+        if (lane == 0 && m < p.M) gv_store(p, m, n, v);
       }
     }
-#pragma unroll
-    for (int m = 0; m < M; ++m) {
-      const float v = wave_sum(acc[m]);
-      if (lane == 0 && m < p.M) gv_store(p, m, n, v);
-    }
+  };
+  if (p.K <= 1024) {
+    columns(std::integral_constant<int, 8>{}, std::integral_constant<int, 2>{}, 0);
+  } else {
+    static_assert(GV_MAXK <= 6 * 512, "k-chunks per row");
+    for (int j0 = 0; j0 < COLS_PER_WAVE; j0 += 2) columns(std::integral_constant<int, 2>{}, std::integral_constant<int, 6>{}, j0);
   }
 }
 
