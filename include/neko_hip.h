@@ -33,7 +33,7 @@ extern "C" {
 #define NEKO_ERR_UNSUPPORTED (-2)
 #define NEKO_ERR_LAUNCH (-3)
 
-#define NEKO_ABI_VERSION 13
+#define NEKO_ABI_VERSION 14
 
 int neko_abi_version(void);
 /* human-readable text for a return code (static storage) */
@@ -52,6 +52,9 @@ const char* neko_status_string(int code);
  *   b_kstrided = 0: B[n*ldb + k]        1: B[k*ldb + n]   (Conv1D weight (in,out))
  *   act = 0 none | 1 GELU (pre-activation rounded to bf16 first; optionally stored to pre_out)
  *         | 2 multiply by GELU'(act_in[m,n])  (dgrad through the MLP activation)
+ *         | 3 GELU as 1, but pre_out (required) receives GELU'(pre-activation) as bf16: the factor the backward needs,
+ *             from the same evaluation of the erf series (ABI v14)
+ *         | 4 multiply by act_in[m,n] itself (the factor stored by act = 3)
  *   outputs: Cf (f32) and/or Cb (bf16); accumulate != 0: Cf += result.
  *   splitk > 1: K is cut in `splitk` slices of k_per_split (multiple of 64).  With splitk_ws (f32
  *   [splitk*M*N], N % 4 == 0) the slices are written to the workspace and summed in a fixed order into Cf
@@ -77,8 +80,10 @@ int neko_gemm_bf16(const uint16_t* A, long lda, int a_kstrided, const uint16_t* 
  * neko_gemm_colsum_ws_floats(M, N) floats. */
 long neko_gemm_colsum_ws_floats(int M, int N);
 int neko_gemm_dgrad_gelu_colsum(const uint16_t* dY, long lda, const uint16_t* W, long ldb, int M, int N, int K,
-                                const uint16_t* act_in, long ldact, uint16_t* Cb, long ldcb, float* colsum_ws,
-                                float* colsum_out, void* stream);
+                                const uint16_t* act_in, long ldact, int act_in_is_factor, uint16_t* Cb, long ldcb,
+                                float* colsum_ws, float* colsum_out, void* stream);
+/* act_in_is_factor (ABI v14): 0 = act_in holds the pre-activation (epilogue act 2), 1 = act_in holds gelu'(pre) as the
+ * forward with act = 3 stored it (epilogue act 4: one multiply per element, no erf evaluation in the backward). */
 
 /* ---------------------------------------------------------------------------------------------
  * LayerNorm -- nn.LayerNorm(d, eps) ln_1 / ln_2 / ln_f (trajectory_gpt2.py:301,303,323,353,543,779).

@@ -18,7 +18,7 @@ SIGNATURES = {
     "neko_gemm_bf16": [_vp, _l, _i, _vp, _l, _i, _i, _i, _i, _f, _vp, _vp, _vp, _l, _i, _vp, _l, _vp, _l,
                        _vp, _l, _i, _vp, _l, _i, _i, _vp, _i, C.c_uint, _f, _i, _vp],
     "neko_gemm_colsum_ws_floats": [_i, _i],
-    "neko_gemm_dgrad_gelu_colsum": [_vp, _l, _vp, _l, _i, _i, _i, _vp, _l, _vp, _l, _vp, _vp, _vp],
+    "neko_gemm_dgrad_gelu_colsum": [_vp, _l, _vp, _l, _i, _i, _i, _vp, _l, _i, _vp, _l, _vp, _vp, _vp],
     "neko_dropout_f32": [_vp, _vp, _l, _i, C.c_uint, _f, _vp],
     "neko_gather_rows_bf16": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "neko_scatter_rows_f32": [_vp, _vp, _vp, _i, _i, _vp],

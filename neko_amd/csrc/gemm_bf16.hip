@@ -218,8 +218,14 @@ __global__ __launch_bounds__(NT) void gemm_bf16_kernel(GemmArgs p) {
           const bf16_t pb = f32_to_bf16(v);
           if (p.pre_out) p.pre_out[(long)row * p.ldpre + col] = pb;
           v = gelu_f(bf16_to_f32(pb));
+        } else if (p.act == 3) {
+          const float x = bf16_to_f32(f32_to_bf16(v));
+          p.pre_out[(long)row * p.ldpre + col] = f32_to_bf16(gelu_grad_f(x));
+          v = gelu_f(x);
         } else if (p.act == 2) {
           v *= gelu_grad_f(bf16_to_f32(p.act_in[(long)row * p.ldact + col]));
+        } else if (p.act == 4) {
+          v *= bf16_to_f32(p.act_in[(long)row * p.ldact + col]);
         }
         if (p.drop_thr) v = drop_keep((uint32_t)row * (uint32_t)p.N + (uint32_t)col, p.drop_key, p.drop_thr) ? v * p.drop_scale : 0.f;
         if (p.resid && lead) v += p.resid[(long)row * p.ldr + col];
@@ -255,8 +261,9 @@ int neko_gemm_bf16_impl(GemmArgs a, int a_kstrided, int b_kstrided, int safe_tra
   if (!b_kstrided && (a.K & 7)) return NEKO_ERR_ARG;
   if (a_kstrided && (a.M & 7)) return NEKO_ERR_ARG;
   if (b_kstrided && (a.N & 7)) return NEKO_ERR_ARG;
-  if (a.act == 2 && !a.act_in) return NEKO_ERR_ARG;
-  if (a.act < 0 || a.act > 2) return NEKO_ERR_ARG;
+  if ((a.act == 2 || a.act == 4) && !a.act_in) return NEKO_ERR_ARG;
+  if (a.act == 3 && !a.pre_out) return NEKO_ERR_ARG;
+  if (a.act < 0 || a.act > 4) return NEKO_ERR_ARG;
   if (a.splitk > 1) {
     if (!a.Cf || a.Cb || a.act != 0) return NEKO_ERR_ARG;  // atomics need a linear f32 epilogue
     if (a.k_per_split <= 0 || (a.k_per_split % BK)) return NEKO_ERR_ARG;

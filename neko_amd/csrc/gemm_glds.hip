@@ -239,7 +239,9 @@ struct Cfg {
 // floats: every ds_write_b32 / ds_read_b128 address is lane base + literal offset, no swizzle arithmetic) and walks
 // the output with pointers that advance by a constant row step.
 enum : unsigned { F_BIAS = 1, F_GELU = 2, F_PRE = 4, F_GELUBWD = 8, F_DROP = 16, F_RESID = 32, F_CF = 64, F_ACCUM = 128,
-                  F_CB = 256, F_ALPHA = 512, F_COLSUM = 1024 };
+                  F_CB = 256, F_ALPHA = 512, F_COLSUM = 1024,
+                  F_GP = 2048,        // with F_GELU | F_PRE: the pre_out store holds gelu'(pre) instead of pre (act = 3)
+                  F_MULACT = 4096 };  // with F_GELUBWD: act_in already IS the factor (act = 4), no gelu' evaluation
 
 template <class C>
 struct FastEpi {
@@ -315,24 +317,40 @@ __device__ __forceinline__ void epilogue_fast(const GemmArgs& p, f32x16 (&acc)[C
       if (F & F_BIAS) { v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w; }
       if (F & F_GELU) {
         const uint32_t p01 = pack_bf16x2(v[0], v[1]), p23 = pack_bf16x2(v[2], v[3]);     // bf16 pre-activation
+        const f32x2_v x01 = (f32x2_v){__uint_as_float(p01 << 16), __uint_as_float(p01 & 0xffff0000u)};
+        const f32x2_v x23 = (f32x2_v){__uint_as_float(p23 << 16), __uint_as_float(p23 & 0xffff0000u)};
+        if (F & F_GP) {
+          // act = 3: one evaluation of the erf series yields gelu(pre) AND gelu'(pre); the second output is gelu' (bf16), so
+          // the backward's epilogue is a plain multiply by the stored factor instead of a second erf evaluation per element
+          f32x2_v g01, g23, d01, d23;
+          gelu_and_grad2_f(x01, g01, d01);
+          gelu_and_grad2_f(x23, g23, d23);
 #if NEKO_EPI_ABL == 1
-        if (F & F_PRE) asm volatile("" ::"v"(p01), "v"(p23));
+          asm volatile("" ::"v"(d01), "v"(d23));
 #else
-        if (F & F_PRE) *reinterpret_cast<uint2*>(ppre) = make_uint2(p01, p23);
+          *reinterpret_cast<uint2*>(ppre) = make_uint2(pack_bf16x2(d01.x, d01.y), pack_bf16x2(d23.x, d23.y));
+#endif
+          v[0] = g01.x; v[1] = g01.y; v[2] = g23.x; v[3] = g23.y;
+        } else {
+#if NEKO_EPI_ABL == 1
+          if (F & F_PRE) asm volatile("" ::"v"(p01), "v"(p23));
+#else
+          if (F & F_PRE) *reinterpret_cast<uint2*>(ppre) = make_uint2(p01, p23);
 #endif
 #if NEKO_EPI_ABL == 2
-        const f32x2_v g01 = (f32x2_v){__uint_as_float(p01 << 16), __uint_as_float(p01 & 0xffff0000u)};
-        const f32x2_v g23 = (f32x2_v){__uint_as_float(p23 << 16), __uint_as_float(p23 & 0xffff0000u)};
+          const f32x2_v g01 = x01, g23 = x23;
 #else
-        const f32x2_v g01 = gelu2_f((f32x2_v){__uint_as_float(p01 << 16), __uint_as_float(p01 & 0xffff0000u)});
-        const f32x2_v g23 = gelu2_f((f32x2_v){__uint_as_float(p23 << 16), __uint_as_float(p23 & 0xffff0000u)});
+          const f32x2_v g01 = gelu2_f(x01), g23 = gelu2_f(x23);
 #endif
-        v[0] = g01.x; v[1] = g01.y; v[2] = g23.x; v[3] = g23.y;
+          v[0] = g01.x; v[1] = g01.y; v[2] = g23.x; v[3] = g23.y;
+        }
       }
       if (F & F_GELUBWD) {
         const uint2 q = pre_act[st];
-        const f32x2_v g01 = gelu_grad2_f((f32x2_v){__uint_as_float(q.x << 16), __uint_as_float(q.x & 0xffff0000u)});
-        const f32x2_v g23 = gelu_grad2_f((f32x2_v){__uint_as_float(q.y << 16), __uint_as_float(q.y & 0xffff0000u)});
+        const f32x2_v a01 = (f32x2_v){__uint_as_float(q.x << 16), __uint_as_float(q.x & 0xffff0000u)};
+        const f32x2_v a23 = (f32x2_v){__uint_as_float(q.y << 16), __uint_as_float(q.y & 0xffff0000u)};
+        const f32x2_v g01 = (F & F_MULACT) ? a01 : gelu_grad2_f(a01);
+        const f32x2_v g23 = (F & F_MULACT) ? a23 : gelu_grad2_f(a23);
         v[0] *= g01.x; v[1] *= g01.y; v[2] *= g23.x; v[3] *= g23.y;
       }
       if (F & F_DROP) drop4(v, didx, p.drop_key, p.drop_thr, p.drop_scale);
@@ -407,6 +425,8 @@ __device__ __forceinline__ bool try_epilogue_fast(const GemmArgs& p, f32x16 (&ac
   if (p.bias && lead) f |= F_BIAS;
   if (p.act == 1) f |= F_GELU | (p.pre_out ? F_PRE : 0);
   if (p.act == 2) f |= F_GELUBWD;
+  if (p.act == 3) f |= F_GELU | F_PRE | F_GP;
+  if (p.act == 4) f |= F_GELUBWD | F_MULACT;
   if (p.drop_thr) f |= F_DROP;
   if (p.resid && lead) f |= F_RESID;
   if (Cf_out) f |= F_CF | ((!to_ws && p.accumulate) ? F_ACCUM : 0);
@@ -423,6 +443,9 @@ __device__ __forceinline__ bool try_epilogue_fast(const GemmArgs& p, f32x16 (&ac
     NEKO_FAST_EPI(F_BIAS | F_DROP | F_RESID | F_CF)               // forward proj (residual dropout)
     NEKO_FAST_EPI(F_GELUBWD | F_CB)                               // dgrad through the MLP projection (* GELU')
     NEKO_FAST_EPI(F_GELUBWD | F_CB | F_COLSUM)                    // ... with the c_fc bias gradient folded in
+    NEKO_FAST_EPI(F_BIAS | F_GELU | F_PRE | F_GP | F_CB)          // forward fc that leaves gelu'(pre) for the backward (act = 3)
+    NEKO_FAST_EPI(F_GELUBWD | F_MULACT | F_CB)                    // dgrad through the MLP projection (* stored gelu', act = 4)
+    NEKO_FAST_EPI(F_GELUBWD | F_MULACT | F_CB | F_COLSUM)
     NEKO_FAST_EPI(F_CB)                                           // dgrad attention out, LM-head logits
     NEKO_FAST_EPI(F_CF)                                           // dgrad fc / qkv, split-K slices
     NEKO_FAST_EPI(F_CF | F_ALPHA)                                 // LM-head dH (device-side grad_output)
@@ -506,16 +529,17 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, f32x16 (&acc)[C::TM]
           for (int e = 0; e < nv; ++e) dst[e] = pb[e];
         }
       }
-    } else if (p.act == 2) {
+    } else if (p.act == 3) {            // GELU forward; pre_out receives gelu'(pre) (the backward multiplies by it, act = 4)
+      for (int e = 0; e < nv; ++e) {
+        const float x = bf16_to_f32(f32_to_bf16(v[e]));
+        p.pre_out[(long)row * p.ldpre + col + e] = f32_to_bf16(gelu_grad_f(x));
+        v[e] = gelu_f(x);
+      }
+    } else if (p.act == 2 || p.act == 4) {
       const bf16_t* src = p.act_in + (long)row * p.ldact + col;
-      if (vec) {
-        const uint2 q = *reinterpret_cast<const uint2*>(src);
-        v[0] *= gelu_grad_f(bf16_to_f32((bf16_t)(q.x & 0xffff)));
-        v[1] *= gelu_grad_f(bf16_to_f32((bf16_t)(q.x >> 16)));
-        v[2] *= gelu_grad_f(bf16_to_f32((bf16_t)(q.y & 0xffff)));
-        v[3] *= gelu_grad_f(bf16_to_f32((bf16_t)(q.y >> 16)));
-      } else {
-        for (int e = 0; e < nv; ++e) v[e] *= gelu_grad_f(bf16_to_f32(src[e]));
+      for (int e = 0; e < nv; ++e) {
+        const float a = bf16_to_f32(src[e]);
+        v[e] *= (p.act == 4) ? a : gelu_grad_f(a);
       }
     }
     if (p.drop_thr) {
@@ -687,7 +711,11 @@ __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void gemm_glds_kernel(Gem
 #ifndef NEKO_GEMM_PIPE_TN
 #define NEKO_GEMM_PIPE_TN 1   // both operands k-strided too: with the fragment reads interleaved it wins there as well (wgrad -2..6 %)
 #endif
-  if constexpr (NSTAGE >= 4 && BK == 32 && (A_KC || B_KC || NEKO_GEMM_PIPE_TN) && NEKO_GEMM_PIPE) {
+#ifndef NEKO_GEMM_PIPE_MIN_STAGES
+#define NEKO_GEMM_PIPE_MIN_STAGES 4   // r03: 3 = the 3-stage rings take the pipelined loop too (correct, wait counts scale with NSTAGE); measured +-2 %
+                                      // on 256x128 (profiles/r03_tile_ab1.txt), not measured on 128x128: left off
+#endif
+  if constexpr (NSTAGE >= NEKO_GEMM_PIPE_MIN_STAGES && BK == 32 && (A_KC || B_KC || NEKO_GEMM_PIPE_TN) && NEKO_GEMM_PIPE) {
     // Pipelined loop (4-stage rings).  The block barrier of tile kt+1 sits in the MIDDLE of tile kt, between its two
     // k-steps, and the operands of a k-step are requested one k-step ahead:
     //     [F1 <- tile kt, k-step 1] [MFMAs k-step 0 on F0] [barrier: tile kt+1 visible, slot of tile kt-1 free]
@@ -859,7 +887,7 @@ int launch_cfg(const GemmArgs& a_in, hipStream_t s) {
   const int nbm = (a.M + C::BM - 1) / C::BM, nbn = (a.N + C::BN - 1) / C::BN;
   // column sums ride along only when EVERY tile takes the compiled fast epilogue that carries them (interior tiles of a
   // plain GELU' dgrad); otherwise the caller runs the stand-alone column-sum kernel on the stored result
-  const bool fold = a.colsum_ws && a.M % C::BM == 0 && a.N % C::BN == 0 && a.splitk <= 1 && a.act == 2 && a.Cb && !a.Cf &&
+  const bool fold = a.colsum_ws && a.M % C::BM == 0 && a.N % C::BN == 0 && a.splitk <= 1 && (a.act == 2 || a.act == 4) && a.Cb && !a.Cf &&
                     !a.bias && !a.resid && !a.drop_thr && a.alpha == 1.0f && !a.alpha_dev &&
                     !(((a.ldcb | a.ldact) & 3) || (a.N & 3));
   if (!fold) a.colsum_ws = nullptr;

@@ -189,24 +189,24 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
       }
     }
   }
-  // combine the 4 waves
+  // combine the 4 waves: [wave][2 or 3 rows][d] floats of dynamic LDS (the column-sum row only when it is asked for)
   float4* l4 = reinterpret_cast<float4*>(lds);
+  const int nrow = want_colsum ? 3 : 2;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = lane + 64 * i;
     if (c < nvec) {
-      l4[(wave * 3 + 0) * nvec + c] = dg[i];
-      l4[(wave * 3 + 1) * nvec + c] = db[i];
-      l4[(wave * 3 + 2) * nvec + c] = dc[i];
+      l4[(wave * nrow + 0) * nvec + c] = dg[i];
+      l4[(wave * nrow + 1) * nvec + c] = db[i];
+      if (want_colsum) l4[(wave * nrow + 2) * nvec + c] = dc[i];
     }
   }
   __syncthreads();
-  const int nrow = want_colsum ? 3 : 2;
   for (int idx = threadIdx.x; idx < nrow * nvec; idx += 256) {
     float4 a = l4[idx];
 #pragma unroll
     for (int w = 1; w < 4; ++w) {
-      const float4 b = l4[w * 3 * nvec + idx];
+      const float4 b = l4[w * nrow * nvec + idx];
       a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
     }
     reinterpret_cast<float4*>(part + (long)blockIdx.x * 3 * d)[idx] = a;   // [block][3][d]
@@ -258,11 +258,13 @@ template <int NV>
 int bwd_launch(const void* dy, int dy16, const float* x, const float* g, const float* mean, const float* rstd,
                const float* g_in, float* dx, bf16_t* dx16, float* part, int nblk, int M, int d, int thr, unsigned key,
                float scale, int want_colsum, hipStream_t s) {
+  const size_t lds_bytes = (size_t)(want_colsum ? 12 : 8) * d * sizeof(float);     // 4 waves x (2 or 3) rows x d
+  if (lds_bytes > 160 * 1024) return NEKO_ERR_UNSUPPORTED;                          // one workgroup's LDS limit on gfx950
   if (dy16)
-    hipLaunchKernelGGL((ln_bwd_kernel<NV, true>), dim3(nblk), dim3(256), (size_t)12 * d * sizeof(float), s, dy, x, g, mean,
+    hipLaunchKernelGGL((ln_bwd_kernel<NV, true>), dim3(nblk), dim3(256), lds_bytes, s, dy, x, g, mean,
                        rstd, g_in, dx, dx16, part, M, d, (uint32_t)thr, key, scale, want_colsum);
   else
-    hipLaunchKernelGGL((ln_bwd_kernel<NV, false>), dim3(nblk), dim3(256), (size_t)12 * d * sizeof(float), s, dy, x, g, mean,
+    hipLaunchKernelGGL((ln_bwd_kernel<NV, false>), dim3(nblk), dim3(256), lds_bytes, s, dy, x, g, mean,
                        rstd, g_in, dx, dx16, part, M, d, (uint32_t)thr, key, scale, want_colsum);
   NEKO_CHECK_LAUNCH();
   return NEKO_OK;

@@ -30,10 +30,10 @@ int neko_gemm_bf16(const uint16_t* A, long lda, int a_kstrided, const uint16_t* 
 
 long neko_gemm_colsum_ws_floats(int M, int N) { return (long)((M + 63) / 64) * (long)N; }
 int neko_gemm_dgrad_gelu_colsum(const uint16_t* dY, long lda, const uint16_t* W, long ldb, int M, int N, int K,
-                                const uint16_t* act_in, long ldact, uint16_t* Cb, long ldcb, float* colsum_ws,
-                                float* colsum_out, void* stream) {
+                                const uint16_t* act_in, long ldact, int act_in_is_factor, uint16_t* Cb, long ldcb,
+                                float* colsum_ws, float* colsum_out, void* stream) {
   if (!Cb || !act_in || !colsum_out) return NEKO_ERR_ARG;
-  GemmArgs a{dY, W, lda, ldb, M, N, K, 1.0f, nullptr, nullptr, nullptr, 0, act_in, ldact, nullptr, 0, 2,
+  GemmArgs a{dY, W, lda, ldb, M, N, K, 1.0f, nullptr, nullptr, nullptr, 0, act_in, ldact, nullptr, 0, act_in_is_factor ? 4 : 2,
              nullptr, 0, 0, Cb, ldcb, 1, 0, nullptr, 0, 0u, 1.0f};
   a.colsum_ws = colsum_ws;
   (void)neko_gemm_glds_colsum_bands();

@@ -71,6 +71,7 @@ class LayerCtx:
     dmask: object = None      # attention-dropout keep masks of the forward (tensor, list per segment, or None)
     x1: torch.Tensor = None; a2: torch.Tensor = None; mean2: torch.Tensor = None; rstd2: torch.Tensor = None
     pre: torch.Tensor = None; h: torch.Tensor = None; gate: torch.Tensor = None
+    pre_is_factor: bool = False     # `pre` holds gelu'(pre-activation) (forward epilogue act 3) instead of the pre-activation
 
 
 @dataclass
@@ -102,6 +103,13 @@ class StackCtx:
 #: box (23.17 vs 22.96 ms: the 8-byte-per-lane bf16 epilogue stores of the N = 768 dgrads cost more than the LayerNorm
 #: backward saves), so fp32 stays the default; both paths are covered by the LayerNorm parity test.
 LN_DY_DTYPE = BF16 if os.environ.get("NEKO_LN_DY_BF16", "0") == "1" else F32
+
+#: The forward c_fc GEMM can leave gelu'(pre) (bf16) instead of the pre-activation in its second output (epilogue act 3:
+#: both values come out of ONE evaluation of the erf series), so that the dgrad through the MLP projection multiplies by a
+#: stored factor (act 4) instead of evaluating the series again for 65536 x 3072 elements per layer: its GELU' epilogue
+#: cost 11.6 us of every 30 us tile.  The factor is rounded to bf16 (2^-9 relative, unbiased) before the
+#: product is; gated MLPs (GEGLU) keep the pre-activation, their backward needs gelu(pre) as well.  NEKO_GELU_FACTOR=0: off.
+GELU_FACTOR = os.environ.get("NEKO_GELU_FACTOR", "1") != "0"
 
 
 def _dgrad_to_ln(a, w, M, N, K, ldb):
@@ -268,14 +276,15 @@ def stack_forward(P: StackParams, x: torch.Tensor, mask: torch.Tensor, save: boo
         ops.layernorm_fwd(x1, lp.ln2_w, lp.ln2_b, y16=a2, mean=mean2, rstd=rstd2, eps=P.eps)
         pre = torch.empty(M, 4 * d, dtype=BF16, device=dev) if save else None
         h = torch.empty(M, 4 * d, dtype=BF16, device=dev)
-        ops.gemm(a2, lp.w_fc, M, 4 * d, d, b_kstrided=True, bias=lp.b_fc, act=1, pre_out=pre, out_bf16=h)
+        factor = save and GELU_FACTOR and lp.w_gate is None       # `pre` then holds gelu'(pre), see GELU_FACTOR
+        ops.gemm(a2, lp.w_fc, M, 4 * d, d, b_kstrided=True, bias=lp.b_fc, act=3 if factor else 1, pre_out=pre, out_bf16=h)
         gate = _geglu_gate(lp, a2, h, M, d)
         x2 = torch.empty(M, d, dtype=F32, device=dev)
         ops.gemm(h, lp.w_pr, M, d, 4 * d, b_kstrided=True, bias=lp.b_pr, resid=x1, out_f32=x2,
                  drop=dr.resid_mlp[li] if dr else None)
         if save:
             ctx.layers.append(LayerCtx(x=x, a1=a1, mean1=mean1, rstd1=rstd1, qkv=qkv, o=o, lse=lse, dmask=dmask, x1=x1, a2=a2,
-                                       mean2=mean2, rstd2=rstd2, pre=pre, h=h, gate=gate))
+                                       mean2=mean2, rstd2=rstd2, pre=pre, h=h, gate=gate, pre_is_factor=factor))
         x = x2
     hf16 = torch.empty(M, d, dtype=BF16, device=dev) if want_bf16 else None
     hf32 = torch.empty(M, d, dtype=F32, device=dev) if want_f32 else None
@@ -316,7 +325,8 @@ def stack_backward(P: StackParams, ctx: StackCtx, dhf: torch.Tensor,
         d_pre = torch.empty(M, 4 * d, dtype=BF16, device=dev)
         d_gate = None
         if c.gate is None:    # dgrad * gelu', the c_fc bias gradient (column sums of d_pre) folded into its epilogue
-            ops.gemm_dgrad_gelu_colsum(g16, lp.w_pr, M, 4 * d, d, c.pre, d_pre, lp.g_b_fc, ldb=d)
+            ops.gemm_dgrad_gelu_colsum(g16, lp.w_pr, M, 4 * d, d, c.pre, d_pre, lp.g_b_fc, ldb=d,
+                                       act_in_is_factor=c.pre_is_factor)
         else:                                                                                 # GEGLU: h = gelu(pre) * gate
             ops.gemm(g16, lp.w_pr, M, 4 * d, d, ldb=d, out_bf16=d_pre)                        # d_h
             d_pre, d_gate = ops.geglu_bwd(d_pre, c.pre, c.gate)

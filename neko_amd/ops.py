@@ -140,15 +140,17 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, a_kstrided
 
 
 def gemm_dgrad_gelu_colsum(dY: torch.Tensor, W: torch.Tensor, M: int, N: int, K: int, act_in: torch.Tensor,
-                           out_bf16: torch.Tensor, colsum_out: torch.Tensor, ldb: Optional[int] = None) -> None:
+                           out_bf16: torch.Tensor, colsum_out: torch.Tensor, ldb: Optional[int] = None,
+                           act_in_is_factor: bool = False) -> None:
     """out_bf16[M,N] = (dY[M,K] @ W[N,K]^T) * gelu'(act_in); colsum_out[N] += its column sums (the c_fc bias gradient),
-    one launch (+ a 10 us band reduction).  See neko_gemm_dgrad_gelu_colsum in include/neko_hip.h."""
+    one launch (+ a 10 us band reduction).  act_in_is_factor: act_in already holds gelu'(pre) (forward ran with act=3).
+    See neko_gemm_dgrad_gelu_colsum in include/neko_hip.h."""
     _chk(dY, BF16, "dY"); _chk(W, BF16, "W"); _chk(act_in, BF16, "act_in"); _chk(out_bf16, BF16, "out_bf16")
     _chk(colsum_out, torch.float32, "colsum_out"); assert colsum_out.numel() >= N
     ws = torch.empty(int(_lib.load().neko_gemm_colsum_ws_floats(M, N)), dtype=torch.float32, device=dY.device)
     _lib.call("neko_gemm_dgrad_gelu_colsum", _p(dY), dY.stride(0) if dY.dim() == 2 else K, _p(W),
               ldb if ldb is not None else (W.stride(0) if W.dim() == 2 else K), M, N, K, _p(act_in),
-              act_in.stride(0) if act_in.dim() == 2 else N, _p(out_bf16),
+              act_in.stride(0) if act_in.dim() == 2 else N, int(bool(act_in_is_factor)), _p(out_bf16),
               out_bf16.stride(0) if out_bf16.dim() == 2 else N, _p(ws), _p(colsum_out), _stream())
 
 

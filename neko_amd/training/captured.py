@@ -51,7 +51,6 @@ class CapturedTrainStep:
         self.entries: Dict[tuple, _Entry] = {}
         self.max_graphs = max_graphs
         self.salt = torch.zeros(1, dtype=torch.int32, device=dev)
-        self._lr_host = torch.zeros(1, dtype=torch.float32).pin_memory()
         optimizer.lr_dev = torch.full((1,), float(optimizer.param_groups[0]["lr"]), dtype=torch.float32, device=dev)
         ops.set_drop_salt(self.salt)                 # eager steps of this model read the same salt: one code path
         self._eager_active = optimizer.active        # the optimiser's own flag tensor (eager steps rewrite it)
@@ -87,8 +86,9 @@ class CapturedTrainStep:
         pr = m._prepare(batch, rg if len(batch) > 1 else 0)
         lr = float(self.sch.get_last_lr()[0]) if self.sch is not None else float(self.opt.param_groups[0]["lr"])
         self.opt.param_groups[0]["lr"] = lr
-        self._lr_host[0] = lr
-        self.opt.lr_dev.copy_(self._lr_host, non_blocking=True)
+        # the value travels as the ARGUMENT of a fill launch outside the graph: a reusable pinned host word could be overwritten
+        # by a later step() before an earlier asynchronous upload has read it (the host runs ahead of the device in replay mode)
+        self.opt.lr_dev.fill_(lr)
         key = pr.signature()
         e = self.entries.get(key)
         if e is None:

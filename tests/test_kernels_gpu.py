@@ -197,6 +197,43 @@ def test_gemm_dgrad_gelu_colsum(ops, M, N, K):
     assert torch.equal(out, out3)
 
 
+@pytest.mark.parametrize("M,N,K", [(1024, 3072, 768), (300, 256, 192)])
+def test_gemm_gelu_factor_epilogues(ops, M, N, K):
+    """ABI v14: the forward epilogue act = 3 leaves gelu'(pre) (bf16) in its second output, the backward epilogue act = 4
+    multiplies by that stored factor (trajectory_gpt2.py:266,274 forward / backward of h = gelu(c_fc x)): interior
+    (compiled fast epilogue) and ragged (generic epilogue) tiles, both against torch's erf GELU."""
+    g = torch.Generator().manual_seed(M + 7 * N)
+    A, W = rb(torch.randn(M, K, generator=g)), rb(torch.randn(K, N, generator=g) * 0.1)
+    bias = torch.randn(N, generator=g)
+    fac = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    h = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(bf(A), bf(W), M, N, K, b_kstrided=True, bias=bias.to(DEV), act=3, pre_out=fac, out_bf16=h)
+    x = rb(A @ W + bias)                      # the pre-activation is rounded to bf16 first (as with act = 1)
+    gprime = 0.5 * (1 + torch.erf(x / math.sqrt(2))) + x * torch.exp(-0.5 * x * x) / math.sqrt(2 * math.pi)
+    # the bf16 rounding of the pre-activation may differ by one ulp from the host's: compare through act = 1's stored value
+    pre = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    h1 = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(bf(A), bf(W), M, N, K, b_kstrided=True, bias=bias.to(DEV), act=1, pre_out=pre, out_bf16=h1)
+    assert torch.equal(h, h1), "act = 3 must produce the same activation as act = 1"
+    xd = pre.float().cpu()
+    gprime = 0.5 * (1 + torch.erf(xd / math.sqrt(2))) + xd * torch.exp(-0.5 * xd * xd) / math.sqrt(2 * math.pi)
+    close(fac, gprime, 2 ** -8, 1e-3, "stored gelu'")
+    dY = rb(torch.randn(M, K, generator=g))
+    W2 = rb(torch.randn(N, K, generator=g) * 0.1)
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    base = torch.randn(N, generator=g)
+    cs = base.clone().to(DEV)
+    ops.gemm_dgrad_gelu_colsum(bf(dY), bf(W2), M, N, K, fac, out, cs, act_in_is_factor=True)
+    ref = (dY @ W2.t()) * fac.float().cpu()
+    close(out, ref, 2 ** -8, 2e-3, "d_pre from the stored factor")
+    close(out, (dY @ W2.t()) * gprime, 2 ** -7, 4e-3, "d_pre vs exact gelu'")
+    want = base + ref.sum(0)
+    assert float((cs.cpu() - want).norm() / want.norm()) < 2e-3
+    out2 = torch.empty_like(out)
+    ops.gemm(bf(dY), bf(W2), M, N, K, act=4, act_in=fac, out_bf16=out2)
+    assert torch.equal(out, out2)
+
+
 # ----------------------------------------------------------------------------------------------------
 # LayerNorm
 # ----------------------------------------------------------------------------------------------------
