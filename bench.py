@@ -152,7 +152,7 @@ def time_more_kernels(B: int, Tlen: int, dropout: float):
     """The kernels the step's time actually sits in (the LM-head GEMM is 5 % of it), timed live at the
     workload's shapes: attention forward / backward of one layer (useful causal FLOPs: 2 B T^2 d forward, 2.5x that
     backward) and the three K = 768 / K = 3072 GEMM shapes of a block."""
-    from neko_amd import ops
+    from neko_amd import engine, ops
     M, d, hd = B * Tlen, D, D // H
     out = []
     qkv = (torch.randn(M, 3 * d, device="cuda") * 0.5).to(torch.bfloat16)
@@ -174,11 +174,28 @@ def time_more_kernels(B: int, Tlen: int, dropout: float):
         bias = torch.zeros(N, device="cuda")
         y = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
         pre = torch.empty(M, N, dtype=torch.bfloat16, device="cuda") if "GELU" in name else None
-        ms = _time_events(lambda: ops.gemm(x, w, M, N, K, b_kstrided=True, bias=bias, act=1 if pre is not None else 0,
-                                           pre_out=pre, out_bf16=y))
+        act = (3 if engine.GELU_FACTOR else 1) if pre is not None else 0      # the call stack_forward makes
+        ms = _time_events(lambda: ops.gemm(x, w, M, N, K, b_kstrided=True, bias=bias, act=act, pre_out=pre, out_bf16=y))
         fl = 2.0 * M * N * K
         out.append({"kernel": f"gemm {name}", "shape_MNK": [M, N, K], "ms_per_launch": ms, "achieved": fl / ms / 1e9,
                     "unit": "TFLOP/s", "frac": fl / ms / 1e9 / MFMA_PEAK_TFLOPS, "bound": "mfma"})
+    # the backward's two dgrads through the MLP (the top GEMM family by time): d_pre = (g . Wpr^T) * gelu'
+    # with the c_fc bias gradient folded in, and d_a2 = d_pre . Wfc^T in the dtype the LayerNorm backward is fed
+    g16 = torch.randn(M, d, device="cuda").to(torch.bfloat16)
+    w_pr = (torch.randn(4 * d, d, device="cuda") * 0.02).to(torch.bfloat16)         # (in = 4d, out = d): k-contiguous for the dgrad
+    fac = torch.rand(M, 4 * d, device="cuda").to(torch.bfloat16)
+    d_pre = torch.empty(M, 4 * d, dtype=torch.bfloat16, device="cuda")
+    gb = torch.zeros(4 * d, device="cuda")
+    ms = _time_events(lambda: ops.gemm_dgrad_gelu_colsum(g16, w_pr, M, 4 * d, d, fac, d_pre, gb, ldb=d,
+                                                         act_in_is_factor=engine.GELU_FACTOR))
+    fl = 2.0 * M * 4 * d * d
+    out.append({"kernel": "gemm dgrad mlp c_proj * gelu' (+ c_fc bias gradient)", "shape_MNK": [M, 4 * d, d], "ms_per_launch": ms,
+                "achieved": fl / ms / 1e9, "unit": "TFLOP/s", "frac": fl / ms / 1e9 / MFMA_PEAK_TFLOPS, "bound": "mfma"})
+    w_fc = (torch.randn(d, 4 * d, device="cuda") * 0.02).to(torch.bfloat16)         # (in = d, out = 4d)
+    ms = _time_events(lambda: engine._dgrad_to_ln(d_pre, w_fc, M, d, 4 * d, 4 * d))
+    out.append({"kernel": f"gemm dgrad c_fc ({'bf16' if engine.LN_DY_DTYPE == torch.bfloat16 else 'f32'} out)", "shape_MNK": [M, d, 4 * d],
+                "ms_per_launch": ms, "achieved": fl / ms / 1e9, "unit": "TFLOP/s", "frac": fl / ms / 1e9 / MFMA_PEAK_TFLOPS,
+                "bound": "mfma"})
     return out
 
 
@@ -392,12 +409,16 @@ def main():
         # MFMA-pipe utilisation of the same kernel from the committed SQ counter pass (tools/pmc_gemm.sh): context for
         # `frac`, which is priced against the nominal 2.5 PFLOP/s at 2.4 GHz while the chip sustains ~1.5-1.7 GHz here
         mfma_busy = None
-        cps = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_gemm_counters.txt")), reverse=True)
-        cp = cps[0] if cps else None
-        if cp and D == 768:
+        # newest round first (file names start with the round: r03_... > r02_... > r01_...); the first file that holds a
+        # summarised lmlogit16 line wins, and the bench line names the file it quotes
+        cp = None
+        if D == 768:
             import re
-            mm = re.search(r"lmlogit16: .*?MFMA pipe busy ([0-9.]+) %", open(cp).read())
-            mfma_busy = float(mm.group(1)) / 100 if mm else None
+            for cand in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_gemm_counters*.txt")), reverse=True):
+                mm = re.search(r"lmlogit16: .*?MFMA pipe busy ([0-9.]+) %", open(cand).read())
+                if mm:
+                    cp, mfma_busy = cand, float(mm.group(1)) / 100
+                    break
         out = {
             "metric": METRIC, "value": value, "unit": "tokens/s",
             "value_includes": "fwd + bwd + gradient all-reduce + clip + AdamW (whole job, all GPUs)",

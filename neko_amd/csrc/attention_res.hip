@@ -16,7 +16,6 @@
 //     (the K^T / V^T / Q^T / dO^T operands), so no transposed copy is built.
 //   * workgroup ids are paired so that heads 2j and 2j+1 of one batch row (the two halves of every 128-byte line of
 //     the [B*T, 3d] qkv matrix) run on the same XCD.
-#include <cstdlib>
 #include "neko_kernels.h"
 
 namespace {
@@ -819,382 +818,6 @@ __global__ __launch_bounds__(NEKO_DKV_WAVES * 64) void attn_dkv_res_kernel(const
   NEKO_ATRACE(3, ntiles_traced);
 }
 
-
-// ---- half-resident schedule (r03) -------------------------------------------------------------------------------------
-// The head-resident kernels above keep BOTH operand images of a head in LDS: 128 KB at T = 1024, i.e. ONE workgroup per
-// CU, whose staging (7.6-9.2 us of a 45-63 us forward workgroup, r02 phase trace) and whose wait for its slowest wave
-// (3-6 us) run with nothing else resident on the CU.  Only the operand that is read TRANSPOSED (ds_read_b64_tr_b16: V in
-// the forward, K in dQ) needs LDS; the other one (K rows in the forward, V rows in dQ) is consumed in its natural
-// [row][hd] layout, 16 bytes per lane, and is requested straight from L2 (the 64 KB of a head stay cache-resident) one
-// key block ahead.  That halves the LDS image to 64 KB + 4 KB: TWO workgroups per CU (8 waves each in the forward, 6 in
-// dQ, the same waves per SIMD as before) whose prologues and tails overlap each other's key loops.
-__device__ __forceinline__ void gfrag_rows(const bf16_t* __restrict__ base, long ld, int row0, int T, int lane, bf16x8_v (&f)[2]) {
-  const int row = min(row0 + (lane & 31), T - 1);             // clamped: rows >= T only meet masked (-inf) scores
-  const bf16_t* p = base + (long)row * ld + (lane >> 5) * 8;
-  f[0] = __builtin_bit_cast(bf16x8_v, *reinterpret_cast<const uint4*>(p));
-  f[1] = __builtin_bit_cast(bf16x8_v, *reinterpret_cast<const uint4*>(p + 16));
-}
-// stage ONE [T][32] bf16 matrix into a swizzled image, rows >= T zero; every load in flight before the first LDS store
-__device__ __forceinline__ void stage_one(const bf16_t* __restrict__ a, long lda, char* img, int T, int Tp, int tid, int nthr) {
-  const int total = Tp * 4;
-  constexpr int NB = 8;
-  for (int c0 = 0; c0 < total; c0 += nthr * NB) {
-    uint4 ra[NB];
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      const int c = c0 + i * nthr + tid, row = c >> 2, p = c & 3;
-      ra[i] = make_uint4(0, 0, 0, 0);
-      if (c < total && row < T) ra[i] = *reinterpret_cast<const uint4*>(a + (long)row * lda + p * 8);
-    }
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      const int c = c0 + i * nthr + tid, row = c >> 2, p = c & 3;
-      if (c < total) *reinterpret_cast<uint4*>(img + img_off(row, p)) = ra[i];
-    }
-  }
-}
-
-// =====================================================================================================
-// half-resident forward / dQ (see the note above gfrag_rows)
-// =====================================================================================================
-template <bool DROP, bool MASK>
-__global__ __launch_bounds__(512, 4) void attn_fwd_hr_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ kbias,
-                                                            const int* __restrict__ kstart, bf16_t* __restrict__ out,
-                                                            float* __restrict__ lse, int B, int T, int H, float scale,
-                                                            uint32_t drop_thr, uint32_t drop_key, float drop_scale,
-                                                            uint32_t* __restrict__ dmask) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  if (DROP) drop_key += neko_drop_salt();
-  const int Tp = (T + 31) & ~31, nblk = Tp >> 5;
-  char* imgV = smem;
-  float* ldsKb = reinterpret_cast<float*>(smem + Tp * 64);
-  int* queue = reinterpret_cast<int*>(ldsKb + Tp);
-
-  const int tid = threadIdx.x, lane = tid & 63, nthr = blockDim.x;
-  if (tid == 0) *queue = 0;
-  const int hb = pair_remap(blockIdx.x, B * H);
-  const int b = hb / H, h = hb % H;
-  const int d = H * 32;
-  const long ld = 3L * d;
-  const bf16_t* qbase = qkv + (long)b * T * ld + h * 32;
-  const float* kb = kbias + (long)b * T;
-
-  stage_one(qbase + 2 * d, ld, imgV, T, Tp, tid, nthr);
-  const bf16_t* kbase = qbase + d;
-  for (int i = tid; i < Tp; i += nthr) ldsKb[i] = (i < T) ? kb[i] * LOG2E : 0.f;
-  const int kb_first = kstart ? (kstart[b] >> 5) : 0;
-  __syncthreads();
-  const uint32_t padmask = pad_mask_of(ldsKb, Tp, nblk, lane);     // from the LDS copy (zero beyond T): no second trip to memory
-
-  const float scale2 = scale * LOG2E;
-#pragma unroll 1
-  for (int item = next_item(queue, lane); item < nblk; item = next_item(queue, lane)) {
-    const int qb = block_of_item(item, padmask, nblk);   // heaviest first
-    const int q = qb * 32 + (lane & 31);
-    const bool qvalid = q < T;
-    bf16x8_v qf[2];
-    row_frags(qbase + (long)q * ld, qvalid, lane, qf);
-    // a wave that holds a masked (padded) query row visits every key: the reference's finite masks let such a row see
-    // them; for every other row the keys beyond its diagonal contribute exp(-1e4 - m) == 0 in fp32
-    const bool wave_full = (padmask >> qb) & 1;
-    const int kb_beg = wave_full ? 0 : min(kb_first, qb);
-    const int kb_end = wave_full ? nblk : qb + 1;
-
-    f32x16 o;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[r] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
-    bf16x8_v kcur[2], knext[2];
-    gfrag_rows(kbase, ld, kb_beg * 32, T, lane, kcur);
-
-#pragma unroll 1
-    for (int kbk = kb_beg; kbk < kb_end; ++kbk) {
-      const int k0 = kbk * 32;
-      gfrag_rows(kbase, ld, min(kbk + 1, kb_end - 1) * 32, T, lane, knext);    // one key block ahead (unconditional, clamped)
-      f32x16 st;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) st[r] = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kcur[ks], qf[ks], st, 0, 0, 0);
-      kcur[0] = knext[0];
-      kcur[1] = knext[1];
-      const bool interior = (kbk < qb) && !((padmask >> kbk) & 1) && (k0 + 32 <= T);
-      if (!interior) {
-        const int lim_causal = q - k0 - 4 * (lane >> 5);        // key <= q  <=>  c(r) <= lim_causal
-        const int lim_len = T - 1 - k0 - 4 * (lane >> 5);       // key <  T  <=>  c(r) <= lim_len
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int c = (r & 3) + 8 * (r >> 2);
-          float v = (c <= lim_causal) ? st[r] * scale2 : MASK_VAL * LOG2E;
-          v += ldsKb[k0 + c + 4 * (lane >> 5)];
-          st[r] = (c <= lim_len) ? v : -INFINITY;
-        }
-      }
-      const float sc = interior ? scale2 : 1.0f;      // interior scores are still unscaled
-      // Online softmax WITHOUT a row maximum per sub-tile: the exponentials are taken against the running reference
-      // m_run first, and only when some lane's partial sum shows that a score climbed more than ~2^8 above it (or m_run
-      // is still -inf: first sub-tile of the row, the sum is inf / NaN) the wave computes the row maxima, moves m_run,
-      // rescales and redoes the exponentials.  Softmax is shift invariant, so any reference that keeps the terms inside
-      // the fp32 range gives the same result; the 16-way max chain, the lane^32 exchange and the compare that used to
-      // run for EVERY sub-tile (~15 VALU + one LDS round trip of ~125) now run for the first sub-tile of a row and
-      // after rare jumps.  The two halves of a row (lanes l, l^32) must share m_run: the decision is a wave ballot.
-      f32x16 pr;
-      float ps0 = 0.f, ps1 = 0.f;
-      bool renorm = kbk == kb_beg;                     // first sub-tile of the rows: m_run is still -inf
-      if (!renorm) {
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-          const f32x2_v pv = exp2_fast2(__builtin_elementwise_fma(pk2(st[r], st[r + 1]), (f32x2_v)(sc), (f32x2_v)(-m_run)));
-          pr[r] = pv.x;
-          pr[r + 1] = pv.y;
-          ps0 += pv.x;
-          ps1 += pv.y;
-        }
-        renorm = __builtin_amdgcn_ballot_w64(!((ps0 + ps1) < 256.0f)) != 0;
-      }
-      if (renorm) {
-        float mx = fmaxf(st[0], st[1]);
-#pragma unroll
-        for (int r = 2; r < 16; ++r) mx = fmaxf(mx, st[r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx * sc);
-        const float alpha = exp2_fast(m_run - m_new);   // 2^(-inf) = 0 on the first tile
-        l_run *= alpha;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[r] *= alpha;
-        m_run = m_new;
-        ps0 = 0.f;
-        ps1 = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-          const f32x2_v pv = exp2_fast2(__builtin_elementwise_fma(pk2(st[r], st[r + 1]), (f32x2_v)(sc), (f32x2_v)(-m_run)));
-          pr[r] = pv.x;
-          pr[r + 1] = pv.y;
-          ps0 += pv.x;
-          ps1 += pv.y;
-        }
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) st[r] = pr[r];
-      l_run += ps0 + ps1;
-      if (DROP) {   // attn_dropout on the probabilities (trajectory_gpt2.py:179): the normaliser stays undropped
-        const uint32_t g0 = ((uint32_t)(b * H + h) * (uint32_t)T + (uint32_t)q) * (uint32_t)((T + 3) >> 2) +
-                            (uint32_t)((k0 + 4 * (lane >> 5)) >> 2);
-        unsigned long long km[16];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {          // registers 4j..4j+3 = keys +8j .. +8j+3: one word
-          const uint32_t w = drop_word(g0 + 2 * j, drop_key);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const bool keep = drop_byte_keep(w, e, drop_thr);
-            if (MASK) km[4 * j + e] = __builtin_amdgcn_ballot_w64(keep);     // the compare's own SGPR pair
-            st[4 * j + e] = keep ? st[4 * j + e] : 0.f;
-          }
-        }
-        if (MASK) {     // the sub-tile's 16 lane masks -> mask[(b*H+h)][qb][kbk][32 dwords], 8 scalar stores
-          uint32_t* mp = const_cast<uint32_t*>(static_cast<const uint32_t*>(
-              uniform_ptr(dmask + (((long)hb * nblk + qb) * nblk + kbk) * 32)));
-          sstore_masks<0>(mp, km[0], km[1]);
-          sstore_masks<16>(mp, km[2], km[3]);
-          sstore_masks<32>(mp, km[4], km[5]);
-          sstore_masks<48>(mp, km[6], km[7]);
-          sstore_masks<64>(mp, km[8], km[9]);
-          sstore_masks<80>(mp, km[10], km[11]);
-          sstore_masks<96>(mp, km[12], km[13]);
-          sstore_masks<112>(mp, km[14], km[15]);
-        }
-      }
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2)
-        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(imgV, k0, s2, lane), frag_from_acc(st, s2), o, 0, 0, 0);
-    }
-
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    if (qvalid) {
-      const float inv = (DROP ? drop_scale : 1.0f) / l_tot;
-      bf16_t* orow = out + ((long)b * T + q) * d + h * 32;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        uint2 pk;
-        pk.x = pack_bf16x2(o[4 * g + 0] * inv, o[4 * g + 1] * inv);
-        pk.y = pack_bf16x2(o[4 * g + 2] * inv, o[4 * g + 3] * inv);
-        *reinterpret_cast<uint2*>(orow + 8 * g + 4 * (lane >> 5)) = pk;
-      }
-      if (lane < 32) lse[((long)b * H + h) * T + q] = m_run * LN2 + __logf(l_tot);
-    }
-  }
-  if (DROP && MASK)   // scalar stores sit in the scalar data cache until written back
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_dcache_wb\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
-}
-
-
-template <bool DROP, bool MASK>
-__global__ __launch_bounds__(384, 3) void attn_dq_hr_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
-                                                           const float* __restrict__ kbias, const int* __restrict__ kstart,
-                                                           const float* __restrict__ lse, const bf16_t* __restrict__ outp,
-                                                           float* __restrict__ Dout, bf16_t* __restrict__ dqkv, int B, int T,
-                                                           int H, float scale, uint32_t drop_thr, uint32_t drop_key,
-                                                           float drop_scale, const uint32_t* __restrict__ dmask) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  if (DROP) drop_key += neko_drop_salt();
-  const int Tp = (T + 31) & ~31, nblk = Tp >> 5;
-  char* imgK = smem;
-  float* ldsKb = reinterpret_cast<float*>(smem + Tp * 64);
-  int* queue = reinterpret_cast<int*>(ldsKb + Tp);
-
-  const int tid = threadIdx.x, lane = tid & 63, nthr = blockDim.x;
-  if (tid == 0) *queue = 0;
-  const int hb = pair_remap(blockIdx.x, B * H);
-  const int b = hb / H, h = hb % H;
-  const int d = H * 32;
-  const long ld = 3L * d;
-  const bf16_t* qbase = qkv + (long)b * T * ld + h * 32;
-  const float* kb = kbias + (long)b * T;
-
-  stage_one(qbase + d, ld, imgK, T, Tp, tid, nthr);
-  const bf16_t* vbase = qbase + 2 * d;
-  for (int i = tid; i < Tp; i += nthr) ldsKb[i] = (i < T) ? kb[i] * LOG2E : 0.f;
-  const int kb_first = kstart ? (kstart[b] >> 5) : 0;
-  __syncthreads();
-  const uint32_t padmask = pad_mask_of(ldsKb, Tp, nblk, lane);     // from the LDS copy (zero beyond T): no second trip to memory
-
-  const float scale2 = scale * LOG2E;
-#pragma unroll 1
-  for (int item = next_item(queue, lane); item < nblk; item = next_item(queue, lane)) {
-    const int qb = block_of_item(item, padmask, nblk);   // heaviest first
-    const int q = qb * 32 + (lane & 31);
-    const bool qvalid = q < T;
-    bf16x8_v qf[2], dof[2];
-    row_frags(qbase + (long)q * ld, qvalid, lane, qf);
-    row_frags(dout + ((long)b * T + q) * d + h * 32, qvalid, lane, dof);
-    const float my_lse = (qvalid ? lse[((long)b * H + h) * T + q] : 0.f) * LOG2E;
-    // D = sum_hd dO.O of the own row (divided by the dropout survivor scale, which is folded out of dS): the lane pair
-    // (l, l^32) holds the two halves of the row -- the separate D pass of the streaming kernels is not needed here
-    bf16x8_v of[2];
-    row_frags(outp + ((long)b * T + q) * d + h * 32, qvalid, lane, of);
-    float my_D = dot8_bf16(__builtin_bit_cast(uint4, dof[0]), __builtin_bit_cast(uint4, of[0])) +
-                 dot8_bf16(__builtin_bit_cast(uint4, dof[1]), __builtin_bit_cast(uint4, of[1]));
-    my_D += __shfl_xor(my_D, 32, 64);
-    if (DROP) my_D *= 1.0f / drop_scale;
-    if (qvalid && lane < 32) Dout[((long)b * H + h) * T + q] = my_D;      // the dK/dV kernel (launched after this one) stages it
-    // a masked query row whose dO is exactly zero (the training case: no loss reaches a padded position) has dP = D = 0,
-    // hence dS = 0 for every key: the keys beyond the diagonal are then needed by no row of the block
-    const bool live_masked = __builtin_amdgcn_ballot_w64(qvalid && ldsKb[q] != 0.f && (frag_nonzero(dof[0]) || frag_nonzero(dof[1]))) != 0;
-    const bool wave_full = ((padmask >> qb) & 1) && live_masked;
-    const int kb_beg = wave_full ? 0 : min(kb_first, qb);
-    const int kb_end = wave_full ? nblk : qb + 1;
-
-    f32x16 dq;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) dq[r] = 0.f;
-
-    // lane masks of the forward's keep decisions for this query block, one sub-tile (16 x 64 bit, scalar loads) ahead
-    const const_u64* mrow = reinterpret_cast<const const_u64*>(reinterpret_cast<uintptr_t>(
-        (DROP && MASK) ? uniform_ptr(dmask + ((long)hb * nblk + qb) * nblk * 32) : nullptr));
-    unsigned long long mcur[16], mnext[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) mcur[r] = (DROP && MASK) ? mrow[kb_beg * 16 + r] : 0ull;
-
-    bf16x8_v vcur[2], vnext[2];
-    gfrag_rows(vbase, ld, kb_beg * 32, T, lane, vcur);
-#pragma unroll 1
-    for (int kbk = kb_beg; kbk < kb_end; ++kbk) {
-      const int k0 = kbk * 32;
-      gfrag_rows(vbase, ld, min(kbk + 1, kb_end - 1) * 32, T, lane, vnext);    // one key block ahead (unconditional, clamped)
-      f32x16 st, dpt;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { st[r] = 0.f; dpt[r] = 0.f; }
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(imgK, k0, ks, lane), qf[ks], st, 0, 0, 0);
-        dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vcur[ks], dof[ks], dpt, 0, 0, 0);
-      }
-      vcur[0] = vnext[0];
-      vcur[1] = vnext[1];
-      if (DROP && MASK) {       // behind the operand reads of this sub-tile: the loads have a whole sub-tile to land
-        __builtin_amdgcn_sched_barrier(0);
-        const int kn = min(kbk + 1, kb_end - 1);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mnext[r] = mrow[kn * 16 + r];
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      // dS^T = P^T o (keep*dP^T - D/s); zero where the score was REPLACED by the causal constant
-      const uint32_t g0 = ((uint32_t)(b * H + h) * (uint32_t)T + (uint32_t)q) * (uint32_t)((T + 3) >> 2) +
-                          (uint32_t)((k0 + 4 * (lane >> 5)) >> 2);
-      const bool interior = (kbk < qb) && !((padmask >> kbk) & 1) && (k0 + 32 <= T);
-      if (interior) {
-        const float nlse = -my_lse;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const uint32_t w = (DROP && !MASK) ? drop_word(g0 + 2 * j, drop_key) : 0u;
-#pragma unroll
-          for (int e = 0; e < 4; e += 2) {
-            const int r = 4 * j + e;
-            const f32x2_v pv = exp2_fast2(__builtin_elementwise_fma(pk2(st[r], st[r + 1]), (f32x2_v)(scale2), (f32x2_v)(nlse)));
-            float dp0 = dpt[r], dp1 = dpt[r + 1];
-            if (DROP) {
-              dp0 = MASK ? keep_lanes(dp0, mcur[r]) : (drop_byte_keep(w, e, drop_thr) ? dp0 : 0.f);
-              dp1 = MASK ? keep_lanes(dp1, mcur[r + 1]) : (drop_byte_keep(w, e + 1, drop_thr) ? dp1 : 0.f);
-            }
-            const f32x2_v ds = pv * (pk2(dp0, dp1) - (f32x2_v)(my_D));
-            st[r] = ds.x;
-            st[r + 1] = ds.y;
-          }
-        }
-      } else {
-        const int lim_causal = q - k0 - 4 * (lane >> 5);
-        const int lim_len = T - 1 - k0 - 4 * (lane >> 5);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const uint32_t w = (DROP && !MASK) ? drop_word(g0 + 2 * j, drop_key) : 0u;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int r = 4 * j + e;
-            const int c = (r & 3) + 8 * (r >> 2);
-            const bool causal_ok = c <= lim_causal;
-            const float sv = ldsKb[k0 + c + 4 * (lane >> 5)] + (causal_ok ? st[r] * scale2 : MASK_VAL * LOG2E);
-            const float pv = exp2_fast((c <= lim_len) ? sv - my_lse : -INFINITY);      // select, not a branch: 2^-inf = 0
-            float dpe = dpt[r];
-            if (DROP) dpe = MASK ? keep_lanes(dpe, mcur[r]) : (drop_byte_keep(w, e, drop_thr) ? dpe : 0.f);
-            st[r] = causal_ok ? pv * (dpe - my_D) : 0.f;
-          }
-        }
-      }
-      if (DROP && MASK) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mcur[r] = mnext[r];
-      }
-      // dQ^T += K^T . dS^T
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2)
-        dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(imgK, k0, s2, lane), frag_from_acc(st, s2), dq, 0, 0, 0);
-    }
-
-    // dS was formed as P o (keep*dP - D/s): the dropout survivor scale s multiplies the result once, here
-    const float qs = scale * (DROP ? drop_scale : 1.0f);
-    if (qvalid) {
-      bf16_t* orow = dqkv + ((long)b * T + q) * ld + h * 32;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        uint2 pk;
-        pk.x = pack_bf16x2(dq[4 * g + 0] * qs, dq[4 * g + 1] * qs);
-        pk.y = pack_bf16x2(dq[4 * g + 2] * qs, dq[4 * g + 3] * qs);
-        *reinterpret_cast<uint2*>(orow + 8 * g + 4 * (lane >> 5)) = pk;
-      }
-    }
-  }
-}
-
-
-// the half-resident kernels pay when the both-images footprint leaves room for only ONE workgroup per CU (Tp * 132 B > 80 KB);
-// NEKO_ATTN_HR=0 / 1 forces the choice (A/B runs)
-bool use_half_resident(int Tp) {
-  static const int v = [] { const char* e = getenv("NEKO_ATTN_HR"); return e ? atoi(e) : -1; }();
-  if (v >= 0) return v != 0;
-  return (size_t)Tp * 132 + 16 > 80 * 1024;
-}
-
 template <typename K>
 int allow_lds(K kernel, size_t bytes) {
   return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) ==
@@ -1219,24 +842,6 @@ int neko_attn_fwd_res_impl(const bf16_t* qkv, const float* kbias, const int* kst
   const int Tp = (T + 31) & ~31, nblk = Tp / 32, nw = min(16, (nblk + 1) / 2);
   const size_t lds = (size_t)Tp * 128 + (size_t)Tp * 4 + 16;
   const float scale = 1.0f / sqrtf(32.0f);
-  if (use_half_resident(Tp)) {
-    const int nwh = min(8, (nblk + 1) / 2);
-    const size_t ldsh = (size_t)Tp * 64 + (size_t)Tp * 4 + 16;
-    static const int once_h = allow_lds(attn_fwd_hr_kernel<true, true>, 80 * 1024) | allow_lds(attn_fwd_hr_kernel<true, false>, 80 * 1024) |
-                              allow_lds(attn_fwd_hr_kernel<false, false>, 80 * 1024);
-    if (once_h != NEKO_OK) return once_h;
-    if (drop_thr && dmask)
-      hipLaunchKernelGGL((attn_fwd_hr_kernel<true, true>), dim3(B * H), dim3(64 * nwh), ldsh, s, qkv, kbias, kstart, out, lse, B, T,
-                         H, scale, (uint32_t)drop_thr, drop_key, drop_scale, dmask);
-    else if (drop_thr)
-      hipLaunchKernelGGL((attn_fwd_hr_kernel<true, false>), dim3(B * H), dim3(64 * nwh), ldsh, s, qkv, kbias, kstart, out, lse, B, T,
-                         H, scale, (uint32_t)drop_thr, drop_key, drop_scale, nullptr);
-    else
-      hipLaunchKernelGGL((attn_fwd_hr_kernel<false, false>), dim3(B * H), dim3(64 * nwh), ldsh, s, qkv, kbias, kstart, out, lse, B, T,
-                         H, scale, 0u, drop_key, drop_scale, nullptr);
-    NEKO_CHECK_LAUNCH();
-    return NEKO_OK;
-  }
   static const int once = allow_lds(attn_fwd_res_kernel<true, true>, 160 * 1024) | allow_lds(attn_fwd_res_kernel<true, false>, 160 * 1024) |
                           allow_lds(attn_fwd_res_kernel<false, false>, 160 * 1024);
   if (once != NEKO_OK) return once;
@@ -1266,18 +871,8 @@ int neko_attn_bwd_res_impl(const bf16_t* qkv, const bf16_t* out, const bf16_t* d
                           allow_lds(attn_dq_res_kernel<false, false>, 160 * 1024) | allow_lds(attn_dkv_res_kernel<true, true>, 160 * 1024) |
                           allow_lds(attn_dkv_res_kernel<true, false>, 160 * 1024) | allow_lds(attn_dkv_res_kernel<false, false>, 160 * 1024);
   if (once != NEKO_OK) return once;
-  const bool half_dq = use_half_resident(Tp);
-  const int nwh = min(6, (nblk + 1) / 2);
-  const size_t lds_qh = (size_t)Tp * 64 + (size_t)Tp * 4 + 16;
-  static const int once_h = allow_lds(attn_dq_hr_kernel<true, true>, 80 * 1024) | allow_lds(attn_dq_hr_kernel<true, false>, 80 * 1024) |
-                            allow_lds(attn_dq_hr_kernel<false, false>, 80 * 1024);
-  if (once_h != NEKO_OK) return once_h;
 #define NEKO_BWD_RES(DROPV, MASKV, THR, MP)                                                                                       \
   do {                                                                                                                            \
-    if (half_dq)                                                                                                                  \
-      hipLaunchKernelGGL((attn_dq_hr_kernel<DROPV, MASKV>), dim3(B * H), dim3(64 * nwh), lds_qh, s, qkv, dout, kbias, kstart,    \
-                         lse, out, D, dqkv, B, T, H, scale, (uint32_t)(THR), drop_key, drop_scale, MP);                           \
-    else                                                                                                                          \
     hipLaunchKernelGGL((attn_dq_res_kernel<DROPV, MASKV>), dim3(B * H), dim3(64 * nw), lds_q, s, qkv, dout, kbias, kstart, lse,  \
                        out, D, dqkv, B, T, H, scale, (uint32_t)(THR), drop_key, drop_scale, MP);                                 \
     NEKO_CHECK_LAUNCH();                                                                                                          \

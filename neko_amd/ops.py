@@ -193,10 +193,11 @@ def attn_set_path(mode: int) -> int:
     return int(_lib.load().neko_attn_set_path(int(mode)))
 
 
-def attn_fwd(qkv, kbias, kstart, B, T, H, hd, drop=None, out=None, want_mask=False):
+def attn_fwd(qkv, kbias, kstart, B, T, H, hd, drop=None, out=None, want_mask=False, mask_buf=None):
     """out (optional): a contiguous [B*T, H*hd] bf16 row range to write into (ragged groups share one buffer).
     want_mask: with dropout on, also return the keep-mask buffer the backward of this call can reuse (int32 tensor, or
-    None when the schedule in use does not exchange masks): (out, lse, mask) instead of (out, lse)."""
+    None when the schedule in use does not exchange masks): (out, lse, mask) instead of (out, lse).
+    mask_buf (optional, tests): a caller-provided int32 buffer of neko_attn_mask_dwords elements to use as that mask buffer."""
     _chk(qkv, BF16, "qkv")
     assert qkv.is_contiguous() and qkv.shape[0] == B * T
     if out is None:
@@ -208,7 +209,9 @@ def attn_fwd(qkv, kbias, kstart, B, T, H, hd, drop=None, out=None, want_mask=Fal
     if want_mask and drop is not None and drop.thr > 0:
         n = int(_lib.load().neko_attn_mask_dwords(B, T, H, hd))
         if n > 0:
-            mask = torch.empty(n, dtype=torch.int32, device=qkv.device)
+            if mask_buf is not None:
+                _chk(mask_buf, torch.int32, "mask_buf"); assert mask_buf.numel() == n
+            mask = mask_buf if mask_buf is not None else torch.empty(n, dtype=torch.int32, device=qkv.device)
     _lib.call("neko_attn_fwd", _p(qkv), _p(kbias), _p(kstart), _p(out), _p(lse), B, T, H, hd, *_drop(drop), _p(mask), _stream())
     return (out, lse, mask) if want_mask else (out, lse)
 

@@ -45,7 +45,15 @@ def _make():
     return m
 
 
-def _worker(rank, world, port, out):
+def _batches_rank1_without_loss():
+    """Rank 1's batch is a single image-only example: no position of it is a target (gato_policy.py:176-183 selects
+    nothing), its loss is 0 and its gradients are zero -- but it must issue exactly the collectives rank 0 issues."""
+    g = torch.Generator().manual_seed(9)
+    b1 = [{"images": torch.floor(torch.rand(1, 3, 32, 32, generator=g) * 256)}]
+    return _batches()[0], b1
+
+
+def _worker(rank, world, port, out, batches_fn=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -61,7 +69,7 @@ def _worker(rank, world, port, out):
         dp = GradReducer(m._flat, bucket_bytes=32 * 1024)
         dp.broadcast_parameters()
         dp.attach(m, opt)
-        batch = _to_dev(_batches()[rank])
+        batch = _to_dev((batches_fn or _batches)()[rank])
         for _ in range(2):
             _, loss = m.forward(inputs=batch, compute_loss=True, return_logits=False)
             loss.backward()
@@ -77,13 +85,16 @@ def _worker(rank, world, port, out):
         dist.destroy_process_group()
 
 
-def test_dp_two_ranks_match_single_process_average():
+@pytest.mark.parametrize("batches_fn", [_batches, _batches_rank1_without_loss], ids=["both-ranks-have-targets", "rank1-has-no-loss-position"])
+def test_dp_two_ranks_match_single_process_average(batches_fn):
+    """Second case: a rank whose batch has no loss position still runs the whole backward (zero
+    dlogits) and therefore issues the same per-range collectives in the same order; a mismatch would hang this test."""
     from neko_amd.training.optim import NekoAdamW
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     with ctx.Manager() as mgr:
         out = mgr.dict()
-        procs = [ctx.Process(target=_worker, args=(r, world, port, out)) for r in range(world)]
+        procs = [ctx.Process(target=_worker, args=(r, world, port, out, batches_fn)) for r in range(world)]
         for p in procs:
             p.start()
         for p in procs:
@@ -97,7 +108,7 @@ def test_dp_two_ranks_match_single_process_average():
     m = _make()
     opt = NekoAdamW(m, lr=1e-2, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.1)
     opt.grad_scale = torch.full((1,), 0.5, device="cuda")
-    b0, b1 = (_to_dev(b) for b in _batches())
+    b0, b1 = (_to_dev(b) for b in batches_fn())
     for _ in range(2):
         for b in (b0, b1):
             _, loss = m.forward(inputs=b, compute_loss=True, return_logits=False)

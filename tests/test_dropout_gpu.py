@@ -252,3 +252,33 @@ def test_policy_with_dropout_at_the_metric_sequence_length_vs_oracle():
             continue
         assert abs(gn - rn) < 2e-2 * rn + 1e-7, (k, gn, rn)
     assert abs(math.sqrt(sq) - math.sqrt(sq_ref)) < 5e-3 * math.sqrt(sq_ref)
+
+
+def test_backward_does_not_depend_on_mask_words_the_forward_never_wrote():
+    """with left padding the forward starts a query block's key loop at the first block that holds a real key,
+    so the keep-mask words of (query block, all-padding key block) pairs are never written, while the dK/dV kernel walks
+    those pairs and loads them.  They only ever meet probabilities that are exactly zero (padded keys), so the gradients
+    must be BIT-identical whatever those words hold: the same forward into a zero-filled and into a 0xFF-poisoned buffer."""
+    from neko_amd import _lib, ops
+    B, T, H, hd = 3, 1024, 2, 32
+    d = H * hd
+    g = torch.Generator(device="cuda").manual_seed(9)
+    qkv = torch.randn(B * T, 3 * d, device="cuda", generator=g).to(torch.bfloat16)
+    do = torch.randn(B * T, d, device="cuda", generator=g).to(torch.bfloat16)
+    mask = torch.ones(B, T, device="cuda")
+    mask[0, :100] = 0            # three all-padding key blocks in front of sequence 0
+    mask[1, :40] = 0             # one
+    do = (do.view(B, T, d) * mask[:, :, None].to(torch.bfloat16)).view(B * T, d).contiguous()
+    kb, ks = ops.mask_bias(mask)
+    drop = ops.Drop(0.1, 0xBEEF)
+    n = int(_lib.load().neko_attn_mask_dwords(B, T, H, hd))
+    assert n > 0
+    res = []
+    for fill in (0, -1):
+        buf = torch.full((n,), fill, dtype=torch.int32, device="cuda")
+        out, lse, mk = ops.attn_fwd(qkv, kb, ks, B, T, H, hd, drop=drop, want_mask=True, mask_buf=buf)
+        res.append((out.clone(), ops.attn_bwd(qkv, out, do, kb, ks, lse, B, T, H, hd, drop=drop, mask=mk).clone()))
+    assert torch.equal(res[0][0], res[1][0])
+    assert torch.equal(res[0][1], res[1][1])
+    ref = ops.attn_bwd(qkv, res[0][0], do, kb, ks, lse, B, T, H, hd, drop=drop, mask=None)       # re-hashing kernels
+    assert torch.equal(ref, res[0][1])

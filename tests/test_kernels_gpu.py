@@ -342,6 +342,47 @@ def test_attention_fwd_bwd(ops, attn_path, B, T, H, hd, mask_kind):
     close(dqkv.view(B, T, 3 * d), leaf.grad, 2 ** -6, 1e-2 * gs, "attn dqkv")
 
 
+@pytest.mark.parametrize("drop_p", [0.0, 0.1])
+def test_attention_fwd_lazy_reference_survives_a_score_spike(ops, drop_p):
+    """The head-resident forward takes its exponentials against a LAZILY moved reference (no row maximum per sub-tile): a
+    row whose later scores climb far above everything seen before must trigger the rescale, not overflow.  One late key is
+    made huge against the late queries: raw q.k = 512 -> 130 in log2 units above the early scores (2^130 is inf in fp32).
+    Out, lse and the backward (which consumes lse) against the oracle (cdna_hip_programming.md rule 26: a rare
+    data-dependent branch needs an input that forces it)."""
+    B, T, H, hd = 2, 160, 2, 32
+    d = H * hd
+    g = torch.Generator().manual_seed(77)
+    qkv = rb(torch.randn(B, T, 3 * d, generator=g) * 0.5)
+    qkv[:, 100:, 0:hd] = 4.0                 # queries 100.. of head 0
+    qkv[:, 100, d:d + hd] = 4.0              # key 100 of head 0
+    mask = torch.ones(B, T)
+    do = rb(torch.randn(B, T, d, generator=g))
+    leaf = qkv.clone().requires_grad_(True)
+    q, k, v = leaf.split(d, dim=2)
+    sh = lambda t: t.view(B, T, H, hd).permute(0, 2, 1, 3)
+    o_ref = O.attention_core(sh(q), sh(k), sh(v), mask).permute(0, 2, 1, 3).reshape(B, T, d)
+    kb, ks = ops.mask_bias(mask.to(DEV))
+    qkv_d = bf(qkv.view(B * T, 3 * d))
+    if drop_p == 0.0:
+        o_ref.backward(do)
+        out, lse = ops.attn_fwd(qkv_d, kb, ks, B, T, H, hd)
+        assert bool(torch.isfinite(out.float()).all()) and bool(torch.isfinite(lse).all())
+        close(out.view(B, T, d), o_ref, 2 ** -7, 4e-3 * float(o_ref.abs().max()), "attn out (spike)")
+        dqkv = ops.attn_bwd(qkv_d, out, bf(do.view(B * T, d)), kb, ks, lse, B, T, H, hd)
+        close(dqkv.view(B, T, 3 * d), leaf.grad, 2 ** -6, 1e-2 * float(leaf.grad.abs().max()), "attn dqkv (spike)")
+    else:      # with dropout: finite, and identical to the streaming schedule's result up to bf16 rounding
+        drop = ops.Drop(drop_p, 0x13579B)
+        out, lse = ops.attn_fwd(qkv_d, kb, ks, B, T, H, hd, drop=drop)
+        prev = ops.attn_set_path(1)
+        try:
+            out_s, lse_s = ops.attn_fwd(qkv_d, kb, ks, B, T, H, hd, drop=drop)
+        finally:
+            ops.attn_set_path(prev)
+        assert bool(torch.isfinite(out.float()).all())
+        assert float((out.float() - out_s.float()).abs().max()) < 2 ** -6 * float(out_s.float().abs().max())
+        assert float((lse - lse_s).abs().max()) < 1e-3 * float(lse_s.abs().max())
+
+
 @pytest.mark.parametrize("B,T,H", [(3, 200, 2), (2, 1024, 2), (5, 97, 3)])
 def test_attention_bwd_zero_grad_on_masked_rows(ops, B, T, H):
     """Training case: dO is exactly zero on padded query rows.  The head-resident backward then skips the keys beyond the

@@ -24,7 +24,7 @@ bash tools/pmc_step.sh $tag > gpurun_out/${tag}_pmc_step.log 2>&1
 bash tools/pmc_lmhead.sh > gpurun_out/${tag}_pmc_lmhead.log 2>&1
 python3 tools/pmc_lmhead_summarise.py $tag > /dev/null 2>> gpurun_out/${tag}_pmc_lmhead.log
 rm -rf gpurun_out/pmcL1 gpurun_out/pmcL2
-bash tools/pmc_gemm.sh > gpurun_out/${tag}_gemm_counters_raw.txt 2>&1
+bash tools/pmc_gemm.sh > gpurun_out/${tag}_gemm_counters.txt 2>&1
 rm -rf gpurun_out/pmcG_*
 bash tools/pmc_attn.sh $tag 0.1 > /dev/null 2>&1
 python3 tools/gemm_bench.py --iters 30 > gpurun_out/${tag}_gemm_bench.txt 2>&1
