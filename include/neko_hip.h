@@ -71,6 +71,13 @@ int neko_gemm_bf16(const uint16_t* A, long lda, int a_kstrided, const uint16_t* 
                    int accumulate, uint16_t* Cb, long ldcb, int splitk, int k_per_split, float* splitk_ws,
                    int drop_thr, unsigned drop_key, float drop_scale, int safe_transpose, void* stream);
 
+/* neko_gemm_bf16 has a second schedule for bf16-output launches whose tiles are all interior 256 x 256 ones (A k-contiguous,
+ * K >= 608, at least two rounds of tiles): a persistent kernel that streams k-tiles across tile boundaries and drains half of
+ * each tile's epilogue under the next tile's k-loop (neko_amd/csrc/gemm_pers.hip).  It measured level with the default tiles
+ * on the step's shapes and is OFF unless the environment says NEKO_GEMM_PERS=1; neko_gemm_set_persistent(1 / 0) forces it on /
+ * off for the process, (-1) returns to the environment's choice; returns the previous mode (-1, 0, 1).  (ABI v14) */
+int neko_gemm_set_persistent(int mode);
+
 /* Backward of the MLP's first Linear + GELU in one launch (trajectory_gpt2.py:266,274: h = act(c_fc(x)); autograd's
  * d_pre = (d_h . W_proj^T) * gelu'(pre) and the c_fc bias gradient sum_rows d_pre):
  *   Cb[M,N] bf16 = (dY[M,K] . W[N,K]^T) * gelu'(act_in[M,N]);   colsum_out[N] (f32) += column sums of that product.

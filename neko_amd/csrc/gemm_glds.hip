@@ -879,6 +879,7 @@ using C256x128 = Cfg<2, 2, 4, 2, 3>;
 using C256x256 = Cfg<2, 4, 4, 2, 4>;
 using C256x256w4 = Cfg<2, 2, 4, 4, 4>;     // 4 waves x (128 x 128), one wave per SIMD, 256 accumulator AGPRs (the vendor kernel's geometry)
 
+
 thread_local int t_colsum_bands = 0;
 
 template <bool A_KC, bool B_KC, class C>
@@ -1001,6 +1002,10 @@ int neko_gemm_glds_try(const GemmArgs& a, int a_kstrided, int b_kstrided, hipStr
   if (a.bias && (reinterpret_cast<uintptr_t>(a.bias) & 15)) return 1;
   if (a.act_in && ((reinterpret_cast<uintptr_t>(a.act_in) & 7) || (a.ldact & 3))) return 1;
   if (a.pre_out && ((reinterpret_cast<uintptr_t>(a.pre_out) & 7) || (a.ldpre & 3))) return 1;
+  if (!a_kstrided) {        // persistent 256 x 192 kernel with the deferred epilogue (gemm_pers.hip), where it applies
+    const int rc = neko_gemm_pers_try(a, b_kstrided, s);
+    if (rc != 1) return rc;
+  }
   if (a_kstrided && b_kstrided) return launch<false, false>(a, s);
   if (a_kstrided) return launch<false, true>(a, s);
   if (b_kstrided) return launch<true, false>(a, s);

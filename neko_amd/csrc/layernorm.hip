@@ -286,11 +286,22 @@ int neko_layernorm_fwd_impl(const float* x, const float* gamma, const float* bet
   return fwd_launch<16>(x, gamma, beta, y16, y32, mean, rstd, M, d, eps, s);
 }
 
-// number of partial rows the backward writes for a given M (workspace = nblk*3*d floats)
-int neko_layernorm_bwd_blocks_impl(int M) {
-  static const int cap = [] { const char* e = getenv("NEKO_LN_BWD_BLOCKS"); return e ? atoi(e) : 256; }();   // one block per CU measured best (tools/ln_bench.py: 88 us vs 99 at 512)
-  int nb = (M + 3) / 4;
+// number of partial rows the backward may write for a given M (workspace = that many x 3 x d floats): the larger of the two
+// variants' block counts
+static int ln_bwd_cap(int dy16) {
+  // one block per CU measured best with fp32 dy (tools/ln_bench.py: 88 us vs 99 at 512 blocks, 32768 rows); the bf16-dy variant has
+  // 8-byte loads on that operand, fewer bytes in flight per wave, and wants two blocks per CU (65536 rows: 220 us at 256 blocks,
+  // 157 us at 512; fp32 dy: 163 / 173)
+  static const int env = [] { const char* e = getenv("NEKO_LN_BWD_BLOCKS"); return e ? atoi(e) : 0; }();
+  return env > 0 ? env : (dy16 ? 512 : 256);
+}
+static int ln_bwd_blocks(int M, int dy16) {
+  const int cap = ln_bwd_cap(dy16), nb = (M + 3) / 4;
   return nb < cap ? (nb < 1 ? 1 : nb) : cap;
+}
+int neko_layernorm_bwd_blocks_impl(int M) {
+  const int a = ln_bwd_blocks(M, 0), b = ln_bwd_blocks(M, 1);
+  return a > b ? a : b;
 }
 
 int neko_layernorm_bwd_impl(const void* dy, int dy16, const float* x, const float* gamma, const float* mean,
@@ -302,7 +313,7 @@ int neko_layernorm_bwd_impl(const void* dy, int dy16, const float* x, const floa
   if (dcolsum16 && !dx16) return NEKO_ERR_ARG;
   const int wc = dcolsum16 ? 1 : 0;
   if ((d & 3) || d > 256 * LN_MAXV) return NEKO_ERR_UNSUPPORTED;
-  const int nblk = neko_layernorm_bwd_blocks_impl(M);
+  const int nblk = ln_bwd_blocks(M, dy16);
   const int nv = (d / 4 + 63) / 64;
   int rc;
   if (nv <= 1) rc = bwd_launch<1>(dy, dy16, x, gamma, mean, rstd, g_in, dx, dx16, workspace, nblk, M, d, drop_thr, drop_key, drop_scale, wc, s);

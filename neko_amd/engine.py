@@ -98,18 +98,14 @@ class StackCtx:
     rstdf: torch.Tensor = None
 
 
-#: dtype of the gradients that the dgrad GEMMs hand to the LayerNorm backward.  bf16 (NEKO_LN_DY_BF16=1) is what autocast
-#: leaves there in the reference and halves those bytes, but measured 0.2 ms per m-mix step SLOWER than fp32 on the same
-#: box (23.17 vs 22.96 ms: the 8-byte-per-lane bf16 epilogue stores of the N = 768 dgrads cost more than the LayerNorm
-#: backward saves), so fp32 stays the default; both paths are covered by the LayerNorm parity test.
-LN_DY_DTYPE = BF16 if os.environ.get("NEKO_LN_DY_BF16", "0") == "1" else F32
-
-#: The forward c_fc GEMM can leave gelu'(pre) (bf16) instead of the pre-activation in its second output (epilogue act 3:
-#: both values come out of ONE evaluation of the erf series), so that the dgrad through the MLP projection multiplies by a
-#: stored factor (act 4) instead of evaluating the series again for 65536 x 3072 elements per layer: its GELU' epilogue
-#: cost 11.6 us of every 30 us tile.  The factor is rounded to bf16 (2^-9 relative, unbiased) before the
-#: product is; gated MLPs (GEGLU) keep the pre-activation, their backward needs gelu(pre) as well.  NEKO_GELU_FACTOR=0: off.
-GELU_FACTOR = os.environ.get("NEKO_GELU_FACTOR", "1") != "0"
+#: dtype of the gradients that the dgrad GEMMs hand to the LayerNorm backward.  bf16 is what autocast leaves there in the reference
+#: (the gradient of a bf16 addmm input is bf16) and 100 MB less out of each N = 768 dgrad and into each LayerNorm backward at
+#: 65536 rows.  Round 1 measured it 0.2 ms per step SLOWER and kept fp32; the reason turned out to be the LayerNorm backward's
+#: launch shape, not the bytes: with 8-byte loads on that operand a wave has fewer bytes in flight and the kernel wants two blocks
+#: per CU (220 -> 157 us per call at 65536 rows, fp32 dy: 163; tools/ln_bench.py).  With that, bf16 is 0.18 ms per m-mix step
+#: faster (39.58 -> 39.40, profiles/r03_step_ab.txt) and the default; NEKO_LN_DY_BF16=0 returns to fp32.  Both paths are covered
+#: by the LayerNorm parity test.
+LN_DY_DTYPE = F32 if os.environ.get("NEKO_LN_DY_BF16", "1") == "0" else BF16
 
 
 def _dgrad_to_ln(a, w, M, N, K, ldb):

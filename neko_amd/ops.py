@@ -187,6 +187,12 @@ def mask_bias(mask: torch.Tensor):
     return kb, ks
 
 
+def gemm_set_persistent(mode: int) -> int:
+    """1 / 0: force the persistent deferred-epilogue GEMM schedule on / off where it applies, -1: the environment's choice
+    (NEKO_GEMM_PERS, default off); returns the previous mode (neko_gemm_set_persistent)."""
+    return int(_lib.load().neko_gemm_set_persistent(int(mode)))
+
+
 def attn_set_path(mode: int) -> int:
     """0 = automatic (head-resident kernels when hd = 32 and T <= 1024), 1 = always the streaming kernels; returns the
     previous mode (neko_attn_set_path)."""

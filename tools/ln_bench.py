@@ -20,3 +20,7 @@ def t(fn, name, nbytes):
     print(f"{name}: {us:7.1f} us  {nbytes / us / 1e6:5.2f} TB/s")
 t(lambda: ops.layernorm_fwd(x, w, b, y16=y16, mean=mean, rstd=rstd), "ln fwd", M * d * 6)
 t(lambda: ops.layernorm_bwd(dy, x, w, mean, rstd, dg, db, g_in=gin, dx=dx, dx16=dx16), "ln bwd", M * d * 18)
+dy16 = dy.to(torch.bfloat16)
+t(lambda: ops.layernorm_bwd(dy16, x, w, mean, rstd, dg, db, g_in=gin, dx=dx, dx16=dx16), "ln bwd (bf16 dy)", M * d * 16)
+cs = torch.zeros(d, device=dev)
+t(lambda: ops.layernorm_bwd(dy16, x, w, mean, rstd, dg, db, g_in=gin, dx=dx, dx16=dx16, colsum16=cs), "ln bwd (bf16 dy, + column sums)", M * d * 16)
