@@ -107,6 +107,14 @@ class StackCtx:
 #: by the LayerNorm parity test.
 LN_DY_DTYPE = F32 if os.environ.get("NEKO_LN_DY_BF16", "1") == "0" else BF16
 
+#: The forward c_fc GEMM can leave gelu'(pre) (bf16) instead of the pre-activation in its second output (epilogue act 3:
+#: both values come out of ONE evaluation of the erf series), so that the dgrad through the MLP projection multiplies by a
+#: stored factor (act 4) instead of evaluating the series again for 65536 x 3072 elements per layer: its GELU' epilogue
+#: cost 11.6 us of every 30 us tile.  The factor is rounded to bf16 (2^-9 relative, unbiased) before the
+#: product is; gated MLPs (GEGLU) keep the pre-activation, their backward needs gelu(pre) as well.  NEKO_GELU_FACTOR=0: off.
+#: Measured -0.35 ms per m-mix step (profiles/r03_step_ab.txt).
+GELU_FACTOR = os.environ.get("NEKO_GELU_FACTOR", "1") != "0"
+
 
 def _dgrad_to_ln(a, w, M, N, K, ldb):
     out = torch.empty(M, N, dtype=LN_DY_DTYPE, device=a.device)

@@ -70,7 +70,7 @@ def _worker(rank, world, port, out, batches_fn=None):
         dp.broadcast_parameters()
         dp.attach(m, opt)
         batch = _to_dev((batches_fn or _batches)()[rank])
-        for _ in range(2):
+        for it in range(2):
             _, loss = m.forward(inputs=batch, compute_loss=True, return_logits=False)
             loss.backward()
             dp.flush()
@@ -78,6 +78,11 @@ def _worker(rank, world, port, out, batches_fn=None):
             gn = opt.clip_grad_norm_(0.5)
             opt.step()
             opt.zero_grad()
+            if it == 0:          # what the single-process reference is compared with (see the test)
+                torch.cuda.synchronize()
+                out[f"first{rank}"] = {k: v.detach().cpu() for k, v in m.state_dict().items()
+                                       if v.dtype == torch.float32 and v.numel() < 70000}
+                out[f"gn_first{rank}"] = float(gn)
         torch.cuda.synchronize()
         out[rank] = {k: v.detach().cpu() for k, v in m.state_dict().items() if v.dtype == torch.float32 and v.numel() < 70000}
         out[f"gn{rank}"] = float(gn)
@@ -101,25 +106,34 @@ def test_dp_two_ranks_match_single_process_average(batches_fn):
             p.join(timeout=600)
             assert p.exitcode == 0, f"worker exit code {p.exitcode}"
         r0, r1, gn0, gn1 = out[0], out[1], out["gn0"], out["gn1"]
-    for k in r0:
+        f0, gnf0 = out["first0"], out["gn_first0"]
+    for k in r0:                              # after two steps the ranks hold the very same bits
         assert torch.equal(r0[k], r1[k]), f"ranks diverged on {k}"
     assert gn0 == gn1
-    # single-process reference: the two batches one after the other, gradients averaged with equal weight per rank
+    # single-process reference: the two batches one after the other, gradients averaged with equal weight per rank.  Compared
+    # after ONE step: the first Adam update is lr * g / |g| per element, so an element whose gradient is rounding noise around
+    # zero moves by +-lr with a sign that depends on the summation order (gradient accumulation here, all-reduce there) -- from
+    # the second step on the two runs are different trajectories at the 1e-4 level (tools/determinism_probe.py).
     m = _make()
     opt = NekoAdamW(m, lr=1e-2, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.1)
     opt.grad_scale = torch.full((1,), 0.5, device="cuda")
     b0, b1 = (_to_dev(b) for b in batches_fn())
-    for _ in range(2):
-        for b in (b0, b1):
-            _, loss = m.forward(inputs=b, compute_loss=True, return_logits=False)
-            loss.backward()                  # accumulates into the flat gradient
-        gn = opt.clip_grad_norm_(0.5)
-        opt.step()
-        opt.zero_grad()
+    for b in (b0, b1):
+        _, loss = m.forward(inputs=b, compute_loss=True, return_logits=False)
+        loss.backward()                      # accumulates into the flat gradient
+    gn = opt.clip_grad_norm_(0.5)
+    opt.step()
+    opt.zero_grad()
     ref = {k: v.detach().cpu() for k, v in m.state_dict().items()}
-    assert abs(float(gn) - gn0) < 1e-4 * gn0
-    for k, v in r0.items():
-        assert torch.allclose(v, ref[k], rtol=2e-4, atol=2e-6), (k, float((v - ref[k]).abs().max()))
+    assert abs(float(gn) - gnf0) < 1e-5 * gnf0, (float(gn), gnf0)
+    bad = 0
+    for k, v in f0.items():
+        close_ = torch.isclose(v, ref[k], rtol=2e-4, atol=2e-6)
+        # the +-lr sign flips of noise-level gradient elements: a handful of entries may differ by up to 2 lr
+        assert float((v - ref[k]).abs().max()) <= 2.1e-2, (k, float((v - ref[k]).abs().max()))
+        bad += int((~close_).sum())
+    total = sum(v.numel() for v in f0.values())
+    assert bad <= 2e-3 * total, (bad, total)
 
 
 def _rccl_worker(port, out):

@@ -190,12 +190,13 @@ def test_training_trace_100_steps_on_the_metric_model_vs_oracle():
     opt = NekoAdamW(m, lr=lr, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.1)
     sch = get_linear_warmup_cosine_decay_scheduler(opt, warm, steps, base_lr=lr, init_lr=init_lr, min_lr=min_lr)
     g = torch.Generator().manual_seed(41)
-    batches = [[_control(17, 6, 10, g) for _ in range(4)] for _ in range(3)]
+    NB = 25
+    batches = [[_control(17, 6, 10, g) for _ in range(4)] for _ in range(NB)]
     dev_batches = [_dev_batch(b) for b in batches]
     losses, norms, lrs = [], [], []
     for step in range(steps):
         lrs.append(float(sch.get_last_lr()[0]))
-        _, loss = m.forward(inputs=dev_batches[step % 3], compute_loss=True, return_logits=False)
+        _, loss = m.forward(inputs=dev_batches[step % NB], compute_loss=True, return_logits=False)
         loss.backward()
         norms.append(opt.clip_grad_norm_(1.0))
         opt.step()
@@ -210,13 +211,14 @@ def test_training_trace_100_steps_on_the_metric_model_vs_oracle():
     for step in range(steps):
         lr_t = lr * O.lr_ratio(step, warm, steps, lr, init_lr, min_lr)
         assert abs(lr_t - lrs[step]) <= 1e-12 + 1e-9 * lr_t, (step, lr_t, lrs[step])
-        l, n = O.train_step(sd, cfg, st, batches[step % 3], lr_t, grad_norm_clip=1.0)
+        l, n = O.train_step(sd, cfg, st, batches[step % NB], lr_t, grad_norm_clip=1.0)
         ref_l.append(l)
         ref_n.append(n)
     rel = [abs(a - b) / abs(b) for a, b in zip(losses, ref_l)]
     reln = [abs(a - b) / abs(b) for a, b in zip(norms, ref_n)]
     print(f"[trace 768d x 6L V=52305] loss {losses[0]:.4f} -> {losses[-1]:.4f} (oracle {ref_l[0]:.4f} -> {ref_l[-1]:.4f}); "
           f"max rel loss dev {max(rel):.2e} at step {rel.index(max(rel))}; grad norm dev median {sorted(reln)[len(reln) // 2]:.2e} max {max(reln):.2e}")
+    print("   rel loss dev per decade of steps:", [f"{max(rel[i:i + 10]):.1e}" for i in range(0, steps, 10)])
     assert ref_l[-1] < ref_l[0] - 0.5                      # it trains (the loss leaves its random-init plateau)
     assert max(rel) < 1e-3, (max(rel), rel.index(max(rel)))
     assert max(reln[:5]) < 5e-3, reln[:5]
