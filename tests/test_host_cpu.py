@@ -435,3 +435,29 @@ def test_cli_refuses_cpu_and_fp32_modes_and_types_optional_flags():
             parse_args(bad)
         assert "not supported" in str(e.value)
     assert parse_args(["--mixed_precision", "bf16"]).mixed_precision == "bf16"
+
+
+def test_host_stager_rings_are_keyed_by_capacity_and_capped(monkeypatch):
+    """the pinned staging rings must not grow with the number of distinct upload SHAPES (variable-length batches give
+    a new shape on almost every step): one ring per (dtype, power-of-two capacity), uploads are slices of it, and the total of
+    pinned bytes is capped by dropping idle rings.  (No GPU: events and pinning are stubbed.)"""
+    import torch
+    from neko_amd.utils import utils as U
+
+    class _Ev:
+        def record(self): pass
+        def query(self): return True
+        def synchronize(self): pass
+    monkeypatch.setattr(torch.cuda, "Event", _Ev)
+    monkeypatch.setattr(torch.Tensor, "pin_memory", lambda self: self)
+    st = U.HostStager(max_bytes=1 << 20)
+    for n in range(1000, 1100):                       # 100 distinct shapes, one capacity class
+        x = torch.arange(n, dtype=torch.int32)
+        assert torch.equal(st.upload(x, "cpu"), x)
+        y = torch.arange(2 * n, dtype=torch.float32).reshape(2, n)
+        assert torch.equal(st.upload(y, "cpu"), y)
+    assert len(st._slots) <= 4, st._slots.keys()      # 200 distinct shapes -> int32 1024 / 2048 and float32 2048 / 4096
+    assert st._bytes <= 1 << 20
+    big = torch.zeros(200000, dtype=torch.float32)    # 1 MiB class: the idle small rings are dropped to make room
+    assert torch.equal(st.upload(big, "cpu"), big)
+    assert st._bytes <= (1 << 20) + 262144 * 4
