@@ -135,6 +135,23 @@ int neko_layernorm_bwd_bf16dy(const uint16_t* dy, const float* x, const float* g
  *   every element in both of its kernels; with null both directions hash -- identical decisions either way.
  * ------------------------------------------------------------------------------------------- */
 int neko_attn_set_path(int mode);
+
+/* Packed sequences of DIFFERENT lengths in one launch ("varlen": SURVEY 8(f) rank 3; removes the left-pad of
+ * gato/policy/gato_policy.py:408-416 without one attention launch per length bucket).  Rows seq_off[b] .. seq_off[b+1]-1 of qkv /
+ * out / dout / dqkv / kbias are sequence b (seq_off: int32 [nseq + 1], device); kstart [nseq] is relative to its sequence.
+ * lse and D are [rows * H] laid out [sequence][head][position] = seq_off[b] * H + h * T_b + q.  The keep masks of sequence b
+ * start at mask_off[b] dwords (int64 [nseq], device): mask_off[b] = sum over b' < b of H * ceil(T_b' / 32)^2 * 32; the buffer holds
+ * that sum over all sequences.  The dropout hash indexes (unique row id) * ceil(Tmax / 4) + key / 4.  Head-resident kernels only:
+ * hd = 32 and Tmax <= 1024 (neko_attn_varlen_supported), otherwise NEKO_ERR_UNSUPPORTED (callers fall back to one launch per
+ * length bucket).  Arithmetic, masks and dropout semantics are those of neko_attn_fwd / neko_attn_bwd.  (ABI v14) */
+int neko_attn_varlen_supported(int Tmax, int hd);
+int neko_attn_fwd_varlen(const uint16_t* qkv, const float* kbias, const int* kstart, const int* seq_off, const long long* mask_off,
+                         uint16_t* out, float* lse, int nseq, int Tmax, int H, int hd, int drop_thr, unsigned drop_key,
+                         float drop_scale, uint32_t* drop_mask, void* stream);
+int neko_attn_bwd_varlen(const uint16_t* qkv, const uint16_t* out, const uint16_t* dout, const float* kbias, const int* kstart,
+                         const int* seq_off, const long long* mask_off, const float* lse, float* D, uint16_t* dqkv, int nseq,
+                         int Tmax, int H, int hd, int drop_thr, unsigned drop_key, float drop_scale, const uint32_t* drop_mask,
+                         void* stream);
 int neko_mask_bias(const float* mask, float* kbias, int* kstart, int B, int T, void* stream);
 long neko_attn_mask_dwords(int B, int T, int H, int hd);
 int neko_attn_fwd(const uint16_t* qkv, const float* kbias, const int* kstart, uint16_t* out, float* lse, int B,

@@ -241,31 +241,63 @@ __device__ __forceinline__ uint32_t pad_mask_of(const float* __restrict__ kb, in
   return pad_mask_ballot(v);
 }
 
+// Where a (sequence, head) lives.  Uniform batches: sequence b holds rows [b T, (b+1) T).  Packed ("varlen") batches
+// (gato_policy.py:408-416 is the left-pad this removes): seq_off[b] .. seq_off[b+1] are the rows of sequence b,
+// every sequence with its own length, ONE launch for all of them (length buckets needed one launch per bucket).  Per-(b, h)
+// arrays (lse, D) are laid out [sequence][head][position] = row0 * H + h * T + q in both cases; the keep masks of sequence b
+// start at mask_off[b] dwords; the dropout hash walks unique row ids with the row stride of the LONGEST sequence.
+struct SeqGeom {
+  int T;             // length of this sequence
+  long row0;         // its first row in the [rows, ...] matrices
+  long hrow;         // index of (b, h, position 0) in lse / D and unique row id of the dropout hash
+  long mask0;        // dword offset of (b, h) in the keep-mask buffer
+  uint32_t T4;       // dropout hash: words per row
+};
+__device__ __forceinline__ SeqGeom seq_geom(int b, int h, int H, int T_uniform, const int* __restrict__ seq_off,
+                                            const long long* __restrict__ mask_off, int T4_varlen) {
+  SeqGeom g;
+  if (seq_off) {
+    g.row0 = seq_off[b];
+    g.T = seq_off[b + 1] - (int)g.row0;
+    g.T4 = (uint32_t)T4_varlen;
+  } else {
+    g.row0 = (long)b * T_uniform;
+    g.T = T_uniform;
+    g.T4 = (uint32_t)((T_uniform + 3) >> 2);
+  }
+  g.hrow = g.row0 * H + (long)h * g.T;
+  const long nblk = (g.T + 31) >> 5;
+  g.mask0 = (mask_off ? (long)mask_off[b] : (long)b * H * nblk * nblk * 32) + (long)h * nblk * nblk * 32;
+  return g;
+}
+
 // =====================================================================================================
 // forward
 // =====================================================================================================
 template <bool DROP, bool MASK>
 __global__ __launch_bounds__(1024) void attn_fwd_res_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ kbias,
                                                             const int* __restrict__ kstart, bf16_t* __restrict__ out,
-                                                            float* __restrict__ lse, int B, int T, int H, float scale,
+                                                            float* __restrict__ lse, int B, int T_uniform, int H, float scale,
                                                             uint32_t drop_thr, uint32_t drop_key, float drop_scale,
-                                                            uint32_t* __restrict__ dmask) {
+                                                            uint32_t* __restrict__ dmask, const int* __restrict__ seq_off,
+                                                            const long long* __restrict__ mask_off, int T4_varlen) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if (DROP) drop_key += neko_drop_salt();
+  const int tid = threadIdx.x, lane = tid & 63, nthr = blockDim.x;
+  const int hb = pair_remap(blockIdx.x, B * H);
+  const int b = hb / H, h = hb % H;
+  const SeqGeom sg = seq_geom(b, h, H, T_uniform, seq_off, mask_off, T4_varlen);
+  const int T = sg.T;
   const int Tp = (T + 31) & ~31, nblk = Tp >> 5;
   char* imgK = smem;
   char* imgV = smem + Tp * 64;
   float* ldsKb = reinterpret_cast<float*>(smem + Tp * 128);
   int* queue = reinterpret_cast<int*>(ldsKb + Tp);
-
-  const int tid = threadIdx.x, lane = tid & 63, nthr = blockDim.x;
   if (tid == 0) *queue = 0;
-  const int hb = pair_remap(blockIdx.x, B * H);
-  const int b = hb / H, h = hb % H;
   const int d = H * 32;
   const long ld = 3L * d;
-  const bf16_t* qbase = qkv + (long)b * T * ld + h * 32;
-  const float* kb = kbias + (long)b * T;
+  const bf16_t* qbase = qkv + sg.row0 * ld + h * 32;
+  const float* kb = kbias + sg.row0;
 
   stage_pair(qbase + d, ld, qbase + 2 * d, ld, imgK, imgV, T, Tp, tid, nthr);
   for (int i = tid; i < Tp; i += nthr) ldsKb[i] = (i < T) ? kb[i] * LOG2E : 0.f;
@@ -361,8 +393,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_res_kernel(const bf16_t* __rest
       for (int r = 0; r < 16; ++r) st[r] = pr[r];
       l_run += ps0 + ps1;
       if (DROP) {   // attn_dropout on the probabilities (trajectory_gpt2.py:179): the normaliser stays undropped
-        const uint32_t g0 = ((uint32_t)(b * H + h) * (uint32_t)T + (uint32_t)q) * (uint32_t)((T + 3) >> 2) +
-                            (uint32_t)((k0 + 4 * (lane >> 5)) >> 2);
+        const uint32_t g0 = ((uint32_t)sg.hrow + (uint32_t)q) * sg.T4 + (uint32_t)((k0 + 4 * (lane >> 5)) >> 2);
         unsigned long long km[16];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {          // registers 4j..4j+3 = keys +8j .. +8j+3: one word
@@ -376,7 +407,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_res_kernel(const bf16_t* __rest
         }
         if (MASK) {     // the sub-tile's 16 lane masks -> mask[(b*H+h)][qb][kbk][32 dwords], 8 scalar stores
           uint32_t* mp = const_cast<uint32_t*>(static_cast<const uint32_t*>(
-              uniform_ptr(dmask + (((long)hb * nblk + qb) * nblk + kbk) * 32)));
+              uniform_ptr(dmask + sg.mask0 + ((long)qb * nblk + kbk) * 32)));
           sstore_masks<0>(mp, km[0], km[1]);
           sstore_masks<16>(mp, km[2], km[3]);
           sstore_masks<32>(mp, km[4], km[5]);
@@ -395,7 +426,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_res_kernel(const bf16_t* __rest
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     if (qvalid) {
       const float inv = (DROP ? drop_scale : 1.0f) / l_tot;
-      bf16_t* orow = out + ((long)b * T + q) * d + h * 32;
+      bf16_t* orow = out + (sg.row0 + q) * d + h * 32;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         uint2 pk;
@@ -403,7 +434,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_res_kernel(const bf16_t* __rest
         pk.y = pack_bf16x2(o[4 * g + 2] * inv, o[4 * g + 3] * inv);
         *reinterpret_cast<uint2*>(orow + 8 * g + 4 * (lane >> 5)) = pk;
       }
-      if (lane < 32) lse[((long)b * H + h) * T + q] = m_run * LN2 + __logf(l_tot);
+      if (lane < 32) lse[sg.hrow + q] = m_run * LN2 + __logf(l_tot);
     }
   }
   if (DROP && MASK)   // scalar stores sit in the scalar data cache until written back
@@ -417,25 +448,28 @@ template <bool DROP, bool MASK>
 __global__ __launch_bounds__(768) void attn_dq_res_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                            const float* __restrict__ kbias, const int* __restrict__ kstart,
                                                            const float* __restrict__ lse, const bf16_t* __restrict__ outp,
-                                                           float* __restrict__ Dout, bf16_t* __restrict__ dqkv, int B, int T,
+                                                           float* __restrict__ Dout, bf16_t* __restrict__ dqkv, int B, int T_uniform,
                                                            int H, float scale, uint32_t drop_thr, uint32_t drop_key,
-                                                           float drop_scale, const uint32_t* __restrict__ dmask) {
+                                                           float drop_scale, const uint32_t* __restrict__ dmask,
+                                                           const int* __restrict__ seq_off, const long long* __restrict__ mask_off,
+                                                           int T4_varlen) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if (DROP) drop_key += neko_drop_salt();
+  const int tid = threadIdx.x, lane = tid & 63, nthr = blockDim.x;
+  const int hb = pair_remap(blockIdx.x, B * H);
+  const int b = hb / H, h = hb % H;
+  const SeqGeom sg = seq_geom(b, h, H, T_uniform, seq_off, mask_off, T4_varlen);
+  const int T = sg.T;
   const int Tp = (T + 31) & ~31, nblk = Tp >> 5;
   char* imgK = smem;
   char* imgV = smem + Tp * 64;
   float* ldsKb = reinterpret_cast<float*>(smem + Tp * 128);
   int* queue = reinterpret_cast<int*>(ldsKb + Tp);
-
-  const int tid = threadIdx.x, lane = tid & 63, nthr = blockDim.x;
   if (tid == 0) *queue = 0;
-  const int hb = pair_remap(blockIdx.x, B * H);
-  const int b = hb / H, h = hb % H;
   const int d = H * 32;
   const long ld = 3L * d;
-  const bf16_t* qbase = qkv + (long)b * T * ld + h * 32;
-  const float* kb = kbias + (long)b * T;
+  const bf16_t* qbase = qkv + sg.row0 * ld + h * 32;
+  const float* kb = kbias + sg.row0;
 
   stage_pair(qbase + d, ld, qbase + 2 * d, ld, imgK, imgV, T, Tp, tid, nthr);
   for (int i = tid; i < Tp; i += nthr) ldsKb[i] = (i < T) ? kb[i] * LOG2E : 0.f;
@@ -451,17 +485,17 @@ __global__ __launch_bounds__(768) void attn_dq_res_kernel(const bf16_t* __restri
     const bool qvalid = q < T;
     bf16x8_v qf[2], dof[2];
     row_frags(qbase + (long)q * ld, qvalid, lane, qf);
-    row_frags(dout + ((long)b * T + q) * d + h * 32, qvalid, lane, dof);
-    const float my_lse = (qvalid ? lse[((long)b * H + h) * T + q] : 0.f) * LOG2E;
+    row_frags(dout + (sg.row0 + q) * d + h * 32, qvalid, lane, dof);
+    const float my_lse = (qvalid ? lse[sg.hrow + q] : 0.f) * LOG2E;
     // D = sum_hd dO.O of the own row (divided by the dropout survivor scale, which is folded out of dS): the lane pair
     // (l, l^32) holds the two halves of the row -- the separate D pass of the streaming kernels is not needed here
     bf16x8_v of[2];
-    row_frags(outp + ((long)b * T + q) * d + h * 32, qvalid, lane, of);
+    row_frags(outp + (sg.row0 + q) * d + h * 32, qvalid, lane, of);
     float my_D = dot8_bf16(__builtin_bit_cast(uint4, dof[0]), __builtin_bit_cast(uint4, of[0])) +
                  dot8_bf16(__builtin_bit_cast(uint4, dof[1]), __builtin_bit_cast(uint4, of[1]));
     my_D += __shfl_xor(my_D, 32, 64);
     if (DROP) my_D *= 1.0f / drop_scale;
-    if (qvalid && lane < 32) Dout[((long)b * H + h) * T + q] = my_D;      // the dK/dV kernel (launched after this one) stages it
+    if (qvalid && lane < 32) Dout[sg.hrow + q] = my_D;      // the dK/dV kernel (launched after this one) stages it
     // a masked query row whose dO is exactly zero (the training case: no loss reaches a padded position) has dP = D = 0,
     // hence dS = 0 for every key: the keys beyond the diagonal are then needed by no row of the block
     const bool live_masked = __builtin_amdgcn_ballot_w64(qvalid && ldsKb[q] != 0.f && (frag_nonzero(dof[0]) || frag_nonzero(dof[1]))) != 0;
@@ -475,7 +509,7 @@ __global__ __launch_bounds__(768) void attn_dq_res_kernel(const bf16_t* __restri
 
     // lane masks of the forward's keep decisions for this query block, one sub-tile (16 x 64 bit, scalar loads) ahead
     const const_u64* mrow = reinterpret_cast<const const_u64*>(reinterpret_cast<uintptr_t>(
-        (DROP && MASK) ? uniform_ptr(dmask + ((long)hb * nblk + qb) * nblk * 32) : nullptr));
+        (DROP && MASK) ? uniform_ptr(dmask + sg.mask0 + (long)qb * nblk * 32) : nullptr));
     unsigned long long mcur[16], mnext[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) mcur[r] = (DROP && MASK) ? mrow[kb_beg * 16 + r] : 0ull;
@@ -499,8 +533,7 @@ __global__ __launch_bounds__(768) void attn_dq_res_kernel(const bf16_t* __restri
         __builtin_amdgcn_sched_barrier(0);
       }
       // dS^T = P^T o (keep*dP^T - D/s); zero where the score was REPLACED by the causal constant
-      const uint32_t g0 = ((uint32_t)(b * H + h) * (uint32_t)T + (uint32_t)q) * (uint32_t)((T + 3) >> 2) +
-                          (uint32_t)((k0 + 4 * (lane >> 5)) >> 2);
+      const uint32_t g0 = ((uint32_t)sg.hrow + (uint32_t)q) * sg.T4 + (uint32_t)((k0 + 4 * (lane >> 5)) >> 2);
       const bool interior = (kbk < qb) && !((padmask >> kbk) & 1) && (k0 + 32 <= T);
       if (interior) {
         const float nlse = -my_lse;
@@ -553,7 +586,7 @@ __global__ __launch_bounds__(768) void attn_dq_res_kernel(const bf16_t* __restri
     // dS was formed as P o (keep*dP - D/s): the dropout survivor scale s multiplies the result once, here
     const float qs = scale * (DROP ? drop_scale : 1.0f);
     if (qvalid) {
-      bf16_t* orow = dqkv + ((long)b * T + q) * ld + h * 32;
+      bf16_t* orow = dqkv + (sg.row0 + q) * ld + h * 32;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         uint2 pk;
@@ -572,12 +605,17 @@ template <bool DROP, bool MASK>
 __global__ __launch_bounds__(NEKO_DKV_WAVES * 64) void attn_dkv_res_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                             const float* __restrict__ kbias, const float* __restrict__ lse,
                                                             const float* __restrict__ Din, bf16_t* __restrict__ dqkv, int B,
-                                                            int T, int H, float scale, uint32_t drop_thr,
+                                                            int T_uniform, int H, float scale, uint32_t drop_thr,
                                                             uint32_t drop_key, float drop_scale,
-                                                            const uint32_t* __restrict__ dmask) {
+                                                            const uint32_t* __restrict__ dmask, const int* __restrict__ seq_off,
+                                                            const long long* __restrict__ mask_off, int T4_varlen) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   NEKO_ATRACE(0, __builtin_amdgcn_s_memrealtime());
   if (DROP) drop_key += neko_drop_salt();
+  const int hb = pair_remap(blockIdx.x, B * H);
+  const int b = hb / H, h = hb % H;
+  const SeqGeom sg = seq_geom(b, h, H, T_uniform, seq_off, mask_off, T4_varlen);
+  const int T = sg.T;
   const int Tp = (T + 31) & ~31, nblk = Tp >> 5;
   char* imgQ = smem;
   char* imgdO = smem + Tp * 64;
@@ -586,15 +624,13 @@ __global__ __launch_bounds__(NEKO_DKV_WAVES * 64) void attn_dkv_res_kernel(const
   int* queue = reinterpret_cast<int*>(ldsD + Tp);
   const int tid = threadIdx.x, lane = tid & 63, nthr = blockDim.x;
   if (tid == 0) *queue = 0;
-  const int hb = pair_remap(blockIdx.x, B * H);
-  const int b = hb / H, h = hb % H;
   const int d = H * 32;
   const long ld = 3L * d;
-  const bf16_t* qbase = qkv + (long)b * T * ld + h * 32;
-  const bf16_t* dobase = dout + (long)b * T * d + h * 32;
-  const float* kb = kbias + (long)b * T;
-  const float* lse_b = lse + ((long)b * H + h) * T;
-  const float* D_b = Din + ((long)b * H + h) * T;
+  const bf16_t* qbase = qkv + sg.row0 * ld + h * 32;
+  const bf16_t* dobase = dout + sg.row0 * d + h * 32;
+  const float* kb = kbias + sg.row0;
+  const float* lse_b = lse + sg.hrow;
+  const float* D_b = Din + sg.hrow;
 
   // Staging: Q and dO images, -lse and D[q] = sum_hd dO.O / s (written by the dQ kernel, which runs first and needs the sum
   // for its own rows anyway: a third of this prologue's bytes were the O rows read only to form it).  EVERY global load
@@ -662,7 +698,7 @@ __global__ __launch_bounds__(NEKO_DKV_WAVES * 64) void attn_dkv_res_kernel(const
   }
 
   const float scale2 = scale * LOG2E;
-  const uint32_t T4 = (uint32_t)((T + 3) >> 2);
+  const uint32_t T4 = sg.T4;
   NEKO_ATRACE(1, __builtin_amdgcn_s_memrealtime());
   unsigned long long ntiles_traced = 0;
 #pragma unroll 1
@@ -694,7 +730,7 @@ __global__ __launch_bounds__(NEKO_DKV_WAVES * 64) void attn_dkv_res_kernel(const
     // 1.14 us per sub-tile without dropout, 1.58 us with, 1.39 us with the loads ablated): two blocks of lead through two
     // alternating registers, the same through a per-wave LDS-DMA ring (global_load_lds_dword + counted vmcnt), and a
     // key-block-major mask layout that makes this kernel's walk sequential -- 1.58 / 1.63 / 1.74 us: it is not latency.
-    const uint32_t* mcol = (DROP && MASK) ? dmask + ((long)hb * nblk * nblk + kbw) * 32 + mask_slot_of_key(lane & 31) : nullptr;
+    const uint32_t* mcol = (DROP && MASK) ? dmask + sg.mask0 + (long)kbw * 32 + mask_slot_of_key(lane & 31) : nullptr;
     auto mask_word = [&](int q) { return (DROP && MASK && !(NEKO_ATTN_ABL & 4)) ? mcol[(long)min(q, nblk - 1) * nblk * 32] : 0xFFFFFFFFu; };
     auto sub_tile = [&](const int qb, const uint32_t wraw) {
       const int q0 = qb * 32;
@@ -711,7 +747,7 @@ __global__ __launch_bounds__(NEKO_DKV_WAVES * 64) void attn_dkv_res_kernel(const
       // (key & 3) = i hashes rows 4j + i and the quad shares the 16 words by DPP
       uint32_t mine[4] = {0u, 0u, 0u, 0u};
       if (DROP && !MASK) {
-        const uint32_t gq = ((uint32_t)(b * H + h) * (uint32_t)T + (uint32_t)(q0 + 4 * (lane >> 5) + (lane & 3))) * T4 +
+        const uint32_t gq = ((uint32_t)sg.hrow + (uint32_t)(q0 + 4 * (lane >> 5) + (lane & 3))) * T4 +
                             (uint32_t)(key >> 2);
 #pragma unroll
         for (int j = 0; j < 4; ++j) mine[j] = drop_word(gq + (uint32_t)(8 * j) * T4, drop_key);    // row c = (lane&3) + 8j
@@ -800,7 +836,7 @@ __global__ __launch_bounds__(NEKO_DKV_WAVES * 64) void attn_dkv_res_kernel(const
     // P and dP were masked but not scaled in the loop (D holds D/s): the survivor scale s is applied once, here
     const float vsc = DROP ? drop_scale : 1.0f, ksc = scale * vsc;
     if (kvalid) {
-      bf16_t* krow = dqkv + ((long)b * T + key) * ld + d + h * 32;
+      bf16_t* krow = dqkv + (sg.row0 + key) * ld + d + h * 32;
       bf16_t* vrow = krow + d;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -837,23 +873,26 @@ long neko_attn_res_mask_dwords(int B, int T, int H, int hd) {
   return (long)B * H * nblk * nblk * 32;
 }
 
+// seq_off / mask_off null: the uniform (B, T) batch; otherwise nseq = B packed sequences (see SeqGeom) whose longest has T rows
 int neko_attn_fwd_res_impl(const bf16_t* qkv, const float* kbias, const int* kstart, bf16_t* out, float* lse, int B, int T,
-                           int H, int drop_thr, unsigned drop_key, float drop_scale, uint32_t* dmask, hipStream_t s) {
+                           int H, int drop_thr, unsigned drop_key, float drop_scale, uint32_t* dmask, hipStream_t s,
+                           const int* seq_off, const long long* mask_off) {
   const int Tp = (T + 31) & ~31, nblk = Tp / 32, nw = min(16, (nblk + 1) / 2);
   const size_t lds = (size_t)Tp * 128 + (size_t)Tp * 4 + 16;
   const float scale = 1.0f / sqrtf(32.0f);
+  const int T4 = (T + 3) >> 2;
   static const int once = allow_lds(attn_fwd_res_kernel<true, true>, 160 * 1024) | allow_lds(attn_fwd_res_kernel<true, false>, 160 * 1024) |
                           allow_lds(attn_fwd_res_kernel<false, false>, 160 * 1024);
   if (once != NEKO_OK) return once;
   if (drop_thr && dmask)
     hipLaunchKernelGGL((attn_fwd_res_kernel<true, true>), dim3(B * H), dim3(64 * nw), lds, s, qkv, kbias, kstart, out, lse, B, T,
-                       H, scale, (uint32_t)drop_thr, drop_key, drop_scale, dmask);
+                       H, scale, (uint32_t)drop_thr, drop_key, drop_scale, dmask, seq_off, mask_off, T4);
   else if (drop_thr)
     hipLaunchKernelGGL((attn_fwd_res_kernel<true, false>), dim3(B * H), dim3(64 * nw), lds, s, qkv, kbias, kstart, out, lse, B, T,
-                       H, scale, (uint32_t)drop_thr, drop_key, drop_scale, nullptr);
+                       H, scale, (uint32_t)drop_thr, drop_key, drop_scale, nullptr, seq_off, mask_off, T4);
   else
     hipLaunchKernelGGL((attn_fwd_res_kernel<false, false>), dim3(B * H), dim3(64 * nw), lds, s, qkv, kbias, kstart, out, lse, B, T,
-                       H, scale, 0u, drop_key, drop_scale, nullptr);
+                       H, scale, 0u, drop_key, drop_scale, nullptr, seq_off, mask_off, T4);
   NEKO_CHECK_LAUNCH();
   return NEKO_OK;
 }
@@ -862,11 +901,13 @@ int neko_attn_fwd_res_impl(const bf16_t* qkv, const float* kbias, const int* kst
 // dmask: the keep masks the forward call of the same (qkv, drop_key) wrote, or null (the kernels re-hash the decisions).
 int neko_attn_bwd_res_impl(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const float* kbias, const int* kstart,
                            const float* lse, float* D, bf16_t* dqkv, int B, int T, int H, int drop_thr, unsigned drop_key,
-                           float drop_scale, const uint32_t* dmask, hipStream_t s) {
-  if (!D) return NEKO_ERR_ARG;          // f32 [B*H*T]: the dQ kernel leaves sum_hd dO.O / s there for the dK/dV kernel
+                           float drop_scale, const uint32_t* dmask, hipStream_t s, const int* seq_off,
+                           const long long* mask_off) {
+  if (!D) return NEKO_ERR_ARG;          // f32 [rows * H]: the dQ kernel leaves sum_hd dO.O / s there for the dK/dV kernel
   const int Tp = (T + 31) & ~31, nblk = Tp / 32, nw = min(12, (nblk + 1) / 2), nw_kv = min(NEKO_DKV_WAVES, (nblk + 1) / 2);
   const size_t lds_q = (size_t)Tp * 128 + (size_t)Tp * 4 + 16, lds_kv = (size_t)Tp * 128 + (size_t)Tp * 8 + 16;
   const float scale = 1.0f / sqrtf(32.0f);
+  const int T4 = (T + 3) >> 2;
   static const int once = allow_lds(attn_dq_res_kernel<true, true>, 160 * 1024) | allow_lds(attn_dq_res_kernel<true, false>, 160 * 1024) |
                           allow_lds(attn_dq_res_kernel<false, false>, 160 * 1024) | allow_lds(attn_dkv_res_kernel<true, true>, 160 * 1024) |
                           allow_lds(attn_dkv_res_kernel<true, false>, 160 * 1024) | allow_lds(attn_dkv_res_kernel<false, false>, 160 * 1024);
@@ -874,10 +915,10 @@ int neko_attn_bwd_res_impl(const bf16_t* qkv, const bf16_t* out, const bf16_t* d
 #define NEKO_BWD_RES(DROPV, MASKV, THR, MP)                                                                                       \
   do {                                                                                                                            \
     hipLaunchKernelGGL((attn_dq_res_kernel<DROPV, MASKV>), dim3(B * H), dim3(64 * nw), lds_q, s, qkv, dout, kbias, kstart, lse,  \
-                       out, D, dqkv, B, T, H, scale, (uint32_t)(THR), drop_key, drop_scale, MP);                                 \
+                       out, D, dqkv, B, T, H, scale, (uint32_t)(THR), drop_key, drop_scale, MP, seq_off, mask_off, T4);          \
     NEKO_CHECK_LAUNCH();                                                                                                          \
     hipLaunchKernelGGL((attn_dkv_res_kernel<DROPV, MASKV>), dim3(B * H), dim3(64 * nw_kv), lds_kv, s, qkv, dout, kbias, lse, D, \
-                       dqkv, B, T, H, scale, (uint32_t)(THR), drop_key, drop_scale, MP);                                         \
+                       dqkv, B, T, H, scale, (uint32_t)(THR), drop_key, drop_scale, MP, seq_off, mask_off, T4);                  \
   } while (0)
   if (drop_thr && dmask) NEKO_BWD_RES(true, true, drop_thr, dmask);
   else if (drop_thr) NEKO_BWD_RES(true, false, drop_thr, nullptr);

@@ -75,6 +75,27 @@ int neko_attn_fwd(const uint16_t* qkv, const float* kbias, const int* kstart, ui
   return neko_attn_fwd_impl(qkv, kbias, kstart, out, lse, B, T, H, hd, drop_thr, drop_key, drop_scale, drop_mask, S(stream));
 }
 long neko_attn_mask_dwords(int B, int T, int H, int hd) { return neko_attn_mask_dwords_impl(B, T, H, hd); }
+// packed sequences of different lengths in ONE launch (head-resident kernels only: hd = 32, every length <= 1024)
+int neko_attn_varlen_supported(int Tmax, int hd) { return neko_attn_res_applicable(Tmax, hd) ? 1 : 0; }
+int neko_attn_fwd_varlen(const uint16_t* qkv, const float* kbias, const int* kstart, const int* seq_off, const long long* mask_off,
+                         uint16_t* out, float* lse, int nseq, int Tmax, int H, int hd, int drop_thr, unsigned drop_key,
+                         float drop_scale, uint32_t* drop_mask, void* stream) {
+  if (!qkv || !kbias || !seq_off || !out || !lse || nseq <= 0 || Tmax <= 0 || H <= 0) return NEKO_ERR_ARG;
+  if (drop_thr < 0 || drop_thr > 255 || (drop_mask && !mask_off)) return NEKO_ERR_ARG;
+  if (!neko_attn_res_applicable(Tmax, hd)) return NEKO_ERR_UNSUPPORTED;
+  return neko_attn_fwd_res_impl(qkv, kbias, kstart, out, lse, nseq, Tmax, H, drop_thr, drop_key, drop_scale, drop_mask, S(stream),
+                                seq_off, mask_off);
+}
+int neko_attn_bwd_varlen(const uint16_t* qkv, const uint16_t* out, const uint16_t* dout, const float* kbias, const int* kstart,
+                         const int* seq_off, const long long* mask_off, const float* lse, float* D, uint16_t* dqkv, int nseq,
+                         int Tmax, int H, int hd, int drop_thr, unsigned drop_key, float drop_scale, const uint32_t* drop_mask,
+                         void* stream) {
+  if (!qkv || !out || !dout || !kbias || !seq_off || !lse || !D || !dqkv || nseq <= 0 || Tmax <= 0 || H <= 0) return NEKO_ERR_ARG;
+  if (drop_thr < 0 || drop_thr > 255 || (drop_mask && !mask_off)) return NEKO_ERR_ARG;
+  if (!neko_attn_res_applicable(Tmax, hd)) return NEKO_ERR_UNSUPPORTED;
+  return neko_attn_bwd_res_impl(qkv, out, dout, kbias, kstart, lse, D, dqkv, nseq, Tmax, H, drop_thr, drop_key, drop_scale,
+                                drop_mask, S(stream), seq_off, mask_off);
+}
 int neko_attn_set_path(int mode) { return neko_attn_set_path_impl(mode); }
 int neko_attn_bwd(const uint16_t* qkv, const uint16_t* out, const uint16_t* dout, const float* kbias,
                   const int* kstart, const float* lse, float* D, int* qflags, uint16_t* dqkv, int B, int T, int H,

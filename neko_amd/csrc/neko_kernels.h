@@ -61,10 +61,12 @@ int neko_attn_bwd_impl(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout,
 int neko_attn_set_path_impl(int mode);
 bool neko_attn_res_applicable(int T, int hd);
 int neko_attn_fwd_res_impl(const bf16_t* qkv, const float* kbias, const int* kstart, bf16_t* out, float* lse, int B, int T,
-                           int H, int drop_thr, unsigned drop_key, float drop_scale, uint32_t* dmask, hipStream_t s);
+                           int H, int drop_thr, unsigned drop_key, float drop_scale, uint32_t* dmask, hipStream_t s,
+                           const int* seq_off = nullptr, const long long* mask_off = nullptr);
 int neko_attn_bwd_res_impl(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const float* kbias, const int* kstart,
                            const float* lse, float* D, bf16_t* dqkv, int B, int T, int H, int drop_thr, unsigned drop_key,
-                           float drop_scale, const uint32_t* dmask, hipStream_t s);
+                           float drop_scale, const uint32_t* dmask, hipStream_t s, const int* seq_off = nullptr,
+                           const long long* mask_off = nullptr);
 int neko_gemv_bf16_impl(const bf16_t* x, long ldx, const bf16_t* W, long ldw, int b_kstrided, int M, int N, int K,
                         const float* bias, const float* resid, long ldr, int act, float* Cf, long ldcf, bf16_t* Cb,
                         long ldcb, hipStream_t s);

@@ -91,6 +91,7 @@ class StackCtx:
     B: int = 0
     T: int = 0
     segs: List[Segment] = field(default_factory=list)
+    varlen: object = None            # Varlen: the packed single-launch view of `segs` (ragged batches on the head-resident kernels)
     layers: List[LayerCtx] = field(default_factory=list)
     drops: Optional[DropSites] = None
     xf: torch.Tensor = None          # residual stream entering ln_f
@@ -203,9 +204,36 @@ def _seg_drop(drop: Optional[ops.Drop], si: int) -> Optional[ops.Drop]:
     return d2
 
 
-def _attn_fwd_segs(qkv, segs: List[Segment], H: int, hd: int, drop, save: bool = False):
+#: Length-bucketed (ragged) batches run their attention as ONE packed launch over all sequences (neko_attn_*_varlen) when the
+#: head-resident kernels apply (hd = 32, every length <= 1024); NEKO_ATTN_VARLEN=0 returns to one launch per bucket.
+ATTN_VARLEN = os.environ.get("NEKO_ATTN_VARLEN", "1") != "0"
+
+
+@dataclass
+class Varlen:
+    """The packed view of a segment list: per-sequence geometry + key bias / first real key of every row / sequence."""
+    geom: "ops.VarlenGeom"
+    kbias: torch.Tensor
+    kstart: torch.Tensor
+
+
+def _varlen_of(segs: List[Segment], H: int, hd: int, device) -> Optional[Varlen]:
+    if not ATTN_VARLEN or len(segs) < 2 or not ops.attn_varlen_supported(max(s.T for s in segs), hd):
+        return None
+    lengths = [s.T for s in segs for _ in range(s.B)]
+    return Varlen(geom=ops.VarlenGeom(lengths, H, device), kbias=torch.cat([s.kbias.reshape(-1) for s in segs]),
+                  kstart=torch.cat([s.kstart.reshape(-1) for s in segs]))
+
+
+def _attn_fwd_segs(qkv, segs: List[Segment], H: int, hd: int, drop, save: bool = False, varlen: Optional[Varlen] = None):
     """-> (o, lse, keep masks).  With `save` and dropout on, the forward also hands back the keep decisions it made (one
     buffer per attention call) so that the backward does not re-hash them in both of its kernels."""
+    if varlen is not None:
+        o = torch.empty(qkv.shape[0], H * hd, dtype=BF16, device=qkv.device)
+        if qkv.shape[0] > varlen.geom.rows:
+            o[varlen.geom.rows:].zero_()           # alignment rows behind the last sequence (all padding)
+        _, lse, mk = ops.attn_fwd_varlen(qkv, varlen.kbias, varlen.kstart, varlen.geom, hd, drop=drop, out=o, want_mask=save)
+        return o, lse, mk
     if len(segs) == 1 and segs[0].B * segs[0].T == qkv.shape[0]:
         sg = segs[0]
         return ops.attn_fwd(qkv, sg.kbias, sg.kstart, sg.B, sg.T, H, hd, drop=drop, want_mask=True) if save else \
@@ -223,7 +251,12 @@ def _attn_fwd_segs(qkv, segs: List[Segment], H: int, hd: int, drop, save: bool =
     return o, lses, masks
 
 
-def _attn_bwd_segs(qkv, o, d_o, lse, segs: List[Segment], H: int, hd: int, drop, dmask=None):
+def _attn_bwd_segs(qkv, o, d_o, lse, segs: List[Segment], H: int, hd: int, drop, dmask=None, varlen: Optional[Varlen] = None):
+    if varlen is not None:
+        dqkv = torch.empty_like(qkv)
+        if qkv.shape[0] > varlen.geom.rows:
+            dqkv[varlen.geom.rows:].zero_()
+        return ops.attn_bwd_varlen(qkv, o, d_o, varlen.kbias, varlen.kstart, lse, varlen.geom, hd, drop=drop, dqkv=dqkv, mask=dmask)
     if len(segs) == 1 and segs[0].B * segs[0].T == qkv.shape[0]:
         sg = segs[0]
         return ops.attn_bwd(qkv, o, d_o, sg.kbias, sg.kstart, lse, sg.B, sg.T, H, hd, drop=drop, mask=dmask)
@@ -259,7 +292,8 @@ def stack_forward(P: StackParams, x: torch.Tensor, mask: torch.Tensor, save: boo
     # touches: their attention output / gradient rows are zero
     assert segs[0].row0 == 0 and all(a.row0 + a.B * a.T == b.row0 for a, b in zip(segs, segs[1:])) \
         and segs[-1].row0 + segs[-1].B * segs[-1].T <= M, "segments must tile the rows of x"
-    ctx = StackCtx(B=B, T=T, segs=segs, drops=drops) if save else None
+    varlen = _varlen_of(segs, H, hd, dev)
+    ctx = StackCtx(B=B, T=T, segs=segs, drops=drops, varlen=varlen) if save else None
     dr = drops
     if dr is not None and dr.embd is not None:
         x = ops.dropout_f32(x, dr.embd)                       # embedding dropout (:707)
@@ -270,7 +304,7 @@ def stack_forward(P: StackParams, x: torch.Tensor, mask: torch.Tensor, save: boo
         ops.layernorm_fwd(x, lp.ln1_w, lp.ln1_b, y16=a1, mean=mean1, rstd=rstd1, eps=P.eps)
         qkv = torch.empty(M, 3 * d, dtype=BF16, device=dev)
         ops.gemm(a1, lp.w_qkv, M, 3 * d, d, b_kstrided=True, bias=lp.b_qkv, out_bf16=qkv)
-        o, lse, dmask = _attn_fwd_segs(qkv, segs, H, hd, dr.attn[li] if dr else None, save=save)
+        o, lse, dmask = _attn_fwd_segs(qkv, segs, H, hd, dr.attn[li] if dr else None, save=save, varlen=varlen)
         x1 = torch.empty(M, d, dtype=F32, device=dev)
         ops.gemm(o, lp.w_o, M, d, d, b_kstrided=True, bias=lp.b_o, resid=x, out_f32=x1,
                  drop=dr.resid_attn[li] if dr else None)
@@ -356,7 +390,7 @@ def stack_backward(P: StackParams, ctx: StackCtx, dhf: torch.Tensor,
         d_o = torch.empty(M, d, dtype=BF16, device=dev)
         ops.gemm(g1_16, lp.w_o, M, d, d, ldb=d, out_bf16=d_o)
         SideStream.fork(lambda c=c, lp=lp, g1_16=g1_16: _wgrad(c.o, g1_16, d, d, M, lp.g_w_o), g1_16)
-        dqkv = _attn_bwd_segs(c.qkv, c.o, d_o, c.lse, ctx.segs, H, hd, dr.attn[i] if dr else None, dmask=c.dmask)
+        dqkv = _attn_bwd_segs(c.qkv, c.o, d_o, c.lse, ctx.segs, H, hd, dr.attn[i] if dr else None, dmask=c.dmask, varlen=ctx.varlen)
         d_a1 = _dgrad_to_ln(dqkv, lp.w_qkv, M, d, 3 * d, 3 * d)
         SideStream.fork(lambda c=c, lp=lp, dqkv=dqkv: (_wgrad(c.a1, dqkv, d, 3 * d, M, lp.g_w_qkv),
                                                       ops.colsum_bf16(dqkv, M, 3 * d, lp.g_b_qkv)), dqkv)

@@ -222,6 +222,57 @@ def attn_fwd(qkv, kbias, kstart, B, T, H, hd, drop=None, out=None, want_mask=Fal
     return (out, lse, mask) if want_mask else (out, lse)
 
 
+class VarlenGeom:
+    """Packed sequences for the single-launch attention (neko_attn_*_varlen): lengths (host ints, in row order) -> row offsets,
+    keep-mask offsets and sizes; the two offset arrays live on the device."""
+
+    def __init__(self, lengths, H: int, device):
+        self.lengths = [int(t) for t in lengths]
+        self.nseq, self.Tmax, self.H = len(self.lengths), max(self.lengths), int(H)
+        off, moff = [0], [0]
+        for t in self.lengths:
+            off.append(off[-1] + t)
+            nb = (t + 31) // 32
+            moff.append(moff[-1] + self.H * nb * nb * 32)
+        self.rows, self.mask_dwords = off[-1], moff[-1]
+        self.seq_off = torch.tensor(off, dtype=torch.int32).to(device, non_blocking=True)
+        self.mask_off = torch.tensor(moff[:-1], dtype=torch.int64).to(device, non_blocking=True)
+
+
+def attn_varlen_supported(Tmax: int, hd: int) -> bool:
+    return bool(_lib.load().neko_attn_varlen_supported(int(Tmax), int(hd)))
+
+
+def attn_fwd_varlen(qkv, kbias, kstart, geom: VarlenGeom, hd, drop=None, out=None, want_mask=False):
+    """Packed counterpart of attn_fwd: qkv [rows, 3 H hd], kbias [rows], kstart [nseq] -> (out [rows, H hd], lse [rows * H]
+    laid out [sequence][head][position], keep masks or None)."""
+    _chk(qkv, BF16, "qkv")
+    H = geom.H
+    assert qkv.is_contiguous() and qkv.shape[0] >= geom.rows and kbias.numel() >= geom.rows
+    if out is None:
+        out = torch.empty(qkv.shape[0], H * hd, dtype=BF16, device=qkv.device)
+    lse = torch.empty(geom.rows * H, dtype=torch.float32, device=qkv.device)
+    mask = None
+    if want_mask and drop is not None and drop.thr > 0:
+        mask = torch.empty(geom.mask_dwords, dtype=torch.int32, device=qkv.device)
+    _lib.call("neko_attn_fwd_varlen", _p(qkv), _p(kbias), _p(kstart), _p(geom.seq_off), _p(geom.mask_off), _p(out), _p(lse),
+              geom.nseq, geom.Tmax, H, hd, *_drop(drop), _p(mask), _stream())
+    return out, lse, mask
+
+
+def attn_bwd_varlen(qkv, out, dout, kbias, kstart, lse, geom: VarlenGeom, hd, drop=None, dqkv=None, mask=None):
+    _chk(dout, BF16, "dout")
+    H = geom.H
+    D = torch.empty(geom.rows * H, dtype=torch.float32, device=qkv.device)
+    if dqkv is None:
+        dqkv = torch.empty_like(qkv)
+    if mask is not None:
+        _chk(mask, torch.int32, "mask"); assert mask.numel() == geom.mask_dwords
+    _lib.call("neko_attn_bwd_varlen", _p(qkv), _p(out), _p(dout), _p(kbias), _p(kstart), _p(geom.seq_off), _p(geom.mask_off),
+              _p(lse), _p(D), _p(dqkv), geom.nseq, geom.Tmax, H, hd, *_drop(drop), _p(mask), _stream())
+    return dqkv
+
+
 def attn_bwd(qkv, out, dout, kbias, kstart, lse, B, T, H, hd, drop=None, dqkv=None, mask=None):
     """dqkv (optional): a contiguous [B*T, 3*H*hd] bf16 row range to write into.
     mask: the keep-mask buffer attn_fwd(..., want_mask=True) returned for the SAME call (or None: decisions are re-hashed)."""

@@ -61,6 +61,10 @@ def _as_2d_ids(t):
     return t
 
 
+#: a bucketed (ragged) layout is used only when it removes at least this fraction of the padded rows (see build_layout)
+RAGGED_MIN_SAVING = float(os.environ.get("NEKO_RAGGED_MIN_SAVING", "0.10"))
+
+
 def plan_ragged_groups(lengths: Sequence[int], max_groups: int) -> List[List[int]]:
     """Partition examples into at most `max_groups` length buckets minimising the padded token count
     sum_k B_k * T_k (T_k = longest member of bucket k).  Exact dynamic programme over the distinct lengths in
@@ -207,7 +211,7 @@ def build_layout(inputs: Sequence[dict], use_pos_encoding: bool, context_len: in
         # buckets pay with one attention launch each and ragged GEMM edges: with nearly full sequences (the metric's
         # m-mix: 1024 / 1008 / 988 tokens, 1.6 % padding) they measured 6 % SLOWER than the padded layout, with the
         # 1024 / 494 / 289 / 240 mix 1.54x faster -- so they are only used when they remove at least a tenth of the rows
-        if bucket_rows > 0.9 * len(per_ex) * max(lens):
+        if bucket_rows > (1.0 - RAGGED_MIN_SAVING) * len(per_ex) * max(lens):
             groups = None
     if ragged_groups > 0 and groups is not None:
         blocks, segs, order, row0 = [], [], [], 0

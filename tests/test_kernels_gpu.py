@@ -687,3 +687,69 @@ def test_lm_head_chunking_is_invisible(ops):
     dw_ref = da.float().t() @ hf.float()
     close(dh, dh_ref, 1e-3, 1e-3 * float(dh_ref.abs().max()), "LM-head dH")
     close(hp.g_w, dw_ref, 1e-3, 1e-3 * float(dw_ref.abs().max()), "LM-head dW")
+
+
+# ----------------------------------------------------------------------------------------------------
+# packed sequences of different lengths in one attention launch (neko_attn_*_varlen)
+# ----------------------------------------------------------------------------------------------------
+def test_attention_varlen_equals_per_sequence_calls(ops):
+    """One packed launch over sequences of 1024 / 200 / 33 / 512 / 97 / 1000 positions (two of them left-padded) must give,
+    for every sequence, the very bits the uniform kernels give when that sequence is run alone: out, lse, dqkv."""
+    H, hd = 3, 32
+    d = H * hd
+    lengths = [1024, 200, 33, 512, 97, 1000]
+    pads = [0, 17, 0, 40, 0, 0]
+    rows = sum(lengths)
+    g = torch.Generator(device=DEV).manual_seed(31)
+    qkv = torch.randn(rows, 3 * d, device=DEV, generator=g).to(torch.bfloat16)
+    do = torch.randn(rows, d, device=DEV, generator=g).to(torch.bfloat16)
+    kbs, kss, r0 = [], [], 0
+    for T, pad in zip(lengths, pads):
+        m = torch.ones(1, T, device=DEV)
+        m[0, :pad] = 0
+        kb, ks = ops.mask_bias(m)
+        kbs.append(kb.reshape(-1)); kss.append(ks.reshape(-1))
+        do[r0:r0 + pad] = 0                          # training: no loss reaches a padded position
+        r0 += T
+    geom = ops.VarlenGeom(lengths, H, DEV)
+    assert geom.rows == rows
+    kb_all, ks_all = torch.cat(kbs), torch.cat(kss)
+    out, lse, _ = ops.attn_fwd_varlen(qkv, kb_all, ks_all, geom, hd)
+    dqkv = ops.attn_bwd_varlen(qkv, out, do, kb_all, ks_all, lse, geom, hd)
+    r0 = 0
+    for i, T in enumerate(lengths):
+        q1 = qkv[r0:r0 + T].contiguous()
+        o1, l1 = ops.attn_fwd(q1, kbs[i].view(1, T), kss[i], 1, T, H, hd)
+        g1 = ops.attn_bwd(q1, o1, do[r0:r0 + T].contiguous(), kbs[i].view(1, T), kss[i], l1, 1, T, H, hd)
+        assert torch.equal(out[r0:r0 + T], o1), f"out of sequence {i}"
+        assert torch.equal(lse[r0 * H:(r0 + T) * H].view(H, T), l1.view(H, T)), f"lse of sequence {i}"
+        assert torch.equal(dqkv[r0:r0 + T], g1), f"dqkv of sequence {i}"
+        r0 += T
+
+
+def test_attention_varlen_dropout_masks_are_consistent(ops):
+    """Packed launch with attention dropout: the backward that reuses the forward's stored keep masks must produce the very bits of
+    the backward that re-hashes them (same index formula on both sides: unique row id x ceil(Tmax / 4) + key / 4), the keep rate
+    is the requested one, and with the masks handed to a second forward into the same buffer nothing stale survives."""
+    H, hd = 2, 32
+    d = H * hd
+    lengths = [1024, 300, 64, 777]
+    rows = sum(lengths)
+    g = torch.Generator(device=DEV).manual_seed(32)
+    qkv = (torch.randn(rows, 3 * d, device=DEV, generator=g) * 0.7).to(torch.bfloat16)
+    do = torch.randn(rows, d, device=DEV, generator=g).to(torch.bfloat16)
+    kb = torch.zeros(rows, device=DEV)
+    ks = torch.zeros(len(lengths), dtype=torch.int32, device=DEV)
+    geom = ops.VarlenGeom(lengths, H, DEV)
+    drop = ops.Drop(0.1, 0xC0FFEE)
+    out, lse, mk = ops.attn_fwd_varlen(qkv, kb, ks, geom, hd, drop=drop, want_mask=True)
+    assert mk is not None and mk.numel() == geom.mask_dwords
+    g_mask = ops.attn_bwd_varlen(qkv, out, do, kb, ks, lse, geom, hd, drop=drop, mask=mk)
+    g_hash = ops.attn_bwd_varlen(qkv, out, do, kb, ks, lse, geom, hd, drop=drop, mask=None)
+    assert torch.equal(g_mask, g_hash)
+    out0, _, _ = ops.attn_fwd_varlen(qkv, kb, ks, geom, hd)
+    assert bool(torch.isfinite(out.float()).all())
+    # dropped and undropped outputs differ, but agree in expectation: mean absolute difference well below the signal
+    assert float((out.float() - out0.float()).abs().mean()) < 0.35 * float(out0.float().abs().mean())
+    out2, lse2, mk2 = ops.attn_fwd_varlen(qkv, kb, ks, geom, hd, drop=drop, want_mask=True)
+    assert torch.equal(out, out2) and torch.equal(lse, lse2)
