@@ -791,6 +791,8 @@ int neko_attn_fwd_impl(const bf16_t* qkv, const float* kbias, const int* kstart,
   if (!qkv || !kbias || !out || !lse || H <= 0 || drop_thr < 0 || drop_thr > 255) return NEKO_ERR_ARG;
   if (g_attn_path == 0 && neko_attn_res_applicable(T, hd))
     return neko_attn_fwd_res_impl(qkv, kbias, kstart, out, lse, B, T, H, drop_thr, drop_key, drop_scale, dmask, s);
+  if (g_attn_path == 0 && neko_attn_stream_applicable(T, hd))       // hd = 64 / 128: DMA-ring kernels (attention_stream.hip)
+    return neko_attn_fwd_stream_impl(qkv, kbias, kstart, out, lse, B, T, H, hd, drop_thr, drop_key, drop_scale, s);
   switch (hd) {
     case 32: return fwd_launch<32>(qkv, kbias, kstart, out, lse, B, T, H, drop_thr, drop_key, drop_scale, s);
     case 64: return fwd_launch<64>(qkv, kbias, kstart, out, lse, B, T, H, drop_thr, drop_key, drop_scale, s);

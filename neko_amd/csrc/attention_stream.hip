@@ -1,0 +1,608 @@
+// Streaming attention for wide heads (hd = 64 / 128), forward and backward: K / V (or Q / dO) tiles of 64 rows travel
+// HBM -> LDS by DMA (global_load_lds_dwordx4) through a ring of stages, one block barrier per tile, counted vmcnt waits.
+// Replaces Attention._attn + split_heads / merge_heads + the mask preparation of the reference
+// (gato/transformers/trajectory_gpt2.py:163-188,190-201,222-226,252 and :663-679) and their autograd, for the widths the
+// head-resident kernels of attention_res.hip do not cover (configs[4]: 2048d x 16 heads, hd = 128).
+//
+// Same arithmetic, same mask semantics and the same dropout index as attention.hip (whose register-staged kernels these
+// replace at hd >= 64: two barriers per tile, V transposed through 2-byte LDS stores, 180-335 TFLOP/s at hd = 128):
+//     s = (q.k)/sqrt(hd);  s = (key <= query) ? s : -1e4 (REPLACE);  s += (1 - mask[key]) * -1e4 (ADD)
+// scores are computed transposed (S^T = K.Q^T, one lane owns one query column), probabilities leave the accumulator as
+// the B operand of O^T += V^T.P^T with the key order permuted identically on the V^T side.
+//
+// LDS images: a tile is [64 rows][hd] bf16, row-major, 16-B chunk c of row r stored at chunk c ^ swz(r).  swz() is
+// chosen so that BOTH access patterns are conflict-free:
+//   * ds_read_b128 of one chunk column by 16 consecutive rows (the K / Q / V / dO "natural" A fragments), and
+//   * ds_read_b64_tr_b16 of 4 consecutive rows x 4 consecutive chunks (the transposed V^T / K^T / Q^T / dO^T fragments:
+//     the hardware transposes 4 x 4 blocks of 16-bit values inside each 16-lane group, no transposed copy is ever written).
+// The DMA writes 1 KiB per wave instruction at consecutive LDS addresses, so the swizzle is applied on the GLOBAL side:
+// lane L of a piece fetches the chunk whose swizzled position is L.
+#include "neko_kernels.h"
+
+extern int neko_attn_path_mode();
+
+#ifndef NEKO_AS_DIAG
+#define NEKO_AS_DIAG 0      // ablations for tools/attn_bench.py (wrong results): 1 no in-loop DMA, 2 no softmax arithmetic, 4 no P.V, 8 no barrier
+#endif
+
+namespace {
+
+constexpr int KT = 64;
+constexpr int TMAX = 4096;      // key-bias image of a whole sequence lives in LDS
+constexpr float MASK_VAL = -10000.0f;
+constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+__device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }
+
+template <int HD> struct SC {
+  static constexpr int CH = HD / 8;          // 16-B chunks per row
+  static constexpr int ROWB = HD * 2;        // bytes per row
+  static constexpr int TILE = KT * ROWB;     // bytes per 64-row tile
+  static constexpr int KS = HD / 16;         // MFMA k-steps over the head dim
+  static constexpr int IB = HD / 32;         // 32-wide blocks over the head dim
+  static constexpr int PIECES = TILE / 1024; // DMA wave-instructions per tile
+};
+// SW = 0: tiles read BOTH ways (natural ds_read_b128 by 16 consecutive rows and ds_read_b64_tr_b16): the swizzle is injective on
+//         the low 4 row bits; SW = 1: tiles read only transposed: the swizzle depends on the two row bits that separate the 4 rows
+//         of one transposed read -- rows 8 and 16 apart then share it, and every fragment of a tile is one per-lane base register
+//         plus an immediate offset
+template <int HD, int SW>
+__device__ __forceinline__ int swz(int row) {
+  if constexpr (HD == 128) return SW ? ((row & 3) << 2) : (((row & 3) << 2) | ((row >> 2) & 3));
+  else return SW ? (((row >> 1) & 1) << 2) : ((((row >> 1) & 1) << 2) | ((row >> 2) & 3));       // hd = 64: two rows per 256-B bank sweep
+}
+template <int HD, int SW>
+__device__ __forceinline__ int img_off(int row, int c) { return row * SC<HD>::ROWB + ((c ^ swz<HD, SW>(row)) << 4); }
+
+typedef __attribute__((address_space(3))) const uint4 lds_u4;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+__device__ __forceinline__ bf16x8_v lds_read16(unsigned addr) {
+  return __builtin_bit_cast(bf16x8_v, *reinterpret_cast<lds_u4*>((uintptr_t)addr));
+}
+__device__ __forceinline__ bf16x8_v lds_read_tr(unsigned addr_lo, unsigned addr_hi) {
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<lds_s16x4*>((uintptr_t)addr_lo));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<lds_s16x4*>((uintptr_t)addr_hi));
+  s16x8 r;
+  r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+  r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+  return __builtin_bit_cast(bf16x8_v, r);
+}
+// natural A fragment of k-step ks: row (lane % 32) [+ 32 t by an immediate], head-dim slots 16 ks + 8 (lane / 32) + 0..7.
+// Byte offset inside the tile, lane part only; rows 32 apart share the swizzle
+template <int HD, int SW>
+__device__ __forceinline__ unsigned nat_off(int ks, int lane) { return (unsigned)img_off<HD, SW>(lane & 31, 2 * ks + (lane >> 5)); }
+// transposed A fragment: row = head-dim index 32 i + lane % 32; contraction slot j of lane half h = tile row
+// 16 s + 8 (j >> 2) + 4 h + (j & 3) -- the order in which a 32x32 accumulator leaves its rows in a lane.  Offset of the `lo`
+// read at s = 0 (lane part); with SW = 1 the `hi` read is 8 rows further and step s is 16 s rows further, both immediates
+template <int HD, int SW>
+__device__ __forceinline__ unsigned tr_off(int i, int s, int hi, int lane) {
+  const int g = lane >> 4, c16 = lane & 15;
+  const int col = 32 * i + 16 * (g & 1) + 4 * (c16 & 3);
+  const int r = 16 * s + 8 * hi + 4 * (g >> 1) + (c16 >> 2);
+  return (unsigned)(img_off<HD, SW>(r, col >> 3) + ((col & 7) << 1));
+}
+// B fragment of contraction step h2 (16 rows of a 32-row sub-tile) from a 32x32 accumulator
+__device__ __forceinline__ bf16x8_v frag_from_acc(const f32x16& a, int h2) {
+  const int o = 8 * h2;
+  const uint4 r = make_uint4(pack_bf16x2(a[o + 0], a[o + 1]), pack_bf16x2(a[o + 2], a[o + 3]),
+                             pack_bf16x2(a[o + 4], a[o + 5]), pack_bf16x2(a[o + 6], a[o + 7]));
+  return __builtin_bit_cast(bf16x8_v, r);
+}
+// own-row B fragments (the lane's query / key row, head-dim slots 16 ks + 8 (lane / 32) ..+7) straight from HBM
+template <int HD>
+__device__ __forceinline__ void row_frags(const bf16_t* __restrict__ rowptr, bool valid, int lane, bf16x8_v (&f)[SC<HD>::KS]) {
+#pragma unroll
+  for (int ks = 0; ks < SC<HD>::KS; ++ks) {
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (valid) v = *reinterpret_cast<const uint4*>(rowptr + ks * 16 + (lane >> 5) * 8);
+    f[ks] = __builtin_bit_cast(bf16x8_v, v);
+  }
+}
+__device__ __forceinline__ uint32_t quad_bcast(uint32_t x, int i) {   // value of lane (lane & ~3) + i, i literal 0..3
+  switch (i) {
+    case 0: return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x00, 0xf, 0xf, true);
+    case 1: return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x55, 0xf, 0xf, true);
+    case 2: return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0xAA, 0xf, 0xf, true);
+    default: return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0xFF, 0xf, 0xf, true);
+  }
+}
+
+// lane ^ 32 exchange on the VALU (v_permlane32_swap_b32, new on gfx950): both lanes of a pair end with the pair's maximum / sum.
+// __shfl_xor(x, 32) is a ds_bpermute: an LDS crossbar round trip in the middle of the softmax chain
+__device__ __forceinline__ float pair_max(float x) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float pair_sum(float x) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+// ---- DMA ------------------------------------------------------------------------------------------------------------
+// Issued from inline asm: the compiler's wait-count pass does not see these loads, the only waits are the counted ones
+// below (with the builtin it drains the queue in front of every first LDS read of a stage).  Wave-uniform 64-bit base in
+// SGPRs, 32-bit per-lane byte offset, LDS destination in M0 by register constraint.
+__device__ __forceinline__ void glds16_s(const void* base_uniform, unsigned byte_off, unsigned lds_dst_wave_uniform) {
+  asm volatile("s_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(byte_off), "s"(base_uniform), "{m0}"(lds_dst_wave_uniform) : "memory");
+}
+__device__ __forceinline__ const void* uniform_ptr(const void* p) {
+  const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+  return reinterpret_cast<const void*>(((uintptr_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32)) << 32) |
+                                       (uintptr_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a));
+}
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory"); }
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+  return (unsigned)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) const char*)p);
+}
+// this wave's pieces of one 64-row tile: per-lane byte offsets of the pieces relative to the tile's first row (row stride ldb
+// bytes), computed once; `last` = the same for the last tile of the sequence, whose rows past T - 1 re-read row T - 1
+template <int HD, int NW, int SW>
+__device__ __forceinline__ void dma_offsets(unsigned ldb, int T, int wave, int lane, unsigned (&off)[SC<HD>::PIECES / NW],
+                                            unsigned (&off_last)[SC<HD>::PIECES / NW]) {
+  constexpr int PPW = SC<HD>::PIECES / NW;
+  const int last0 = (T - 1) / KT * KT;
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) {
+    const int p = wave * PPW + i;
+    const int row = p * (1024 / SC<HD>::ROWB) + lane / SC<HD>::CH;
+    const int c = (lane % SC<HD>::CH) ^ swz<HD, SW>(row);
+    off[i] = (unsigned)row * ldb + (unsigned)c * 16u;
+    off_last[i] = (unsigned)(min(last0 + row, T - 1) - last0) * ldb + (unsigned)c * 16u;
+  }
+}
+template <int HD, int NW>
+__device__ __forceinline__ void dma_tile(const void* tile_base_uniform, const unsigned (&off)[SC<HD>::PIECES / NW], unsigned img_lds, int wave) {
+  constexpr int PPW = SC<HD>::PIECES / NW;
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) glds16_s(tile_base_uniform, off[i], __builtin_amdgcn_readfirstlane(img_lds + (wave * PPW + i) * 1024));
+}
+
+// Workgroups are dealt to the 8 XCDs round-robin by linear id.  The workgroups of one (sequence, head) stream the same K / V
+// tiles in the same order: ids n and n + 8 are made the same head, so the second reader of a tile finds it in its XCD's L2 (with
+// the plain grid order the P query blocks of a head sat on P different XCDs and every one of them fetched K / V from HBM).
+// Returns the (sequence * H + head) index and the tile pair of this workgroup; P = pairs per head.
+__device__ __forceinline__ void xcd_remap(int P, int nbh, int& bh, int& pair) {
+  const int n = blockIdx.x;
+  const int grp = 8 * P, full = (nbh / 8) * grp;
+  if (n < full) {
+    const int g = n % grp;
+    bh = (n / grp) * 8 + (g & 7);
+    pair = g >> 3;
+  } else {
+    bh = (nbh / 8) * 8 + (n - full) / P;
+    pair = (n - full) % P;
+  }
+}
+
+// key-bias image of the sequence + one "holds a padded key" flag per 64-key tile (both read by every wave all along)
+template <int NW>
+__device__ __forceinline__ void stage_kbias(const float* __restrict__ kb, int T, float* ldsKb, int* ldsPad, int tid, int lane, int wave) {
+  const int ntile = (T + KT - 1) / KT;
+  for (int j = wave; j < ntile; j += NW) {
+    const int k = j * KT + lane;
+    const float v = k < T ? kb[k] : 0.f;
+    ldsKb[k] = v;
+    const bool any = __builtin_amdgcn_ballot_w64(v != 0.f) != 0;
+    if (lane == 0) ldsPad[j] = any ? 1 : 0;
+  }
+}
+
+// =====================================================================================================================
+// forward: NW waves x 32 queries per block
+// =====================================================================================================================
+template <int HD, bool DROP, int NW, int NST>
+__device__ __forceinline__ void fwd_tile(char* ring, const float* ldsKb, const int* ldsPad, const bf16_t* __restrict__ qkv,
+                                         const int* __restrict__ kstart, bf16_t* __restrict__ out, float* __restrict__ lse,
+                                         int T, int H, float scale, uint32_t drop_thr, uint32_t drop_key, float drop_scale,
+                                         const int tile, const int b, const int h) {
+  using C = SC<HD>;
+  constexpr int QB = 32 * NW, PPW = C::PIECES / NW;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int d = H * HD;
+  const long ld = 3L * d;
+  const unsigned ldb = (unsigned)(ld * 2);
+  const bf16_t* qbase = qkv + (long)b * T * ld + h * HD;
+  const char* kbase = reinterpret_cast<const char*>(qbase + d);
+  const char* vbase = reinterpret_cast<const char*>(qbase + 2 * d);
+  const unsigned ring_lds = lds_addr(ring);
+
+  const int q0 = tile * QB, qw0 = q0 + wave * 32;
+  const int q = qw0 + (lane & 31);
+  const bool qvalid = q < T;
+  bf16x8_v qf[C::KS];
+  row_frags<HD>(qbase + (long)q * ld, qvalid, lane, qf);
+
+  // a block that holds a masked (padded) query row visits every key: those rows see all of them (finite -1e4 scores)
+  int full = 0;
+  for (int j = q0 / KT; j < min((q0 + QB + KT - 1) / KT, (T + KT - 1) / KT); ++j) full |= ldsPad[j];      // block-uniform
+  const bool wave_full = __builtin_amdgcn_ballot_w64(qvalid && ldsKb[min(q, T - 1)] != 0.f) != 0;
+  const int qmax = min(q0 + QB - 1, T - 1);
+  const int ntile = (T + KT - 1) / KT;
+  const int kt_end = full ? ntile : qmax / KT + 1;
+  const int kt_beg = full ? 0 : (kstart ? kstart[b] / KT : 0);
+
+  // per-lane addressing, computed once and kept small (the loop lives at the 256-register limit of two waves per SIMD):
+  //   K fragments (natural reads): ONE base, k-step ks is base ^ (ks << 5) -- the swizzle XORs the chunk index and 2 ks + h differs
+  //     from h in exactly those bits -- sub-tile by immediate;
+  //   V^T fragments (transposed reads): one base per 32-wide head-dim block, key step and lo / hi by immediates;
+  //   DMA: one per-lane offset per operand; piece p adds a wave-uniform row offset (folded into the SGPR base) and, for K, XORs
+  //     its two low chunk bits with p & 3 (rows 4 p .. 4 p + 3: the part of the swizzle that depends on the piece)
+  const unsigned kfrag0 = ring_lds + nat_off<HD, 0>(0, lane);
+  unsigned voff[C::IB];
+#pragma unroll
+  for (int i = 0; i < C::IB; ++i) voff[i] = ring_lds + C::TILE + tr_off<HD, 1>(i, 0, 0, lane);
+  constexpr int RPP = 1024 / C::ROWB;                    // rows per DMA piece
+  const int prow = lane / C::CH;                          // row of this lane inside a piece
+  const unsigned dmaK0 = (unsigned)prow * ldb + (unsigned)(((lane % C::CH) ^ swz<HD, 0>(prow)) << 4);      // piece 0
+  const unsigned dmaV0 = (unsigned)prow * ldb + (unsigned)(((lane % C::CH) ^ swz<HD, 1>(prow)) << 4);      // every piece
+
+  f32x16 o[C::IB];
+#pragma unroll
+  for (int i = 0; i < C::IB; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  const float scale2 = scale * LOG2E;
+
+  auto issue = [&](int kt, int stage) {       // tiles past the end re-fetch the last one: the counted waits stay uniform
+    const int ktc = min(kt, kt_end - 1);
+    const unsigned img = ring_lds + stage * 2 * C::TILE;
+    const bool ragged = (ktc + 1) * KT > T;                // last tile of a sequence whose length is not a multiple of 64
+    const char* kt_k = kbase + (long)ktc * KT * ldb;
+    const char* kt_v = vbase + (long)ktc * KT * ldb;
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      const int p = wave * PPW + i;                          // wave-uniform
+      const unsigned pxor = (unsigned)((swz<HD, 0>(p * RPP) & (C::CH - 1)) << 4);
+      unsigned offK, offV;
+      if (!ragged) {
+        offK = (dmaK0 ^ pxor) + (unsigned)(p * RPP) * ldb;
+        offV = dmaV0 + (unsigned)(p * RPP) * ldb;
+      } else {                                               // rows past T - 1 re-read row T - 1 (finite values under zero weights)
+        const unsigned row = (unsigned)min(p * RPP + prow, T - 1 - ktc * KT);
+        offK = row * ldb + (((dmaK0 ^ pxor) - (unsigned)prow * ldb) & 0xffu);
+        offV = row * ldb + ((dmaV0 - (unsigned)prow * ldb) & 0xffu);
+      }
+      glds16_s(uniform_ptr(kt_k), offK, __builtin_amdgcn_readfirstlane(img + p * 1024));
+      glds16_s(uniform_ptr(kt_v), offV, __builtin_amdgcn_readfirstlane(img + C::TILE + p * 1024));
+    }
+  };
+  if (kt_beg < kt_end) {
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s) issue(kt_beg + s, s);
+  }
+  int stage = 0;
+  // barrier + refill of one tile step; returns the LDS offset of the stage that holds tile kt
+  auto tile_sync = [&](int kt) -> unsigned {
+    if (!(NEKO_AS_DIAG & 1)) wait_vm<(NST - 2) * 2 * PPW>();          // this wave's pieces of tile kt have landed
+    if (!(NEKO_AS_DIAG & 8)) __syncthreads();                         // ... everyone's have, and everyone is done with the stage refilled next
+    if (!(NEKO_AS_DIAG & 1)) {
+      int st_next = stage + NST - 1;
+      if (st_next >= NST) st_next -= NST;
+      issue(kt + NST - 1, st_next);
+    }
+    const unsigned sb = (unsigned)stage * 2u * C::TILE;
+    if (++stage == NST) stage = 0;
+    return sb;
+  };
+  // the common tile: every key visible to every query of the wave, nothing padded
+  auto is_fast = [&](int kt) { return !(NEKO_AS_DIAG & 16) && (kt * KT + KT - 1 <= qw0) && ldsPad[kt] == 0 && (kt * KT + KT <= T); };
+  auto fast_tile = [&](int kt) __attribute__((always_inline)) {
+    const int k0 = kt * KT;
+    const unsigned sb = tile_sync(kt);
+      // ---- the common tile: every key visible to every query of the wave, nothing padded.  Both sub-tiles in one software
+      // pipeline, MFMA groups and the softmax arithmetic of the OTHER sub-tile issued alternately (a wave issues in order: behind
+      // a chain of dependent MFMAs its VALU work would wait for the whole chain, and two waves of a SIMD that run the same
+      // phases in lockstep -- one barrier per tile keeps them there -- only add their times up):
+      //   K reads | S0 chain + V reads(0) | max(0) | S1 chain || exp/sum/pack(0) | max(1) | P.V(0) || exp/sum/pack(1) + V reads(1) | P.V(1)
+      // Register budget (two waves per SIMD: 256): o 64, qf 32, s0 + s1 32, ONE set of K fragments (32: sub-tile 0, reloaded for
+      // sub-tile 1 behind the S0 chain) and ONE set of V^T fragments in two halves (2 x 16: each half reloaded for sub-tile 1 as
+      // soon as the MFMAs of sub-tile 0 that read it are issued).  The sched_barriers fence the phases: left alone, hipcc hoists
+      // every fragment read of the tile to the top and spills.
+      bf16x8_v kfr[C::KS], vA[C::IB], vB[C::IB];
+#pragma unroll
+      for (int ks = 0; ks < C::KS; ++ks) kfr[ks] = lds_read16((kfrag0 + sb) ^ (unsigned)(ks << 5));
+      f32x16 s0, s1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ks = 0; ks < C::KS; ++ks) s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[ks], qf[ks], s0, 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < C::IB; ++i) {
+        const unsigned a0 = voff[i] + sb, a1 = voff[i] + sb + 16 * C::ROWB;
+        vA[i] = lds_read_tr(a0, a0 + 8 * C::ROWB);
+        vB[i] = lds_read_tr(a1, a1 + 8 * C::ROWB);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ks = 0; ks < C::KS; ++ks) kfr[ks] = lds_read16((kfrag0 + sb + 32 * C::ROWB) ^ (unsigned)(ks << 5));
+      __builtin_amdgcn_sched_barrier(0);
+      // row maximum of a sub-tile and the (rare) move of the lazy reference
+      auto move_reference = [&](const f32x16& st) {
+        float mx = fmaxf(fmaxf(st[0], st[1]), st[2]);
+#pragma unroll
+        for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, st[r]), st[r + 1]);
+        mx = pair_max(fmaxf(mx, st[15]));
+        const float cand = mx * scale2;
+        if (__builtin_amdgcn_ballot_w64(cand > m_run + 8.0f) != 0) {
+          const float m_new = fmaxf(m_run, cand);
+          const float alpha = exp2_fast(m_run - m_new);
+          l_run *= alpha;
+#pragma unroll
+          for (int i = 0; i < C::IB; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+          m_run = m_new;
+        }
+      };
+      // probabilities of a sub-tile (in place), row sum, dropout
+      auto probabilities = [&](f32x16& st, int t) {
+        f32x2_v ps = {0.f, 0.f};
+        const f32x2_v sc2 = {scale2, scale2}, nm2 = {-m_run, -m_run};
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const f32x2_v a = __builtin_elementwise_fma((f32x2_v){st[r], st[r + 1]}, sc2, nm2);
+          const f32x2_v e = {exp2_fast(a.x), exp2_fast(a.y)};
+          st[r] = e.x;
+          st[r + 1] = e.y;
+          ps += e;
+        }
+        l_run += ps.x + ps.y;
+        if (DROP) {
+          const uint32_t g0 = ((uint32_t)(b * H + h) * (uint32_t)T + (uint32_t)q) * (uint32_t)((T + 3) >> 2) +
+                              (uint32_t)((k0 + t * 32 + 4 * (lane >> 5)) >> 2);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const uint32_t w = drop_word(g0 + 2 * j, drop_key);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) st[4 * j + e] = drop_byte_keep(w, e, drop_thr) ? st[4 * j + e] : 0.f;
+          }
+        }
+      };
+      move_reference(s0);
+      // S1 chain || probabilities of sub-tile 0
+#pragma unroll
+      for (int ks = 0; ks < C::KS; ++ks) s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[ks], qf[ks], s1, 0, 0, 0);
+      probabilities(s0, 0);
+      const bf16x8_v p00 = frag_from_acc(s0, 0), p01 = frag_from_acc(s0, 1);
+      if (!DROP) {
+#pragma unroll
+        for (int g = 0; g < C::KS; ++g) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 24 / C::KS, 0);
+          __builtin_amdgcn_sched_group_barrier(0x400, 16 / C::KS, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      move_reference(s1);
+      // P.V of sub-tile 0 || probabilities of sub-tile 1
+#pragma unroll
+      for (int i = 0; i < C::IB; ++i) o[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vA[i], p00, o[i], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < C::IB; ++i) {
+        const unsigned a0 = voff[i] + sb + 32 * C::ROWB;
+        vA[i] = lds_read_tr(a0, a0 + 8 * C::ROWB);
+      }
+#pragma unroll
+      for (int i = 0; i < C::IB; ++i) o[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vB[i], p01, o[i], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < C::IB; ++i) {
+        const unsigned a1 = voff[i] + sb + 48 * C::ROWB;
+        vB[i] = lds_read_tr(a1, a1 + 8 * C::ROWB);
+      }
+      probabilities(s1, 1);
+      const bf16x8_v p10 = frag_from_acc(s1, 0), p11 = frag_from_acc(s1, 1);
+      if (!DROP) {
+#pragma unroll
+        for (int g = 0; g < 2 * C::IB; ++g) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 24 / (2 * C::IB), 0);
+          __builtin_amdgcn_sched_group_barrier(0x400, 16 / (2 * C::IB), 0);
+          if (g == C::IB - 1 || g == 2 * C::IB - 1) __builtin_amdgcn_sched_group_barrier(0x100, 2 * C::IB, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < C::IB; ++i) o[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vA[i], p10, o[i], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < C::IB; ++i) o[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vB[i], p11, o[i], 0, 0, 0);
+  };
+  // the rare tile (diagonal, padded keys, ragged end), one sub-tile at a time
+  auto slow_tile = [&](int kt) __attribute__((always_inline)) {
+    const int k0 = kt * KT;
+    const unsigned sb = tile_sync(kt);
+    const bool has_pad = ldsPad[kt] != 0;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      if (!wave_full && k0 + t * 32 > qw0 + 31) continue;     // wave-uniform: nothing visible, no masked row
+      // the rare tile (diagonal, padded keys, ragged end), one sub-tile at a time.  Its per-lane constants are derived from an
+      // opaque copy of the lane id INSIDE the branch: derived from `lane` they are loop invariants, hipcc hoists them out of the
+      // tile loop, they stay live across the common path above and the kernel spills
+      int lane_s = lane;
+      asm volatile("" : "+v"(lane_s));
+      const int q_s = qw0 + (lane_s & 31);
+      f32x16 st;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[r] = 0.f;
+      {
+        // every fragment of the sub-tile is requested before the first MFMA waits for one (left to itself hipcc reuses one
+        // register quad: read, wait, MFMA, read, ... -- an LDS round trip in front of every MFMA)
+        bf16x8_v kfr[C::KS];
+#pragma unroll
+        for (int ks = 0; ks < C::KS; ++ks) kfr[ks] = lds_read16((kfrag0 + sb + t * 32 * C::ROWB) ^ (unsigned)(ks << 5));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < C::KS; ++ks) st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[ks], qf[ks], st, 0, 0, 0);
+      }
+      // the V^T fragments of this sub-tile do not depend on the softmax: requested now, they arrive under its arithmetic
+      bf16x8_v vfr[2][C::IB];
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+        for (int i = 0; i < C::IB; ++i) {
+          const unsigned a = voff[i] + sb + (2 * t + h2) * 16 * C::ROWB;
+          vfr[h2][i] = lds_read_tr(a, a + 8 * C::ROWB);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+      if (!(NEKO_AS_DIAG & 2)) {
+      const bool interior = (k0 + t * 32 + 31 <= qw0) && !has_pad && (k0 + KT <= T);
+      if (!interior) {
+        const int lim_causal = q_s - k0 - t * 32 - 4 * (lane_s >> 5);        // key <= q  <=>  c(r) <= lim_causal
+        const int lim_len = T - 1 - k0 - t * 32 - 4 * (lane_s >> 5);       // key <  T  <=>  c(r) <= lim_len
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int c = (r & 3) + 8 * (r >> 2);
+          float v = (c <= lim_causal) ? st[r] * scale2 : MASK_VAL * LOG2E;
+          v = fmaf(ldsKb[k0 + t * 32 + c + 4 * (lane_s >> 5)], LOG2E, v);       // the image is padded to whole tiles
+          st[r] = (c <= lim_len) ? v : -INFINITY;
+        }
+      }
+      float mx = fmaxf(fmaxf(st[0], st[1]), st[2]);
+#pragma unroll
+      for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, st[r]), st[r + 1]);
+      mx = fmaxf(mx, st[15]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float sc = interior ? scale2 : 1.0f;      // interior scores are still unscaled
+      // lazy rescale (attention.hip): the reference maximum moves only when some row's maximum grew by more than 2^8
+      const float cand = mx * sc;
+      if (__builtin_amdgcn_ballot_w64(cand > m_run + 8.0f) != 0) {
+        const float m_new = fmaxf(m_run, cand);
+        const float alpha = exp2_fast(m_run - m_new);   // 2^(-inf) = 0 on the first tile
+        l_run *= alpha;
+#pragma unroll
+        for (int i = 0; i < C::IB; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+        m_run = m_new;
+      }
+      f32x2_v ps = {0.f, 0.f};
+      const f32x2_v sc2 = {sc, sc}, nm2 = {-m_run, -m_run};
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {       // the exponent arguments and the row sum on the packed fp32 pipe
+        const f32x2_v a = __builtin_elementwise_fma((f32x2_v){st[r], st[r + 1]}, sc2, nm2);
+        const f32x2_v e = {exp2_fast(a.x), exp2_fast(a.y)};
+        st[r] = e.x;
+        st[r + 1] = e.y;
+        ps += e;
+      }
+      l_run += ps.x + ps.y;
+      }
+      if (DROP) {   // attn_dropout on the probabilities (trajectory_gpt2.py:179): the normaliser stays undropped
+        const uint32_t g0 = ((uint32_t)(b * H + h) * (uint32_t)T + (uint32_t)q_s) * (uint32_t)((T + 3) >> 2) +
+                            (uint32_t)((k0 + t * 32 + 4 * (lane_s >> 5)) >> 2);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {          // registers 4j..4j+3 = keys +8j .. +8j+3: one word
+          const uint32_t w = drop_word(g0 + 2 * j, drop_key);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) st[4 * j + e] = drop_byte_keep(w, e, drop_thr) ? st[4 * j + e] : 0.f;   // survivor scale: in the final 1/l
+        }
+      }
+      if (!(NEKO_AS_DIAG & 4))
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2) {
+        const bf16x8_v pf = frag_from_acc(st, h2);
+#pragma unroll
+        for (int i = 0; i < C::IB; ++i) o[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[h2][i], pf, o[i], 0, 0, 0);
+      }
+    }
+  };
+  // Three loops instead of one loop with a branch: [padded prefix] [common tiles] [diagonal and whatever follows].  In one loop
+  // the per-lane constants of the rare path are hoisted, stay live across the common path and the kernel spills (the common
+  // path alone needs 220 registers, the rare one 200, both in one loop body more than 256).  Every wave passes one barrier per
+  // tile whichever loop it is in.
+  int kt = kt_beg;
+  for (; kt < kt_end && !is_fast(kt); ++kt) slow_tile(kt);
+  for (; kt < kt_end && is_fast(kt); ++kt) fast_tile(kt);
+  for (; kt < kt_end; ++kt) slow_tile(kt);
+  wait_vm<0>();
+
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  if (qvalid) {
+    const float inv = (DROP ? drop_scale : 1.0f) / l_tot;
+    bf16_t* orow = out + ((long)b * T + q) * d + h * HD;
+#pragma unroll
+    for (int i = 0; i < C::IB; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        uint2 pk;
+        pk.x = pack_bf16x2(o[i][4 * g + 0] * inv, o[i][4 * g + 1] * inv);
+        pk.y = pack_bf16x2(o[i][4 * g + 2] * inv, o[i][4 * g + 3] * inv);
+        *reinterpret_cast<uint2*>(orow + i * 32 + 8 * g + 4 * (lane >> 5)) = pk;
+      }
+    if (lane < 32) lse[((long)b * H + h) * T + q] = m_run * LN2 + __logf(l_tot);
+  }
+}
+
+template <int HD, bool DROP, int NW, int NST>
+__global__ __launch_bounds__(64 * NW, 2) void attn_fwd_stream_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ kbias,
+                                                                     const int* __restrict__ kstart, bf16_t* __restrict__ out,
+                                                                     float* __restrict__ lse, int B, int T, int H, float scale,
+                                                                     uint32_t drop_thr, uint32_t drop_key, float drop_scale) {
+  extern __shared__ __attribute__((aligned(1024))) char dyn_smem[];
+  char* ring = dyn_smem;                                                        // NST stages of [K tile | V tile]
+  float* ldsKb = reinterpret_cast<float*>(dyn_smem + NST * 2 * SC<HD>::TILE);   // [round_up(T, 64)]
+  int* ldsPad = reinterpret_cast<int*>(ldsKb + (T + KT - 1) / KT * KT);         // [ceil(T / 64)]
+  if (DROP) drop_key += neko_drop_salt();
+  const int tid = threadIdx.x;
+  // one workgroup = a heavy and a light causal tile (G-1-p and p): every workgroup walks the same number of key tiles
+  const int G = (T + 32 * NW - 1) / (32 * NW);
+  int bh, p;
+  xcd_remap((G + 1) / 2, B * H, bh, p);
+  const int b = bh / H, h = bh - b * H;
+  stage_kbias<NW>(kbias + (long)b * T, T, ldsKb, ldsPad, tid, tid & 63, tid >> 6);
+  __syncthreads();
+  const int first = G - 1 - p, second = p;
+  fwd_tile<HD, DROP, NW, NST>(ring, ldsKb, ldsPad, qkv, kstart, out, lse, T, H, scale, drop_thr, drop_key, drop_scale, first, b, h);
+  if (second != first) {
+    __syncthreads();
+    fwd_tile<HD, DROP, NW, NST>(ring, ldsKb, ldsPad, qkv, kstart, out, lse, T, H, scale, drop_thr, drop_key, drop_scale, second, b, h);
+  }
+}
+
+template <int HD, int NW, int NST>
+int fwd_launch(const bf16_t* qkv, const float* kbias, const int* kstart, bf16_t* out, float* lse, int B, int T, int H,
+               int thr, unsigned key, float dscale, hipStream_t s) {
+  const float scale = 1.0f / sqrtf((float)HD);
+  const int G = (T + 32 * NW - 1) / (32 * NW);
+  dim3 grid((unsigned)((long)((G + 1) / 2) * H * B), 1, 1);      // (sequence, head, tile pair) decoded by xcd_remap
+  const int ntile = (T + KT - 1) / KT;
+  const size_t lds = (size_t)NST * 2 * SC<HD>::TILE + (size_t)ntile * KT * 4 + (size_t)ntile * 4;
+  static bool attr_set[2] = {false, false};
+  if (!attr_set[thr ? 1 : 0]) {
+    hipError_t e = thr ? hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_stream_kernel<HD, true, NW, NST>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+                       : hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_stream_kernel<HD, false, NW, NST>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return NEKO_ERR_LAUNCH;
+    attr_set[thr ? 1 : 0] = true;
+  }
+  if (thr)
+    hipLaunchKernelGGL((attn_fwd_stream_kernel<HD, true, NW, NST>), grid, dim3(64 * NW), lds, s, qkv, kbias, kstart, out, lse,
+                       B, T, H, scale, (uint32_t)thr, key, dscale);
+  else
+    hipLaunchKernelGGL((attn_fwd_stream_kernel<HD, false, NW, NST>), grid, dim3(64 * NW), lds, s, qkv, kbias, kstart, out, lse,
+                       B, T, H, scale, 0u, key, dscale);
+  NEKO_CHECK_LAUNCH();
+  return NEKO_OK;
+}
+
+}  // namespace
+
+bool neko_attn_stream_applicable(int T, int hd) { return (hd == 64 || hd == 128) && T >= 1 && T <= TMAX; }
+
+int neko_attn_fwd_stream_impl(const bf16_t* qkv, const float* kbias, const int* kstart, bf16_t* out, float* lse, int B, int T,
+                              int H, int hd, int drop_thr, unsigned drop_key, float drop_scale, hipStream_t s) {
+  static const int nw = [] { const char* e = getenv("NEKO_ATTN_STREAM_WAVES"); return e ? atoi(e) : 8; }();
+  if (hd == 128) {
+    if (nw == 4) return fwd_launch<128, 4, 2>(qkv, kbias, kstart, out, lse, B, T, H, drop_thr, drop_key, drop_scale, s);
+    return fwd_launch<128, 8, 3>(qkv, kbias, kstart, out, lse, B, T, H, drop_thr, drop_key, drop_scale, s);
+  }
+  if (hd == 64) {
+    if (nw == 4) return fwd_launch<64, 4, 3>(qkv, kbias, kstart, out, lse, B, T, H, drop_thr, drop_key, drop_scale, s);
+    return fwd_launch<64, 8, 3>(qkv, kbias, kstart, out, lse, B, T, H, drop_thr, drop_key, drop_scale, s);
+  }
+  return NEKO_ERR_UNSUPPORTED;
+}
+
+NEKO_DEFINE_SALT_SETTER(attention_stream)

@@ -176,6 +176,7 @@ int neko_set_drop_salt(const uint32_t* salt) {
   if (rc == NEKO_OK) rc = neko_set_drop_salt_gemm_glds(salt);
   if (rc == NEKO_OK) rc = neko_set_drop_salt_attention(salt);
   if (rc == NEKO_OK) rc = neko_set_drop_salt_attention_res(salt);
+  if (rc == NEKO_OK) rc = neko_set_drop_salt_attention_stream(salt);
   return rc;
 }
 

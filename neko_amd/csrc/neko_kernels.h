@@ -60,6 +60,9 @@ int neko_attn_bwd_impl(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout,
                        int drop_thr, unsigned drop_key, float drop_scale, const uint32_t* dmask, hipStream_t s);
 int neko_attn_set_path_impl(int mode);
 bool neko_attn_res_applicable(int T, int hd);
+bool neko_attn_stream_applicable(int T, int hd);
+int neko_attn_fwd_stream_impl(const bf16_t* qkv, const float* kbias, const int* kstart, bf16_t* out, float* lse, int B, int T,
+                              int H, int hd, int drop_thr, unsigned drop_key, float drop_scale, hipStream_t s);
 int neko_attn_fwd_res_impl(const bf16_t* qkv, const float* kbias, const int* kstart, bf16_t* out, float* lse, int B, int T,
                            int H, int drop_thr, unsigned drop_key, float drop_scale, uint32_t* dmask, hipStream_t s,
                            const int* seq_off = nullptr, const long long* mask_off = nullptr);
@@ -101,6 +104,7 @@ int neko_set_drop_salt_gemm_bf16(const uint32_t* p);
 int neko_set_drop_salt_gemm_glds(const uint32_t* p);
 int neko_set_drop_salt_attention(const uint32_t* p);
 int neko_set_drop_salt_attention_res(const uint32_t* p);
+int neko_set_drop_salt_attention_stream(const uint32_t* p);
 int neko_patch_resblock_fwd_impl(const void* images, int images_are_u8, int n, int H, int W, const float* w1,
                                  const float* b1, const float* gn_w, const float* gn_b, const float* w2,
                                  const float* b2, int mid_channels, int num_groups, bf16_t* y16, float* x_patches,

@@ -44,8 +44,26 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   const long slice = (long)M * N;
   const int n4 = N >> 2;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+    // eight slices requested before the first is added (S is a run-time value: the plain loop was compiled as one
+    // dependent round trip per slice); the additions keep the slice order, so the sum is the same bits as before
     float4 a = reinterpret_cast<const float4*>(ws)[i];
-    for (int s = 1; s < S; ++s) {
+    int s = 1;
+    for (; s + 8 <= S; s += 8) {
+      float4 b[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) b[u] = reinterpret_cast<const float4*>(ws + (s + u) * slice)[i];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { a.x += b[u].x; a.y += b[u].y; a.z += b[u].z; a.w += b[u].w; }
+    }
+    if (s + 4 <= S) {
+      float4 b[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) b[u] = reinterpret_cast<const float4*>(ws + (s + u) * slice)[i];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { a.x += b[u].x; a.y += b[u].y; a.z += b[u].z; a.w += b[u].w; }
+      s += 4;
+    }
+    for (; s < S; ++s) {
       const float4 b = reinterpret_cast<const float4*>(ws + s * slice)[i];
       a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
     }
@@ -82,7 +100,7 @@ int neko_splitk_reduce_impl(const float* ws, int S, int M, int N, float* C, long
   if (S <= 0 || M <= 0 || N <= 0) return NEKO_OK;
   if (!ws || !C || (N & 3) || (ldc & 3)) return NEKO_ERR_ARG;
   long blocks = ((long)M * N / 4 + 255) / 256;
-  if (blocks > 2048) blocks = 2048;
+  if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, ws, S, M, N, C, ldc, accumulate);
   NEKO_CHECK_LAUNCH();
   return NEKO_OK;

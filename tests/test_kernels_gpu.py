@@ -371,7 +371,7 @@ def attn_path(request, ops):
 @pytest.mark.parametrize("mask_kind", ["none", "left", "right", "holes"])
 @pytest.mark.parametrize("B,T,H,hd", [(2, 40, 2, 32), (3, 200, 4, 32), (2, 333, 2, 64), (1, 130, 2, 128),
                                       (2, 256, 3, 32), (1, 1, 2, 32), (2, 31, 1, 32), (1, 1024, 2, 32),
-                                      (2, 1000, 3, 32), (17, 97, 3, 32)])
+                                      (2, 1000, 3, 32), (17, 97, 3, 32), (2, 1024, 2, 128), (1, 600, 3, 64), (3, 257, 1, 128)])
 def test_attention_fwd_bwd(ops, attn_path, B, T, H, hd, mask_kind):
     if attn_path == "streaming" and hd == 32 and T >= 1000 and mask_kind in ("right", "holes"):
         pytest.skip("large streaming cases are covered by the 'none' and 'left' masks")
