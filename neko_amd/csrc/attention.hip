@@ -746,6 +746,8 @@ int bwd_launch(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const f
   const float scale = 1.0f / sqrtf((float)HD);
   if (neko_attn_path_mode() == 0 && neko_attn_res_applicable(T, HD))
     return neko_attn_bwd_res_impl(qkv, out, dout, kbias, kstart, lse, D, dqkv, B, T, H, thr, key, dscale, dmask, s);
+  if (neko_attn_path_mode() == 0 && neko_attn_stream_applicable(T, HD))      // hd = 64 / 128: DMA-ring kernels (attention_stream.hip)
+    return neko_attn_bwd_stream_impl(qkv, out, dout, kbias, kstart, lse, D, dqkv, B, T, H, HD, thr, key, dscale, s);
   const long total = (long)B * T * H;
   hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, out, dout, kbias, D,
                      qflags, B, T, H, HD, thr ? 1.0f / dscale : 1.0f);

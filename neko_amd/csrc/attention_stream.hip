@@ -182,8 +182,8 @@ __device__ __forceinline__ void stage_kbias(const float* __restrict__ kb, int T,
     const int k = j * KT + lane;
     const float v = k < T ? kb[k] : 0.f;
     ldsKb[k] = v;
-    const bool any = __builtin_amdgcn_ballot_w64(v != 0.f) != 0;
-    if (lane == 0) ldsPad[j] = any ? 1 : 0;
+    const unsigned long long bal = __builtin_amdgcn_ballot_w64(v != 0.f);      // bit t: 32-position half t holds a padded position
+    if (lane == 0) ldsPad[j] = ((uint32_t)bal ? 1 : 0) | ((uint32_t)(bal >> 32) ? 2 : 0);
   }
 }
 
@@ -560,6 +560,447 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_stream_kernel(const bf16_
   }
 }
 
+// =====================================================================================================================
+// backward.  D = sum(dO * O) / s and nothing else comes from the prep kernel of attention.hip; lse and D of the sequence
+// (dK/dV) and the key bias live in LDS for the whole workgroup.
+// =====================================================================================================================
+// one operand stream: 64-row tiles of a [rows, ld] bf16 matrix, read both ways (swizzle kind 0)
+template <int HD, int NW>
+struct TileStream {
+  const char* base;       // (sequence, head) origin of the operand
+  unsigned ldb, lane_off; // row stride in bytes; per-lane offset of DMA piece 0
+  int prow;
+  __device__ __forceinline__ void init(const void* b, long ld_elems, int lane) {
+    base = reinterpret_cast<const char*>(b);
+    ldb = (unsigned)(ld_elems * 2);
+    prow = lane / SC<HD>::CH;
+    lane_off = (unsigned)prow * ldb + (unsigned)(((lane % SC<HD>::CH) ^ swz<HD, 0>(prow)) << 4);
+  }
+  // this wave's pieces of the tile whose first row is row0 (rows past nrows - 1 re-read the last row)
+  __device__ __forceinline__ void issue(int row0, int nrows, unsigned img_lds, int wave) const {
+    constexpr int PPW = SC<HD>::PIECES / NW, RPP = 1024 / SC<HD>::ROWB;
+    const char* tb = base + (long)row0 * ldb;
+    const bool ragged = row0 + KT > nrows;
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      const int p = wave * PPW + i;
+      const unsigned pxor = (unsigned)((swz<HD, 0>(p * RPP) & (SC<HD>::CH - 1)) << 4);
+      unsigned off;
+      if (!ragged) off = (lane_off ^ pxor) + (unsigned)(p * RPP) * ldb;
+      else off = (unsigned)min(p * RPP + prow, nrows - 1 - row0) * ldb + (((lane_off ^ pxor) - (unsigned)prow * ldb) & 0xffu);
+      glds16_s(uniform_ptr(tb), off, __builtin_amdgcn_readfirstlane(img_lds + p * 1024));
+    }
+  }
+};
+// transposed fragment of a kind-0 tile: lo address from tr_off<HD, 0>(i, 0, 0, lane) + 16 s rows; the hi read is 8 rows further,
+// where the swizzle differs in chunk bit 1
+__device__ __forceinline__ bf16x8_v lds_read_tr0(unsigned lo, int rowb) { return lds_read_tr(lo, (lo ^ 32u) + 8u * rowb); }
+
+// ---- dQ: lanes own queries (the forward's geometry) -------------------------------------------------------------------------
+template <int HD, bool DROP, int NW, int NST>
+__device__ __forceinline__ void dq_tile(char* ring, const float* ldsKb, const int* ldsPad, const bf16_t* __restrict__ qkv,
+                                        const bf16_t* __restrict__ dout, const int* __restrict__ kstart,
+                                        const float* __restrict__ lse, const float* __restrict__ Dv, bf16_t* __restrict__ dqkv,
+                                        int T, int H, float scale, uint32_t drop_thr, uint32_t drop_key, float drop_scale,
+                                        const int tile, const int b, const int h) {
+  using C = SC<HD>;
+  constexpr int QB = 32 * NW, PPW = C::PIECES / NW;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int d = H * HD;
+  const long ld = 3L * d;
+  const bf16_t* qbase = qkv + (long)b * T * ld + h * HD;
+  const unsigned ring_lds = lds_addr(ring);
+  TileStream<HD, NW> srcK, srcV;
+  srcK.init(qbase + d, ld, lane);
+  srcV.init(qbase + 2 * d, ld, lane);
+
+  const int q0 = tile * QB, qw0 = q0 + wave * 32;
+  const int q = qw0 + (lane & 31);
+  const bool qvalid = q < T;
+  bf16x8_v qf[C::KS], dof[C::KS];
+  row_frags<HD>(qbase + (long)q * ld, qvalid, lane, qf);
+  row_frags<HD>(dout + ((long)b * T + q) * d + h * HD, qvalid, lane, dof);
+  const float my_lse = (qvalid ? lse[((long)b * H + h) * T + q] : 0.f) * LOG2E;
+  const float my_D = qvalid ? Dv[((long)b * H + h) * T + q] : 0.f;
+  const float scale2 = scale * LOG2E;
+
+  int full = 0;
+  for (int j = q0 / KT; j < min((q0 + QB + KT - 1) / KT, (T + KT - 1) / KT); ++j) full |= ldsPad[j];      // block-uniform
+  const bool wave_full = __builtin_amdgcn_ballot_w64(qvalid && ldsKb[min(q, T - 1)] != 0.f) != 0;
+  const int qmax = min(q0 + QB - 1, T - 1);
+  const int ntile = (T + KT - 1) / KT;
+  const int kt_end = full ? ntile : qmax / KT + 1;
+  const int kt_beg = full ? 0 : (kstart ? kstart[b] / KT : 0);
+
+  const unsigned nat0 = ring_lds + nat_off<HD, 0>(0, lane);      // K (and, + TILE, V) natural fragment of k-step 0; k-step ks: ^ (ks << 5)
+  unsigned ktr[C::IB];                                           // K^T fragment of head-dim block i, key step 0, lo read
+#pragma unroll
+  for (int i = 0; i < C::IB; ++i) ktr[i] = ring_lds + tr_off<HD, 0>(i, 0, 0, lane);
+
+  f32x16 dq[C::IB];
+#pragma unroll
+  for (int i = 0; i < C::IB; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dq[i][r] = 0.f;
+
+  auto issue = [&](int kt, int stage) {
+    const int k0 = min(kt, kt_end - 1) * KT;
+    srcK.issue(k0, T, ring_lds + stage * 2 * C::TILE, wave);
+    srcV.issue(k0, T, ring_lds + stage * 2 * C::TILE + C::TILE, wave);
+  };
+  if (kt_beg < kt_end) {
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s) issue(kt_beg + s, s);
+  }
+  int stage = 0;
+  for (int kt = kt_beg; kt < kt_end; ++kt) {
+    const int k0 = kt * KT;
+    wait_vm<(NST - 2) * 2 * PPW>();
+    __syncthreads();
+    {
+      int st_next = stage + NST - 1;
+      if (st_next >= NST) st_next -= NST;
+      issue(kt + NST - 1, st_next);
+    }
+    const unsigned sb = (unsigned)stage * 2u * C::TILE;
+    const bool has_pad = ldsPad[kt] != 0;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      if (!wave_full && k0 + t * 32 > qw0 + 31) continue;     // wave-uniform: nothing visible, no masked row
+      f32x16 st, dpt;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { st[r] = 0.f; dpt[r] = 0.f; }
+      {
+        bf16x8_v kfr[C::KS], vfr[C::KS];
+#pragma unroll
+        for (int ks = 0; ks < C::KS; ++ks) {
+          kfr[ks] = lds_read16((nat0 + sb + t * 32 * C::ROWB) ^ (unsigned)(ks << 5));
+          vfr[ks] = lds_read16((nat0 + sb + C::TILE + t * 32 * C::ROWB) ^ (unsigned)(ks << 5));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < C::KS; ++ks) {          // two independent accumulation chains
+          st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[ks], qf[ks], st, 0, 0, 0);
+          dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[ks], dof[ks], dpt, 0, 0, 0);
+        }
+      }
+      // K^T fragments of the sub-tile: requested now, they arrive under the elementwise work
+      bf16x8_v ktf[2][C::IB];
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+        for (int i = 0; i < C::IB; ++i) ktf[h2][i] = lds_read_tr0(ktr[i] + sb + (2 * t + h2) * 16 * C::ROWB, C::ROWB);
+      __builtin_amdgcn_sched_barrier(0);
+      // dS^T = P^T o (keep * dP^T - D / s); zero where the score was REPLACED by the causal constant
+      const uint32_t g0 = ((uint32_t)(b * H + h) * (uint32_t)T + (uint32_t)q) * (uint32_t)((T + 3) >> 2) +
+                          (uint32_t)((k0 + t * 32 + 4 * (lane >> 5)) >> 2);
+      const bool interior = (k0 + t * 32 + 31 <= qw0) && !has_pad && (k0 + KT <= T);
+      if (interior) {
+        const float nlse = -my_lse;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const uint32_t w = DROP ? drop_word(g0 + 2 * j, drop_key) : 0u;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * j + e;
+            const float pv = exp2_fast(fmaf(st[r], scale2, nlse));
+            float dpe = dpt[r];
+            if (DROP) dpe = drop_byte_keep(w, e, drop_thr) ? dpe : 0.f;
+            st[r] = pv * (dpe - my_D);
+          }
+        }
+      } else {
+        const int lim_causal = q - k0 - t * 32 - 4 * (lane >> 5);
+        const int lim_len = T - 1 - k0 - t * 32 - 4 * (lane >> 5);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const uint32_t w = DROP ? drop_word(g0 + 2 * j, drop_key) : 0u;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * j + e;
+            const int c = (r & 3) + 8 * (r >> 2);
+            const bool causal_ok = c <= lim_causal;
+            const float sv = fmaf(ldsKb[k0 + t * 32 + c + 4 * (lane >> 5)], LOG2E, causal_ok ? st[r] * scale2 : MASK_VAL * LOG2E);
+            const float pv = exp2_fast((c <= lim_len) ? sv - my_lse : -INFINITY);      // select, not a branch: 2^-inf = 0
+            float dpe = dpt[r];
+            if (DROP) dpe = drop_byte_keep(w, e, drop_thr) ? dpe : 0.f;
+            st[r] = causal_ok ? pv * (dpe - my_D) : 0.f;
+          }
+        }
+      }
+      // dQ^T += K^T . dS^T
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2) {
+        const bf16x8_v df = frag_from_acc(st, h2);
+#pragma unroll
+        for (int i = 0; i < C::IB; ++i) dq[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[h2][i], df, dq[i], 0, 0, 0);
+      }
+    }
+    if (++stage == NST) stage = 0;
+  }
+  wait_vm<0>();
+
+  // dS was formed as P o (keep * dP - D / s): the dropout survivor scale s multiplies the result once, here
+  const float qs = scale * (DROP ? drop_scale : 1.0f);
+  if (qvalid) {
+    bf16_t* orow = dqkv + ((long)b * T + q) * ld + h * HD;
+#pragma unroll
+    for (int i = 0; i < C::IB; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        uint2 pk;
+        pk.x = pack_bf16x2(dq[i][4 * g + 0] * qs, dq[i][4 * g + 1] * qs);
+        pk.y = pack_bf16x2(dq[i][4 * g + 2] * qs, dq[i][4 * g + 3] * qs);
+        *reinterpret_cast<uint2*>(orow + i * 32 + 8 * g + 4 * (lane >> 5)) = pk;
+      }
+  }
+}
+
+template <int HD, bool DROP, int NW, int NST>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void attn_dq_stream_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+                                                                    const float* __restrict__ kbias, const int* __restrict__ kstart,
+                                                                    const float* __restrict__ lse, const float* __restrict__ Dv,
+                                                                    bf16_t* __restrict__ dqkv, int B, int T, int H, float scale,
+                                                                    uint32_t drop_thr, uint32_t drop_key, float drop_scale) {
+  extern __shared__ __attribute__((aligned(1024))) char dyn_smem[];
+  char* ring = dyn_smem;
+  float* ldsKb = reinterpret_cast<float*>(dyn_smem + NST * 2 * SC<HD>::TILE);
+  int* ldsPad = reinterpret_cast<int*>(ldsKb + (T + KT - 1) / KT * KT);
+  if (DROP) drop_key += neko_drop_salt();
+  const int tid = threadIdx.x;
+  const int G = (T + 32 * NW - 1) / (32 * NW);
+  int bh, p;
+  xcd_remap((G + 1) / 2, B * H, bh, p);
+  const int b = bh / H, h = bh - b * H;
+  stage_kbias<NW>(kbias + (long)b * T, T, ldsKb, ldsPad, tid, tid & 63, tid >> 6);
+  __syncthreads();
+  const int first = G - 1 - p, second = p;
+  dq_tile<HD, DROP, NW, NST>(ring, ldsKb, ldsPad, qkv, dout, kstart, lse, Dv, dqkv, T, H, scale, drop_thr, drop_key, drop_scale, first, b, h);
+  if (second != first) {
+    __syncthreads();
+    dq_tile<HD, DROP, NW, NST>(ring, ldsKb, ldsPad, qkv, dout, kstart, lse, Dv, dqkv, T, H, scale, drop_thr, drop_key, drop_scale, second, b, h);
+  }
+}
+
+// ---- dK / dV: lanes own keys, 64-query tiles of Q and dO stream through the ring -------------------------------------------
+template <int HD, bool DROP, int NW, int NST>
+__device__ __forceinline__ void dkv_tile(char* ring, const float* ldsKb, const int* ldsPad, const float* ldsLse, const float* ldsD,
+                                         const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout, bf16_t* __restrict__ dqkv,
+                                         int T, int H, float scale, uint32_t drop_thr, uint32_t drop_key, float drop_scale,
+                                         const int tile, const int b, const int h) {
+  using C = SC<HD>;
+  constexpr int KB = 32 * NW, PPW = C::PIECES / NW;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int d = H * HD;
+  const long ld = 3L * d;
+  const bf16_t* qbase = qkv + (long)b * T * ld + h * HD;
+  const unsigned ring_lds = lds_addr(ring);
+  TileStream<HD, NW> srcQ, srcO;
+  srcQ.init(qbase, ld, lane);
+  srcO.init(dout + (long)b * T * d + h * HD, d, lane);
+
+  const int k0 = tile * KB, kw0 = k0 + wave * 32;
+  const int key = kw0 + (lane & 31);
+  const bool kvalid = key < T;
+  const float my_kb = ldsKb[min(key, T - 1)] * LOG2E * (kvalid ? 1.f : 0.f);
+  const float scale2 = scale * LOG2E;
+  bf16x8_v kf[C::KS], vf[C::KS];
+  row_frags<HD>(qbase + d + (long)key * ld, kvalid, lane, kf);
+  row_frags<HD>(qbase + 2 * d + (long)key * ld, kvalid, lane, vf);
+
+  const unsigned nat0 = ring_lds + nat_off<HD, 0>(0, lane);
+  unsigned qtr[C::IB];
+#pragma unroll
+  for (int i = 0; i < C::IB; ++i) qtr[i] = ring_lds + tr_off<HD, 0>(i, 0, 0, lane);
+
+  f32x16 dk[C::IB], dv[C::IB];
+#pragma unroll
+  for (int i = 0; i < C::IB; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk[i][r] = 0.f; dv[i][r] = 0.f; }
+
+  const int nqt = (T + KT - 1) / KT;
+  const int qt_causal = k0 / KT;      // first query tile that sees this key block causally; earlier ones only through masked query rows
+  auto next_tile = [&](int t) {       // next query tile >= t that has to be visited (block-uniform)
+    while (t < nqt && t < qt_causal && !ldsPad[t]) ++t;
+    return t;
+  };
+  // the visiting order is data dependent: the tiles in flight are kept in a small queue
+  int tq[NST];
+  tq[0] = next_tile(0);
+#pragma unroll
+  for (int s = 1; s < NST; ++s) tq[s] = next_tile(min(tq[s - 1] + 1, nqt));
+  auto issue = [&](int qt, int stage) {
+    const int q0 = min(qt, nqt - 1) * KT;
+    srcQ.issue(q0, T, ring_lds + stage * 2 * C::TILE, wave);
+    srcO.issue(q0, T, ring_lds + stage * 2 * C::TILE + C::TILE, wave);
+  };
+  if (tq[0] < nqt) {
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s) issue(tq[s], s);
+  }
+  int stage = 0;
+  while (tq[0] < nqt) {
+    const int qt = tq[0], q0 = qt * KT;
+    wait_vm<(NST - 2) * 2 * PPW>();
+    __syncthreads();
+    {
+      int st_next = stage + NST - 1;
+      if (st_next >= NST) st_next -= NST;
+      issue(tq[NST - 1], st_next);
+    }
+    const unsigned sb = (unsigned)stage * 2u * C::TILE;
+    const int qfl = ldsPad[qt];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      // wave-uniform skip: no query of the sub-tile sees a key of this wave causally and none is a masked row
+      if (q0 + t * 32 + 31 < kw0 && !((qfl >> t) & 1)) continue;
+      f32x16 st, dpt;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { st[r] = 0.f; dpt[r] = 0.f; }
+      {
+        bf16x8_v qfr[C::KS], ofr[C::KS];
+#pragma unroll
+        for (int ks = 0; ks < C::KS; ++ks) {
+          qfr[ks] = lds_read16((nat0 + sb + t * 32 * C::ROWB) ^ (unsigned)(ks << 5));
+          ofr[ks] = lds_read16((nat0 + sb + C::TILE + t * 32 * C::ROWB) ^ (unsigned)(ks << 5));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < C::KS; ++ks) {
+          st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfr[ks], kf[ks], st, 0, 0, 0);
+          dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ofr[ks], vf[ks], dpt, 0, 0, 0);
+        }
+      }
+      bf16x8_v qtf[2][C::IB], otf[2][C::IB];
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+        for (int i = 0; i < C::IB; ++i) {
+          qtf[h2][i] = lds_read_tr0(qtr[i] + sb + (2 * t + h2) * 16 * C::ROWB, C::ROWB);
+          otf[h2][i] = lds_read_tr0(qtr[i] + sb + C::TILE + (2 * t + h2) * 16 * C::ROWB, C::ROWB);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+      const int lim_causal = q0 + t * 32 + 4 * (lane >> 5) - key;    // key <= query  <=>  -c(r) <= lim_causal
+      const int lim_len = T - 1 - q0 - t * 32 - 4 * (lane >> 5);     // query < T     <=>   c(r) <= lim_len
+      // dropout words: rows of this sub-tile are registers, the 4 lanes of a quad own the 4 keys of one group -> lane
+      // (key & 3) = i hashes rows 4j + i and the quad shares the 16 words by DPP
+      uint32_t mine[4] = {0u, 0u, 0u, 0u};
+      const int ksh = 8 * (lane & 3);
+      if (DROP) {
+        const uint32_t T4 = (uint32_t)((T + 3) >> 2);
+        const uint32_t gq = ((uint32_t)(b * H + h) * (uint32_t)T + (uint32_t)(q0 + t * 32 + 4 * (lane >> 5) + (lane & 3))) * T4 +
+                            (uint32_t)(key >> 2);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mine[j] = drop_word(gq + (uint32_t)(8 * j) * T4, drop_key);    // row c = (lane&3) + 8j
+      }
+      const float* lq = ldsLse + q0 + t * 32 + 4 * (lane >> 5);
+      const float* dq_ = ldsD + q0 + t * 32 + 4 * (lane >> 5);
+      const bool interior = (q0 + t * 32 >= kw0 + 31) && (q0 + t * 32 + 31 < T) && (kw0 + 31 < T) &&
+                            __builtin_amdgcn_ballot_w64(my_kb != 0.f) == 0;
+      if (interior) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int c = (r & 3) + 8 * (r >> 2);
+          const float lse_q = lq[c], d_q = dq_[c];
+          const float pv = exp2_fast(fmaf(st[r], scale2, -lse_q));
+          float pd = pv, dpe = dpt[r];
+          if (DROP) {
+            const bool keep = __builtin_amdgcn_ubfe(quad_bcast(mine[r >> 2], r & 3), ksh, 8) >= drop_thr;
+            pd = keep ? pv : 0.f;
+            dpe = keep ? dpe : 0.f;
+          }
+          st[r] = pd;
+          dpt[r] = pv * (dpe - d_q);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int c = (r & 3) + 8 * (r >> 2);
+          const bool causal_ok = (-c) <= lim_causal;
+          const float sv = (causal_ok ? st[r] * scale2 : MASK_VAL * LOG2E) + my_kb;
+          const float lse_q = lq[c], d_q = dq_[c];            // the arrays are padded to whole tiles
+          const float pv = exp2_fast((c <= lim_len && kvalid) ? sv - lse_q : -INFINITY);        // select: 2^-inf = 0
+          float pd = pv, dpe = dpt[r];
+          if (DROP) {
+            const bool keep = __builtin_amdgcn_ubfe(quad_bcast(mine[r >> 2], r & 3), ksh, 8) >= drop_thr;   // word of row r
+            pd = keep ? pv : 0.f;
+            dpe = keep ? dpe : 0.f;
+          }
+          st[r] = pd;                                              // dropped P (for dV)
+          dpt[r] = causal_ok ? pv * (dpe - d_q) : 0.f;             // dS        (for dK)
+        }
+      }
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2) {
+        const bf16x8_v pf = frag_from_acc(st, h2), df = frag_from_acc(dpt, h2);
+#pragma unroll
+        for (int i = 0; i < C::IB; ++i) {
+          dv[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(otf[h2][i], pf, dv[i], 0, 0, 0);
+          dk[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf[h2][i], df, dk[i], 0, 0, 0);
+        }
+      }
+    }
+    if (++stage == NST) stage = 0;
+#pragma unroll
+    for (int s = 0; s + 1 < NST; ++s) tq[s] = tq[s + 1];
+    tq[NST - 1] = next_tile(min(tq[NST - 1] + 1, nqt));
+  }
+  wait_vm<0>();
+
+  // P and dP were masked but not scaled in the loop (D holds D / s): the survivor scale s is applied once, here
+  const float vsc = DROP ? drop_scale : 1.0f, ksc = scale * vsc;
+  if (kvalid) {
+    bf16_t* krow = dqkv + ((long)b * T + key) * ld + d + h * HD;
+    bf16_t* vrow = krow + d;
+#pragma unroll
+    for (int i = 0; i < C::IB; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        uint2 pk;
+        pk.x = pack_bf16x2(dk[i][4 * g + 0] * ksc, dk[i][4 * g + 1] * ksc);
+        pk.y = pack_bf16x2(dk[i][4 * g + 2] * ksc, dk[i][4 * g + 3] * ksc);
+        *reinterpret_cast<uint2*>(krow + i * 32 + 8 * g + 4 * (lane >> 5)) = pk;
+        pk.x = pack_bf16x2(dv[i][4 * g + 0] * vsc, dv[i][4 * g + 1] * vsc);
+        pk.y = pack_bf16x2(dv[i][4 * g + 2] * vsc, dv[i][4 * g + 3] * vsc);
+        *reinterpret_cast<uint2*>(vrow + i * 32 + 8 * g + 4 * (lane >> 5)) = pk;
+      }
+  }
+}
+
+template <int HD, bool DROP, int NW, int NST>
+__global__ __launch_bounds__(64 * NW, 1) void attn_dkv_stream_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+                                                                     const float* __restrict__ kbias, const float* __restrict__ lse,
+                                                                     const float* __restrict__ Dv, bf16_t* __restrict__ dqkv, int B,
+                                                                     int T, int H, float scale, uint32_t drop_thr, uint32_t drop_key,
+                                                                     float drop_scale) {
+  extern __shared__ __attribute__((aligned(1024))) char dyn_smem[];
+  const int Tp = (T + KT - 1) / KT * KT;
+  char* ring = dyn_smem;                                                        // NST stages of [Q tile | dO tile]
+  float* ldsKb = reinterpret_cast<float*>(dyn_smem + NST * 2 * SC<HD>::TILE);   // [Tp]
+  float* ldsLse = ldsKb + Tp;                                                   // [Tp]  lse * log2(e)
+  float* ldsD = ldsLse + Tp;                                                    // [Tp]  D / s
+  int* ldsPad = reinterpret_cast<int*>(ldsD + Tp);                              // [Tp / 64]  bit t: 32-row half t holds a padded position
+  if (DROP) drop_key += neko_drop_salt();
+  const int tid = threadIdx.x;
+  const int G = (T + 32 * NW - 1) / (32 * NW);
+  int bh, p;
+  xcd_remap((G + 1) / 2, B * H, bh, p);
+  const int b = bh / H, h = bh - b * H;
+  stage_kbias<NW>(kbias + (long)b * T, T, ldsKb, ldsPad, tid, tid & 63, tid >> 6);
+  for (int i = tid; i < Tp; i += 64 * NW) {
+    ldsLse[i] = i < T ? lse[((long)b * H + h) * T + i] * LOG2E : 0.f;
+    ldsD[i] = i < T ? Dv[((long)b * H + h) * T + i] : 0.f;
+  }
+  __syncthreads();
+  const int first = p, second = G - 1 - p;
+  dkv_tile<HD, DROP, NW, NST>(ring, ldsKb, ldsPad, ldsLse, ldsD, qkv, dout, dqkv, T, H, scale, drop_thr, drop_key, drop_scale, first, b, h);
+  if (second != first) {
+    __syncthreads();
+    dkv_tile<HD, DROP, NW, NST>(ring, ldsKb, ldsPad, ldsLse, ldsD, qkv, dout, dqkv, T, H, scale, drop_thr, drop_key, drop_scale, second, b, h);
+  }
+}
+
 template <int HD, int NW, int NST>
 int fwd_launch(const bf16_t* qkv, const float* kbias, const int* kstart, bf16_t* out, float* lse, int B, int T, int H,
                int thr, unsigned key, float dscale, hipStream_t s) {
@@ -587,6 +1028,84 @@ int fwd_launch(const bf16_t* qkv, const float* kbias, const int* kstart, bf16_t*
   return NEKO_OK;
 }
 
+// D[b, h, q] = sum_hd dO * O / s: 8 elements per lane, the HD / 8 lanes of a (row, head) reduce among themselves; every load
+// is a coalesced 16-B piece of the flat [B T, d] arrays (the one-thread-per-(row, head) form of attention.hip walks 256 B per
+// lane at a 256-B lane stride: 82 us at B = 8, H = 16, T = 1024, more than the forward kernel)
+template <int HD>
+__global__ __launch_bounds__(256) void attn_D_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout, float* __restrict__ D,
+                                                    long npieces, int T, int H, float inv_drop_scale) {
+  constexpr int LPH = HD / 8;                 // lanes per (row, head)
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  float acc = 0.f;
+  if (i < npieces) {
+    const uint4 a = reinterpret_cast<const uint4*>(o)[i], g = reinterpret_cast<const uint4*>(dout)[i];
+    const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, gw[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      acc = fmaf(__uint_as_float(aw[e] << 16), __uint_as_float(gw[e] << 16), acc);
+      acc = fmaf(__uint_as_float(aw[e] & 0xffff0000u), __uint_as_float(gw[e] & 0xffff0000u), acc);
+    }
+  }
+#pragma unroll
+  for (int m = 1; m < LPH; m <<= 1) acc += __shfl_xor(acc, m, 64);
+  if (i < npieces && (threadIdx.x & (LPH - 1)) == 0) {
+    const long rh = i / LPH;                  // row * H + head
+    const long row = rh / H;
+    const int h = (int)(rh - row * H);
+    const long b = row / T;
+    const int q = (int)(row - b * T);
+    D[(b * H + h) * T + q] = acc * inv_drop_scale;
+  }
+}
+
+template <typename K>
+int set_lds_limit(K kernel, bool& done) {
+  if (done) return NEKO_OK;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+    return NEKO_ERR_LAUNCH;
+  done = true;
+  return NEKO_OK;
+}
+template <int HD, int NWQ, int NSTQ, int NWK, int NSTK>
+int bwd_launch(const bf16_t* qkv, const bf16_t* dout, const float* kbias, const int* kstart, const float* lse, const float* D,
+               bf16_t* dqkv, int B, int T, int H, int thr, unsigned key, float dscale, hipStream_t s) {
+  const float scale = 1.0f / sqrtf((float)HD);
+  const int ntile = (T + KT - 1) / KT;
+  {
+    const int G = (T + 32 * NWQ - 1) / (32 * NWQ);
+    dim3 grid((unsigned)((long)((G + 1) / 2) * H * B), 1, 1);
+    const size_t lds = (size_t)NSTQ * 2 * SC<HD>::TILE + (size_t)ntile * KT * 4 + (size_t)ntile * 4;
+    static bool done[2] = {false, false};
+    if (thr) {
+      if (set_lds_limit(&attn_dq_stream_kernel<HD, true, NWQ, NSTQ>, done[1]) != NEKO_OK) return NEKO_ERR_LAUNCH;
+      hipLaunchKernelGGL((attn_dq_stream_kernel<HD, true, NWQ, NSTQ>), grid, dim3(64 * NWQ), lds, s, qkv, dout, kbias, kstart, lse, D,
+                         dqkv, B, T, H, scale, (uint32_t)thr, key, dscale);
+    } else {
+      if (set_lds_limit(&attn_dq_stream_kernel<HD, false, NWQ, NSTQ>, done[0]) != NEKO_OK) return NEKO_ERR_LAUNCH;
+      hipLaunchKernelGGL((attn_dq_stream_kernel<HD, false, NWQ, NSTQ>), grid, dim3(64 * NWQ), lds, s, qkv, dout, kbias, kstart, lse, D,
+                         dqkv, B, T, H, scale, 0u, key, dscale);
+    }
+    NEKO_CHECK_LAUNCH();
+  }
+  {
+    const int G = (T + 32 * NWK - 1) / (32 * NWK);
+    dim3 grid((unsigned)((long)((G + 1) / 2) * H * B), 1, 1);
+    const size_t lds = (size_t)NSTK * 2 * SC<HD>::TILE + (size_t)ntile * KT * 4 * 3 + (size_t)ntile * 4;
+    static bool done[2] = {false, false};
+    if (thr) {
+      if (set_lds_limit(&attn_dkv_stream_kernel<HD, true, NWK, NSTK>, done[1]) != NEKO_OK) return NEKO_ERR_LAUNCH;
+      hipLaunchKernelGGL((attn_dkv_stream_kernel<HD, true, NWK, NSTK>), grid, dim3(64 * NWK), lds, s, qkv, dout, kbias, lse, D, dqkv, B,
+                         T, H, scale, (uint32_t)thr, key, dscale);
+    } else {
+      if (set_lds_limit(&attn_dkv_stream_kernel<HD, false, NWK, NSTK>, done[0]) != NEKO_OK) return NEKO_ERR_LAUNCH;
+      hipLaunchKernelGGL((attn_dkv_stream_kernel<HD, false, NWK, NSTK>), grid, dim3(64 * NWK), lds, s, qkv, dout, kbias, lse, D, dqkv, B,
+                         T, H, scale, 0u, key, dscale);
+    }
+    NEKO_CHECK_LAUNCH();
+  }
+  return NEKO_OK;
+}
+
 }  // namespace
 
 bool neko_attn_stream_applicable(int T, int hd) { return (hd == 64 || hd == 128) && T >= 1 && T <= TMAX; }
@@ -602,6 +1121,22 @@ int neko_attn_fwd_stream_impl(const bf16_t* qkv, const float* kbias, const int* 
     if (nw == 4) return fwd_launch<64, 4, 3>(qkv, kbias, kstart, out, lse, B, T, H, drop_thr, drop_key, drop_scale, s);
     return fwd_launch<64, 8, 3>(qkv, kbias, kstart, out, lse, B, T, H, drop_thr, drop_key, drop_scale, s);
   }
+  return NEKO_ERR_UNSUPPORTED;
+}
+
+// D: fp32 workspace [B, H, T]
+int neko_attn_bwd_stream_impl(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const float* kbias, const int* kstart,
+                              const float* lse, float* D, bf16_t* dqkv, int B, int T, int H, int hd, int drop_thr,
+                              unsigned drop_key, float drop_scale, hipStream_t s) {
+  const long npieces = (long)B * T * H * hd / 8;
+  const float inv = drop_thr ? 1.0f / drop_scale : 1.0f;
+  if (hd == 128)
+    hipLaunchKernelGGL((attn_D_kernel<128>), dim3((unsigned)((npieces + 255) / 256)), dim3(256), 0, s, out, dout, D, npieces, T, H, inv);
+  else
+    hipLaunchKernelGGL((attn_D_kernel<64>), dim3((unsigned)((npieces + 255) / 256)), dim3(256), 0, s, out, dout, D, npieces, T, H, inv);
+  NEKO_CHECK_LAUNCH();
+  if (hd == 128) return bwd_launch<128, 4, 2, 4, 3>(qkv, dout, kbias, kstart, lse, D, dqkv, B, T, H, drop_thr, drop_key, drop_scale, s);
+  if (hd == 64) return bwd_launch<64, 4, 3, 4, 3>(qkv, dout, kbias, kstart, lse, D, dqkv, B, T, H, drop_thr, drop_key, drop_scale, s);
   return NEKO_ERR_UNSUPPORTED;
 }
 
