@@ -328,8 +328,16 @@ def main():
 
         def step(i):                               # noqa: F811  (the captured step replaces the eager one)
             return cap.step(batches[i % len(batches)])[0]
+    trace_mode = os.environ.get("NEKO_BENCH_STEP_TIMES", "0")       # diagnosis only: "1" per-step wall times (a sync per step), "2" host enqueue times (no sync)
+    trace_steps = trace_mode == "1"
+    step_ms = []
     for i in range(max(args.warmup, 3 if cap else 0)):
+        ts = time.perf_counter()
         loss = step(i)
+        if trace_steps:
+            torch.cuda.synchronize()
+        if trace_mode != "0":
+            step_ms.append(1e3 * (time.perf_counter() - ts))
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
@@ -337,12 +345,19 @@ def main():
     comm_ev.clear()
     t0 = time.perf_counter()
     for i in range(args.steps):
+        ts = time.perf_counter()
         loss = step(i)
+        if trace_steps:
+            torch.cuda.synchronize()
+        if trace_mode != "0":
+            step_ms.append(1e3 * (time.perf_counter() - ts))
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    if trace_mode != "0" and rank == 0:
+        print("step wall times (ms, warmup then timed): " + " ".join(f"{x:.1f}" for x in step_ms), file=sys.stderr)
     exposed_comm_ms = (sum(a.elapsed_time(b) for a, b in comm_ev) / len(comm_ev)) if comm_ev else 0.0
     if world > 1:
         t = torch.tensor([el], device=dev, dtype=torch.float64)

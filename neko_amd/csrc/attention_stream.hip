@@ -633,9 +633,9 @@ __device__ __forceinline__ void dq_tile(char* ring, const float* ldsKb, const in
   const int kt_beg = full ? 0 : (kstart ? kstart[b] / KT : 0);
 
   const unsigned nat0 = ring_lds + nat_off<HD, 0>(0, lane);      // K (and, + TILE, V) natural fragment of k-step 0; k-step ks: ^ (ks << 5)
-  unsigned ktr[C::IB];                                           // K^T fragment of head-dim block i, key step 0, lo read
+  unsigned ktr[C::IB], ktr_hi[C::IB];                            // K^T fragment of head-dim block i, key step 0: lo / hi read
 #pragma unroll
-  for (int i = 0; i < C::IB; ++i) ktr[i] = ring_lds + tr_off<HD, 0>(i, 0, 0, lane);
+  for (int i = 0; i < C::IB; ++i) { ktr[i] = ring_lds + tr_off<HD, 0>(i, 0, 0, lane); ktr_hi[i] = ring_lds + tr_off<HD, 0>(i, 0, 1, lane); }
 
   f32x16 dq[C::IB];
 #pragma unroll
@@ -664,6 +664,13 @@ __device__ __forceinline__ void dq_tile(char* ring, const float* ldsKb, const in
     }
     const unsigned sb = (unsigned)stage * 2u * C::TILE;
     const bool has_pad = ldsPad[kt] != 0;
+    // the stage's fragment bases, once per tile: every read below is base + immediate (computed per read, the XOR / add pairs were
+    // a third of the kernel's VALU instructions)
+    unsigned nb[C::KS], tlo[C::IB], thi[C::IB];
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) nb[ks] = (nat0 + sb) ^ (unsigned)(ks << 5);
+#pragma unroll
+    for (int i = 0; i < C::IB; ++i) { tlo[i] = ktr[i] + sb; thi[i] = ktr_hi[i] + sb; }
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       if (!wave_full && k0 + t * 32 > qw0 + 31) continue;     // wave-uniform: nothing visible, no masked row
@@ -674,8 +681,8 @@ __device__ __forceinline__ void dq_tile(char* ring, const float* ldsKb, const in
         bf16x8_v kfr[C::KS], vfr[C::KS];
 #pragma unroll
         for (int ks = 0; ks < C::KS; ++ks) {
-          kfr[ks] = lds_read16((nat0 + sb + t * 32 * C::ROWB) ^ (unsigned)(ks << 5));
-          vfr[ks] = lds_read16((nat0 + sb + C::TILE + t * 32 * C::ROWB) ^ (unsigned)(ks << 5));
+          kfr[ks] = lds_read16(nb[ks] + (t * 32 * C::ROWB));
+          vfr[ks] = lds_read16(nb[ks] + (C::TILE + t * 32 * C::ROWB));
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -689,7 +696,7 @@ __device__ __forceinline__ void dq_tile(char* ring, const float* ldsKb, const in
 #pragma unroll
       for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll
-        for (int i = 0; i < C::IB; ++i) ktf[h2][i] = lds_read_tr0(ktr[i] + sb + (2 * t + h2) * 16 * C::ROWB, C::ROWB);
+        for (int i = 0; i < C::IB; ++i) ktf[h2][i] = lds_read_tr(tlo[i] + ((2 * t + h2) * 16 * C::ROWB), thi[i] + ((2 * t + h2) * 16 * C::ROWB));
       __builtin_amdgcn_sched_barrier(0);
       // dS^T = P^T o (keep * dP^T - D / s); zero where the score was REPLACED by the causal constant
       const uint32_t g0 = ((uint32_t)(b * H + h) * (uint32_t)T + (uint32_t)q) * (uint32_t)((T + 3) >> 2) +
@@ -809,9 +816,9 @@ __device__ __forceinline__ void dkv_tile(char* ring, const float* ldsKb, const i
   row_frags<HD>(qbase + 2 * d + (long)key * ld, kvalid, lane, vf);
 
   const unsigned nat0 = ring_lds + nat_off<HD, 0>(0, lane);
-  unsigned qtr[C::IB];
+  unsigned qtr[C::IB], qtr_hi[C::IB];
 #pragma unroll
-  for (int i = 0; i < C::IB; ++i) qtr[i] = ring_lds + tr_off<HD, 0>(i, 0, 0, lane);
+  for (int i = 0; i < C::IB; ++i) { qtr[i] = ring_lds + tr_off<HD, 0>(i, 0, 0, lane); qtr_hi[i] = ring_lds + tr_off<HD, 0>(i, 0, 1, lane); }
 
   f32x16 dk[C::IB], dv[C::IB];
 #pragma unroll
@@ -840,8 +847,8 @@ __device__ __forceinline__ void dkv_tile(char* ring, const float* ldsKb, const i
     for (int s = 0; s < NST - 1; ++s) issue(tq[s], s);
   }
   int stage = 0;
-  while (tq[0] < nqt) {
-    const int qt = tq[0], q0 = qt * KT;
+  // barrier + refill of one tile step; returns the LDS offset of the stage that holds the current tile tq[0]
+  auto tile_sync = [&]() -> unsigned {
     wait_vm<(NST - 2) * 2 * PPW>();
     __syncthreads();
     {
@@ -850,7 +857,167 @@ __device__ __forceinline__ void dkv_tile(char* ring, const float* ldsKb, const i
       issue(tq[NST - 1], st_next);
     }
     const unsigned sb = (unsigned)stage * 2u * C::TILE;
+    if (++stage == NST) stage = 0;
+    return sb;
+  };
+  auto advance = [&]() {
+#pragma unroll
+    for (int s = 0; s + 1 < NST; ++s) tq[s] = tq[s + 1];
+    tq[NST - 1] = next_tile(min(tq[NST - 1] + 1, nqt));
+  };
+  const bool keys_plain = (kw0 + 31 < T) && __builtin_amdgcn_ballot_w64(my_kb != 0.f) == 0;      // no padded / invalid key in this wave
+  // the common tile: every query of the tile sees every key of this wave, nothing padded or ragged
+  auto is_fast = [&](int qt) { return !(NEKO_AS_DIAG & 16) && keys_plain && (qt * KT >= kw0 + 31) && (qt * KT + KT - 1 < T); };
+  // elementwise part of a common sub-tile: st := dropped P, dpt := dS
+  auto elementwise_plain = [&](f32x16& st, f32x16& dpt, int q0, int t) {
+    uint32_t mine[4] = {0u, 0u, 0u, 0u};
+    const int ksh = 8 * (lane & 3);
+    if (DROP) {
+      const uint32_t T4 = (uint32_t)((T + 3) >> 2);
+      const uint32_t gq = ((uint32_t)(b * H + h) * (uint32_t)T + (uint32_t)(q0 + t * 32 + 4 * (lane >> 5) + (lane & 3))) * T4 +
+                          (uint32_t)(key >> 2);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) mine[j] = drop_word(gq + (uint32_t)(8 * j) * T4, drop_key);
+    }
+    // rows (r & 3) + 8 (r >> 2) + 4 h: four consecutive floats per register quad -> one 16-B read each
+    float lq[16], dq_[16];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float4 a = *reinterpret_cast<const float4*>(ldsLse + q0 + t * 32 + 4 * (lane >> 5) + 8 * j);
+      const float4 g = *reinterpret_cast<const float4*>(ldsD + q0 + t * 32 + 4 * (lane >> 5) + 8 * j);
+      lq[4 * j] = a.x; lq[4 * j + 1] = a.y; lq[4 * j + 2] = a.z; lq[4 * j + 3] = a.w;
+      dq_[4 * j] = g.x; dq_[4 * j + 1] = g.y; dq_[4 * j + 2] = g.z; dq_[4 * j + 3] = g.w;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int c = r;
+      const float pv = exp2_fast(fmaf(st[r], scale2, -lq[c]));
+      float pd = pv, dpe = dpt[r];
+      if (DROP) {
+        const bool keep = __builtin_amdgcn_ubfe(quad_bcast(mine[r >> 2], r & 3), ksh, 8) >= drop_thr;
+        pd = keep ? pv : 0.f;
+        dpe = keep ? dpe : 0.f;
+      }
+      st[r] = pd;
+      dpt[r] = pv * (dpe - dq_[c]);
+    }
+  };
+  // Both sub-tiles in one software pipeline (this kernel runs one wave per SIMD: nothing else covers a wave's own chains):
+  //   reads(0) | S0, dP0 chains | S1, dP1 chains || elementwise(0) | dV, dK += (0) || elementwise(1) | dV, dK += (1)
+  auto fast_tile = [&]() __attribute__((always_inline)) {
+    const int q0 = tq[0] * KT;
+    const unsigned sb = tile_sync();
+    unsigned nb[C::KS], tlo[C::IB], thi[C::IB];      // the stage's fragment bases: every read below is base + immediate
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) nb[ks] = (nat0 + sb) ^ (unsigned)(ks << 5);
+#pragma unroll
+    for (int i = 0; i < C::IB; ++i) { tlo[i] = qtr[i] + sb; thi[i] = qtr_hi[i] + sb; }
+    f32x16 s0, p0, s1, p1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s0[r] = 0.f; p0[r] = 0.f; s1[r] = 0.f; p1[r] = 0.f; }
+    {
+      bf16x8_v qfr[C::KS], ofr[C::KS];
+#pragma unroll
+      for (int ks = 0; ks < C::KS; ++ks) {
+        qfr[ks] = lds_read16(nb[ks]);
+        ofr[ks] = lds_read16(nb[ks] + (C::TILE));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ks = 0; ks < C::KS; ++ks) {
+        s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfr[ks], kf[ks], s0, 0, 0, 0);
+        p0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ofr[ks], vf[ks], p0, 0, 0, 0);
+      }
+    }
+    bf16x8_v qtf[2][C::IB], otf[2][C::IB];
+    {
+      bf16x8_v qfr[C::KS], ofr[C::KS];
+#pragma unroll
+      for (int ks = 0; ks < C::KS; ++ks) {
+        qfr[ks] = lds_read16(nb[ks] + (32 * C::ROWB));
+        ofr[ks] = lds_read16(nb[ks] + (C::TILE + 32 * C::ROWB));
+      }
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+        for (int i = 0; i < C::IB; ++i) {
+          qtf[h2][i] = lds_read_tr(tlo[i] + (h2 * 16 * C::ROWB), thi[i] + (h2 * 16 * C::ROWB));
+          otf[h2][i] = lds_read_tr(tlo[i] + (C::TILE + h2 * 16 * C::ROWB), thi[i] + (C::TILE + h2 * 16 * C::ROWB));
+        }
+      __builtin_amdgcn_sched_barrier(0);
+      // S1, dP1 chains || elementwise(0)
+#pragma unroll
+      for (int ks = 0; ks < C::KS; ++ks) {
+        s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfr[ks], kf[ks], s1, 0, 0, 0);
+        p1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ofr[ks], vf[ks], p1, 0, 0, 0);
+      }
+      elementwise_plain(s0, p0, q0, 0);
+      if (!DROP) {
+#pragma unroll
+        for (int g = 0; g < 2 * C::KS; ++g) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+          __builtin_amdgcn_sched_group_barrier(0x400, 1, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    {
+      const bf16x8_v pf0 = frag_from_acc(s0, 0), pf1 = frag_from_acc(s0, 1), df0 = frag_from_acc(p0, 0), df1 = frag_from_acc(p0, 1);
+      // dV, dK += sub-tile 0 || elementwise(1)
+#pragma unroll
+      for (int i = 0; i < C::IB; ++i) {
+        dv[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(otf[0][i], pf0, dv[i], 0, 0, 0);
+        dk[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf[0][i], df0, dk[i], 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < C::IB; ++i) {
+        dv[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(otf[1][i], pf1, dv[i], 0, 0, 0);
+        dk[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf[1][i], df1, dk[i], 0, 0, 0);
+      }
+      elementwise_plain(s1, p1, q0, 1);
+      if (!DROP) {
+#pragma unroll
+        for (int g = 0; g < 4 * C::IB; ++g) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+          __builtin_amdgcn_sched_group_barrier(0x400, 1, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    {
+      bf16x8_v qtg[2][C::IB], otg[2][C::IB];
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+        for (int i = 0; i < C::IB; ++i) {
+          qtg[h2][i] = lds_read_tr(tlo[i] + ((2 + h2) * 16 * C::ROWB), thi[i] + ((2 + h2) * 16 * C::ROWB));
+          otg[h2][i] = lds_read_tr(tlo[i] + (C::TILE + (2 + h2) * 16 * C::ROWB), thi[i] + (C::TILE + (2 + h2) * 16 * C::ROWB));
+        }
+      const bf16x8_v pf0 = frag_from_acc(s1, 0), pf1 = frag_from_acc(s1, 1), df0 = frag_from_acc(p1, 0), df1 = frag_from_acc(p1, 1);
+#pragma unroll
+      for (int i = 0; i < C::IB; ++i) {
+        dv[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(otg[0][i], pf0, dv[i], 0, 0, 0);
+        dk[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtg[0][i], df0, dk[i], 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < C::IB; ++i) {
+        dv[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(otg[1][i], pf1, dv[i], 0, 0, 0);
+        dk[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtg[1][i], df1, dk[i], 0, 0, 0);
+      }
+    }
+    advance();
+  };
+  auto slow_tile = [&]() __attribute__((always_inline)) {
+    const int qt = tq[0], q0 = qt * KT;
+    const unsigned sb = tile_sync();
     const int qfl = ldsPad[qt];
+    unsigned nb[C::KS], tlo[C::IB], thi[C::IB];      // the stage's fragment bases: every read below is base + immediate
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) nb[ks] = (nat0 + sb) ^ (unsigned)(ks << 5);
+#pragma unroll
+    for (int i = 0; i < C::IB; ++i) { tlo[i] = qtr[i] + sb; thi[i] = qtr_hi[i] + sb; }
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       // wave-uniform skip: no query of the sub-tile sees a key of this wave causally and none is a masked row
@@ -862,8 +1029,8 @@ __device__ __forceinline__ void dkv_tile(char* ring, const float* ldsKb, const i
         bf16x8_v qfr[C::KS], ofr[C::KS];
 #pragma unroll
         for (int ks = 0; ks < C::KS; ++ks) {
-          qfr[ks] = lds_read16((nat0 + sb + t * 32 * C::ROWB) ^ (unsigned)(ks << 5));
-          ofr[ks] = lds_read16((nat0 + sb + C::TILE + t * 32 * C::ROWB) ^ (unsigned)(ks << 5));
+          qfr[ks] = lds_read16(nb[ks] + (t * 32 * C::ROWB));
+          ofr[ks] = lds_read16(nb[ks] + (C::TILE + t * 32 * C::ROWB));
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -877,8 +1044,8 @@ __device__ __forceinline__ void dkv_tile(char* ring, const float* ldsKb, const i
       for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll
         for (int i = 0; i < C::IB; ++i) {
-          qtf[h2][i] = lds_read_tr0(qtr[i] + sb + (2 * t + h2) * 16 * C::ROWB, C::ROWB);
-          otf[h2][i] = lds_read_tr0(qtr[i] + sb + C::TILE + (2 * t + h2) * 16 * C::ROWB, C::ROWB);
+          qtf[h2][i] = lds_read_tr(tlo[i] + ((2 * t + h2) * 16 * C::ROWB), thi[i] + ((2 * t + h2) * 16 * C::ROWB));
+          otf[h2][i] = lds_read_tr(tlo[i] + (C::TILE + (2 * t + h2) * 16 * C::ROWB), thi[i] + (C::TILE + (2 * t + h2) * 16 * C::ROWB));
         }
       __builtin_amdgcn_sched_barrier(0);
       const int lim_causal = q0 + t * 32 + 4 * (lane >> 5) - key;    // key <= query  <=>  -c(r) <= lim_causal
@@ -941,11 +1108,11 @@ __device__ __forceinline__ void dkv_tile(char* ring, const float* ldsKb, const i
         }
       }
     }
-    if (++stage == NST) stage = 0;
-#pragma unroll
-    for (int s = 0; s + 1 < NST; ++s) tq[s] = tq[s + 1];
-    tq[NST - 1] = next_tile(min(tq[NST - 1] + 1, nqt));
-  }
+    advance();
+  };
+  while (tq[0] < nqt && !is_fast(tq[0])) slow_tile();
+  while (tq[0] < nqt && is_fast(tq[0])) fast_tile();
+  while (tq[0] < nqt) slow_tile();
   wait_vm<0>();
 
   // P and dP were masked but not scaled in the loop (D holds D / s): the survivor scale s is applied once, here
@@ -1112,7 +1279,8 @@ bool neko_attn_stream_applicable(int T, int hd) { return (hd == 64 || hd == 128)
 
 int neko_attn_fwd_stream_impl(const bf16_t* qkv, const float* kbias, const int* kstart, bf16_t* out, float* lse, int B, int T,
                               int H, int hd, int drop_thr, unsigned drop_key, float drop_scale, hipStream_t s) {
-  static const int nw = [] { const char* e = getenv("NEKO_ATTN_STREAM_WAVES"); return e ? atoi(e) : 8; }();
+  // 4 waves x 2 workgroups per CU measured ahead of 8 waves x 1 (hd = 128: 59 vs 63 us at B = 8, 291 vs 312 at B = 32; hd = 64: 70 vs 81)
+  static const int nw = [] { const char* e = getenv("NEKO_ATTN_STREAM_WAVES"); return e ? atoi(e) : 4; }();
   if (hd == 128) {
     if (nw == 4) return fwd_launch<128, 4, 2>(qkv, kbias, kstart, out, lse, B, T, H, drop_thr, drop_key, drop_scale, s);
     return fwd_launch<128, 8, 3>(qkv, kbias, kstart, out, lse, B, T, H, drop_thr, drop_key, drop_scale, s);
