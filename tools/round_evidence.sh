@@ -12,6 +12,7 @@ for w in c2 c3 c4; do python3 bench.py --workload $w --no-cpu-baseline > gpurun_
 python3 bench.py --model gato-1.2b --workload m-text --batch 8 --steps 10 --warmup 3 > gpurun_out/${tag}_gato1p2b_mtext_b8_bench.json 2>> gpurun_out/${tag}_bench.err
 python3 bench.py --workload c5-mix --batch 32 --no-cpu-baseline > gpurun_out/${tag}_c5mix_pad_bench.json 2>> gpurun_out/${tag}_bench.err
 python3 bench.py --workload c5-mix --batch 32 --ragged-groups 4 --no-cpu-baseline > gpurun_out/${tag}_c5mix_rag4_bench.json 2>> gpurun_out/${tag}_bench.err
+NEKO_ATTN_VARLEN=0 python3 bench.py --workload c5-mix --batch 32 --ragged-groups 4 --no-cpu-baseline > gpurun_out/${tag}_c5mix_rag4_buckets_bench.json 2>> gpurun_out/${tag}_bench.err
 for w in m-mix m-text; do
   s=${w#m-}
   rm -rf gpurun_out/prof_${tag}_$s
@@ -27,9 +28,15 @@ rm -rf gpurun_out/pmcL1 gpurun_out/pmcL2
 bash tools/pmc_gemm.sh > gpurun_out/${tag}_gemm_counters.txt 2>&1
 rm -rf gpurun_out/pmcG_*
 bash tools/pmc_attn.sh $tag 0.1 > /dev/null 2>&1
+bash tools/pmc_attn.sh ${tag}_hd128 0.1 --B 8 --H 16 --hd 128 > /dev/null 2>&1
 python3 tools/gemm_bench.py --iters 30 > gpurun_out/${tag}_gemm_bench.txt 2>&1
 python3 tools/attn_bench.py --drop 0.1 --iters 30 > gpurun_out/${tag}_attn_bench.txt 2>&1
 python3 tools/attn_bench.py --iters 30 >> gpurun_out/${tag}_attn_bench.txt 2>&1
+{ echo "# hd = 128 (configs[4]: 2048d x 16 heads), B = 8, T = 1024: DMA-ring kernels (attention_stream.hip), then the register-staged kernels they replace (--path 1)"
+  python3 tools/attn_bench.py --B 8 --H 16 --hd 128 --iters 30; python3 tools/attn_bench.py --B 8 --H 16 --hd 128 --iters 30 --drop 0.1
+  python3 tools/attn_bench.py --B 8 --H 16 --hd 128 --iters 30 --path 1; python3 tools/attn_bench.py --B 8 --H 16 --hd 128 --iters 30 --drop 0.1 --path 1
+  echo "# hd = 64, B = 8, H = 32"; python3 tools/attn_bench.py --B 8 --H 32 --hd 64 --iters 30; python3 tools/attn_bench.py --B 8 --H 32 --hd 64 --iters 30 --path 1; } > gpurun_out/${tag}_attn_hd128_bench.txt 2>&1
+{ tools/power_probe.sh step python3 bench.py --no-cpu-baseline --steps 150; tools/power_probe.sh sq8k python3 tools/gemm_bench.py --only sq8k --iters 3000; tools/power_probe.sh attn_hd32 python3 tools/attn_bench.py --B 64 --iters 2000 --drop 0.1; } > gpurun_out/${tag}_power_clocks.txt 2>&1
 python3 tools/decode_bench.py > gpurun_out/${tag}_decode_bench.txt 2>&1
 python3 tools/capture_probe.py c2 > gpurun_out/${tag}_capture_probe.txt 2>&1
 echo done
