@@ -10,6 +10,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
 b = lambda n: json.load(open(os.path.join(root, "profiles", f"{tag}_{n}_bench.json")))
 mm, m32, mt, c2, c3, c4 = b("mmix"), b("mmix_b32"), b("mtext"), b("c2"), b("c3"), b("c4")
+g12, c5p, c5r = b("gato1p2b_mtext_b8"), b("c5mix_pad"), b("c5mix_rag4")
 rm = {e["kernel"]: e for e in mm["roofline_more"]}
 
 design = f"""<!-- bench:begin -->
@@ -19,6 +20,8 @@ design = f"""<!-- bench:begin -->
 | m-mix, 32 x 1024 (the r01 default; r01: 23.81 ms, 1.376 M, 0.202) | {m32['ms_per_step']:.2f} | {m32['value']/1e6:.3f} M | {m32['step_mfma_frac']:.3f} |
 | m-text, 64 x 1024 (LM head on every position; r01 at 32: 1.19 M, 0.245) | {mt['ms_per_step']:.2f} | {mt['value']/1e6:.3f} M | {mt['step_mfma_frac']:.3f} |
 | c2 / c3 / c4 (README shapes, 32 sequences) | {c2['ms_per_step']:.2f} / {c3['ms_per_step']:.2f} / {c4['ms_per_step']:.2f} | {c2['value']/1e6:.2f} / {c3['value']/1e6:.2f} / {c4['value']/1e6:.2f} M | {c2['step_mfma_frac']:.3f} / {c3['step_mfma_frac']:.3f} / {c4['step_mfma_frac']:.3f} |
+| configs[4] Gato-1.2B (2048d x 24L x 16H, hd = 128), m-text, 8 x 1024 (r02: 84.5 ms, 0.318) | {g12['ms_per_step']:.2f} | {g12['value']/1e6:.3f} M | {g12['step_mfma_frac']:.3f} |
+| c5-mix (1024 / 494 / 289 / 240-token examples, 8 each): padded layout / 4 length groups, varlen attention | {c5p['ms_per_step']:.2f} / {c5r['ms_per_step']:.2f} | {c5p['real_tokens_per_sec']/1e6:.2f} / {c5r['real_tokens_per_sec']/1e6:.2f} M real tokens/s | {c5p['step_mfma_frac']:.3f} / {c5r['step_mfma_frac']:.3f} |
 
 `roofline` of the bench line (LM-head logits GEMM, HIP events): {mm['roofline']['achieved']:.0f} TFLOP/s = {mm['roofline']['frac']:.3f} of 2.5 PFLOP/s, {mm['roofline']['traffic']/1e6:.0f} MB of
 fabric traffic per launch; `cpu_baseline`: {mm['cpu_baseline']['value']:.0f} tokens/s on {mm['cpu_baseline']['cores']} threads; `roofline_more` (live, B*T = 65536 rows):
