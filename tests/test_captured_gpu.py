@@ -69,11 +69,14 @@ def test_captured_steps_train_like_eager_steps():
     ref, got = torch.stack(ref).cpu(), torch.stack(got).cpu()
     refn, gotn = torch.stack(refn).reshape(-1).cpu(), torch.stack(gotn).reshape(-1).cpu()
     # same kernels, same order; only the fp32 atomics of the embedding / patch-position scatters differ in their last bits,
-    # and Adam normalises that noise: tight while the trajectories are young, tracking afterwards (two EAGER runs of this
-    # recipe differ by the same amounts, tools/determinism_probe.py)
-    assert torch.allclose(got[:7], ref[:7], rtol=2e-5, atol=0), (got, ref)
+    # and Adam normalises that noise: an entry whose gradient IS rounding noise moves by +-lr with a noise-dependent sign.
+    # Two EAGER runs of this very recipe are either bit-identical or, from step 4 on, on a second trajectory (relative loss
+    # differences 6e-8, 8e-6, 3.3e-4, 5e-5, 1e-7, 4.9e-4 at steps 4..9; tools/trajectory_noise_probe.py, 8 runs: 4 of each) --
+    # so the tight gate covers the steps before any run can separate (incl. the first replay) and the loose one the rest.
+    assert torch.allclose(got[:4], ref[:4], rtol=2e-5, atol=0), (got, ref)
     assert torch.allclose(got, ref, rtol=2e-3, atol=0), (got, ref)
-    assert torch.allclose(gotn[:7], refn[:7], rtol=2e-4, atol=0), (gotn, refn)
+    assert torch.allclose(gotn[:4], refn[:4], rtol=2e-4, atol=0), (gotn, refn)
+    assert torch.allclose(gotn, refn, rtol=2e-2, atol=0), (gotn, refn)
     for (k, a), (_, b2) in zip(m1.state_dict().items(), m0.state_dict().items()):
         # (small tensors whose gradient is rounding noise random-walk under Adam: only the weight matrices are compared)
         if a.dtype == torch.float32 and a.numel() >= 4096:

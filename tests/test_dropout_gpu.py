@@ -95,7 +95,7 @@ def test_gemm_epilogue_and_ln_bwd_masks():
 
 
 @pytest.mark.parametrize("path", ["auto", "streaming"])
-@pytest.mark.parametrize("B,T,H,hd", [(2, 96, 2, 32), (1, 200, 2, 64), (2, 301, 3, 32)])
+@pytest.mark.parametrize("B,T,H,hd", [(2, 96, 2, 32), (1, 200, 2, 64), (2, 301, 3, 32), (1, 520, 2, 128), (2, 1024, 1, 128), (1, 777, 2, 64)])
 def test_attention_dropout_fwd_bwd(B, T, H, hd, path):
     from neko_amd import ops
     prev = ops.attn_set_path(1 if path == "streaming" else 0)
