@@ -282,3 +282,56 @@ def test_backward_does_not_depend_on_mask_words_the_forward_never_wrote():
     assert torch.equal(res[0][1], res[1][1])
     ref = ops.attn_bwd(qkv, res[0][0], do, kb, ks, lse, B, T, H, hd, drop=drop, mask=None)       # re-hashing kernels
     assert torch.equal(ref, res[0][1])
+
+
+def mask_attn_varlen(lengths, H, drop):
+    """attention_res.hip's index for packed sequences: unique row id = row0 * H + h * T_b + q (row0 = first row of sequence b),
+    group = row id * ceil(Tmax / 4) + (key >> 2), byte key & 3.  One [H, T_b, T_b] mask per sequence."""
+    T4 = (max(lengths) + 3) // 4
+    out, row0 = [], 0
+    for T in lengths:
+        rows = (np.uint64(row0 * H) + np.arange(H * T, dtype=np.uint64))[:, None]
+        keys = np.arange(T, dtype=np.uint64)[None, :]
+        w = word_np((rows * np.uint64(T4) + (keys >> np.uint64(2))) & M32, drop.key)
+        m = ((w >> (np.uint64(8) * (keys & np.uint64(3)))) & np.uint64(0xFF)) >= np.uint64(drop.thr)
+        out.append(torch.from_numpy(m.astype(np.float32).reshape(1, H, T, T)) * drop.scale)
+        row0 += T
+    return out
+
+
+def test_attention_varlen_with_dropout_vs_oracle():
+    """Packed sequences of different lengths (one of them left-padded) in ONE launch with attention dropout: forward and
+    backward against the oracle fed with the host restatement of the kernels' keep decisions, per sequence."""
+    from neko_amd import ops
+    H, hd = 2, 32
+    d = H * hd
+    lengths, pads = [200, 1024, 47, 333], [0, 0, 5, 12]
+    rows = sum(lengths)
+    g = torch.Generator().manual_seed(77)
+    qkv = rb(torch.randn(rows, 3 * d, generator=g))
+    do = rb(torch.randn(rows, d, generator=g))
+    drop = ops.Drop(0.1, 0x5EEDF00D)
+    masks = mask_attn_varlen(lengths, H, drop)
+    kbs, kss = [], []
+    for T, pad in zip(lengths, pads):
+        m = torch.ones(1, T); m[0, :pad] = 0
+        kb, ks = ops.mask_bias(m.to(DEV))
+        kbs.append(kb.reshape(-1)); kss.append(ks.reshape(-1))
+    geom = ops.VarlenGeom(lengths, H, DEV)
+    qd = qkv.to(torch.bfloat16).to(DEV).contiguous()
+    dod = do.to(torch.bfloat16).to(DEV).contiguous()
+    out, lse, kept = ops.attn_fwd_varlen(qd, torch.cat(kbs), torch.cat(kss), geom, hd, drop=drop, want_mask=True)
+    dqkv = ops.attn_bwd_varlen(qd, out, dod, torch.cat(kbs), torch.cat(kss), lse, geom, hd, drop=drop, mask=kept)
+    r0 = 0
+    for i, (T, pad) in enumerate(zip(lengths, pads)):
+        leaf = qkv[r0:r0 + T].clone().view(1, T, 3 * d).requires_grad_(True)
+        q, k, v = leaf.split(d, dim=2)
+        sh = lambda t: t.view(1, T, H, hd).permute(0, 2, 1, 3)
+        mask = torch.ones(1, T); mask[0, :pad] = 0
+        o_ref = O.attention_core(sh(q), sh(k), sh(v), mask, drop_mask=masks[i]).permute(0, 2, 1, 3).reshape(1, T, d)
+        o_ref.backward(do[r0:r0 + T].view(1, T, d))
+        sc = float(o_ref.detach().abs().max())
+        assert float((out[r0:r0 + T].float().cpu() - o_ref.detach()[0]).abs().max()) < 1e-2 * sc, f"out of sequence {i}"
+        gs = float(leaf.grad.abs().max())
+        assert float((dqkv[r0:r0 + T].float().cpu() - leaf.grad[0]).abs().max()) < 2e-2 * gs, f"dqkv of sequence {i}"
+        r0 += T
