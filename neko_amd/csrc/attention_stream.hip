@@ -300,8 +300,11 @@ __device__ __forceinline__ void fwd_tile(char* ring, const float* ldsKb, const i
       // soon as the MFMAs of sub-tile 0 that read it are issued).  The sched_barriers fence the phases: left alone, hipcc hoists
       // every fragment read of the tile to the top and spills.
       bf16x8_v kfr[C::KS], vA[C::IB], vB[C::IB];
+      unsigned kbase[C::KS];                    // the stage's K fragment bases, once per tile: both sub-tiles read base + immediate
 #pragma unroll
-      for (int ks = 0; ks < C::KS; ++ks) kfr[ks] = lds_read16((kfrag0 + sb) ^ (unsigned)(ks << 5));
+      for (int ks = 0; ks < C::KS; ++ks) kbase[ks] = (kfrag0 + sb) ^ (unsigned)(ks << 5);
+#pragma unroll
+      for (int ks = 0; ks < C::KS; ++ks) kfr[ks] = lds_read16(kbase[ks]);
       f32x16 s0, s1;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
@@ -316,7 +319,7 @@ __device__ __forceinline__ void fwd_tile(char* ring, const float* ldsKb, const i
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int ks = 0; ks < C::KS; ++ks) kfr[ks] = lds_read16((kfrag0 + sb + 32 * C::ROWB) ^ (unsigned)(ks << 5));
+      for (int ks = 0; ks < C::KS; ++ks) kfr[ks] = lds_read16(kbase[ks] + 32 * C::ROWB);
       __builtin_amdgcn_sched_barrier(0);
       // row maximum of a sub-tile and the (rare) move of the lazy reference
       auto move_reference = [&](const f32x16& st) {
@@ -678,25 +681,26 @@ __device__ __forceinline__ void dq_tile(char* ring, const float* ldsKb, const in
 #pragma unroll
       for (int r = 0; r < 16; ++r) { st[r] = 0.f; dpt[r] = 0.f; }
       {
-        bf16x8_v kfr[C::KS], vfr[C::KS];
+        // the two score chains one after the other, V fragments into the registers the K fragments leave (two waves per SIMD: 256
+        // registers; both fragment sets live at once need 300 and one wave per SIMD)
+        bf16x8_v fr[C::KS];
 #pragma unroll
-        for (int ks = 0; ks < C::KS; ++ks) {
-          kfr[ks] = lds_read16(nb[ks] + (t * 32 * C::ROWB));
-          vfr[ks] = lds_read16(nb[ks] + (C::TILE + t * 32 * C::ROWB));
-        }
+        for (int ks = 0; ks < C::KS; ++ks) fr[ks] = lds_read16(nb[ks] + (t * 32 * C::ROWB));
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int ks = 0; ks < C::KS; ++ks) {          // two independent accumulation chains
-          st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[ks], qf[ks], st, 0, 0, 0);
-          dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[ks], dof[ks], dpt, 0, 0, 0);
-        }
+        for (int ks = 0; ks < C::KS; ++ks) st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[ks], qf[ks], st, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < C::KS; ++ks) fr[ks] = lds_read16(nb[ks] + (C::TILE + t * 32 * C::ROWB));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < C::KS; ++ks) dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[ks], dof[ks], dpt, 0, 0, 0);
       }
-      // K^T fragments of the sub-tile: requested now, they arrive under the elementwise work
-      bf16x8_v ktf[2][C::IB];
+      // K^T fragments of the first key half of the sub-tile: requested now, they arrive under the elementwise work (the second
+      // half is requested behind the first half's MFMAs, into the same registers)
+      bf16x8_v ktf[C::IB];
 #pragma unroll
-      for (int h2 = 0; h2 < 2; ++h2)
-#pragma unroll
-        for (int i = 0; i < C::IB; ++i) ktf[h2][i] = lds_read_tr(tlo[i] + ((2 * t + h2) * 16 * C::ROWB), thi[i] + ((2 * t + h2) * 16 * C::ROWB));
+      for (int i = 0; i < C::IB; ++i) ktf[i] = lds_read_tr(tlo[i] + ((2 * t) * 16 * C::ROWB), thi[i] + ((2 * t) * 16 * C::ROWB));
       __builtin_amdgcn_sched_barrier(0);
       // dS^T = P^T o (keep * dP^T - D / s); zero where the score was REPLACED by the causal constant
       const uint32_t g0 = ((uint32_t)(b * H + h) * (uint32_t)T + (uint32_t)q) * (uint32_t)((T + 3) >> 2) +
@@ -736,11 +740,16 @@ __device__ __forceinline__ void dq_tile(char* ring, const float* ldsKb, const in
         }
       }
       // dQ^T += K^T . dS^T
+      {
+        const bf16x8_v df0 = frag_from_acc(st, 0), df1 = frag_from_acc(st, 1);
 #pragma unroll
-      for (int h2 = 0; h2 < 2; ++h2) {
-        const bf16x8_v df = frag_from_acc(st, h2);
+        for (int i = 0; i < C::IB; ++i) dq[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[i], df0, dq[i], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < C::IB; ++i) dq[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[h2][i], df, dq[i], 0, 0, 0);
+        for (int i = 0; i < C::IB; ++i) ktf[i] = lds_read_tr(tlo[i] + ((2 * t + 1) * 16 * C::ROWB), thi[i] + ((2 * t + 1) * 16 * C::ROWB));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < C::IB; ++i) dq[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[i], df1, dq[i], 0, 0, 0);
       }
     }
     if (++stage == NST) stage = 0;
@@ -764,7 +773,9 @@ __device__ __forceinline__ void dq_tile(char* ring, const float* ldsKb, const in
 }
 
 template <int HD, bool DROP, int NW, int NST>
-__global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void attn_dq_stream_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+// two waves per SIMD where the body fits 256 registers: the dropout variant at hd = 128 does (5 spilled registers, 273 -> 254 us for the
+// whole backward), the plain one does not (118 spilled: 96 -> 158 us) and keeps one wave per SIMD
+__global__ __launch_bounds__(64 * NW, (HD <= 64 || DROP) ? 2 : 1) void attn_dq_stream_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                                     const float* __restrict__ kbias, const int* __restrict__ kstart,
                                                                     const float* __restrict__ lse, const float* __restrict__ Dv,
                                                                     bf16_t* __restrict__ dqkv, int B, int T, int H, float scale,
