@@ -753,3 +753,27 @@ def test_attention_varlen_dropout_masks_are_consistent(ops):
     assert float((out.float() - out0.float()).abs().mean()) < 0.35 * float(out0.float().abs().mean())
     out2, lse2, mk2 = ops.attn_fwd_varlen(qkv, kb, ks, geom, hd, drop=drop, want_mask=True)
     assert torch.equal(out, out2) and torch.equal(lse, lse2)
+
+
+@pytest.mark.parametrize("T,hd,mask_kind", [(2048, 128, "left"), (1500, 64, "holes"), (4096, 128, "none"), (4100, 128, "left")])
+def test_attention_long_sequences_wide_heads(ops, T, hd, mask_kind):
+    """Sequences beyond the reference's context length on the wide-head kernels: up to T = 4096 the DMA-ring kernels keep the key
+    bias / lse / D of the whole sequence in LDS (attention_stream.hip), beyond it the dispatcher falls back to the register-staged
+    kernels -- both against the oracle."""
+    B, H = 1, 1
+    g = torch.Generator().manual_seed(T + hd)
+    d = H * hd
+    qkv = rb(torch.randn(B, T, 3 * d, generator=g))
+    mask = _masks(B, T, mask_kind)
+    do = rb(torch.randn(B, T, d, generator=g))
+    leaf = qkv.clone().requires_grad_(True)
+    q, k, v = leaf.split(d, dim=2)
+    sh = lambda t: t.view(B, T, H, hd).permute(0, 2, 1, 3)
+    o_ref = O.attention_core(sh(q), sh(k), sh(v), mask).permute(0, 2, 1, 3).reshape(B, T, d)
+    o_ref.backward(do)
+    kb, ks = ops.mask_bias(mask.to(DEV))
+    qkv_d = bf(qkv.view(B * T, 3 * d))
+    out, lse = ops.attn_fwd(qkv_d, kb, ks, B, T, H, hd)
+    close(out.view(B, T, d), o_ref, 2 ** -7, 4e-3 * float(o_ref.abs().max()), "attn out")
+    dqkv = ops.attn_bwd(qkv_d, out, bf(do.view(B * T, d)), kb, ks, lse, B, T, H, hd)
+    close(dqkv.view(B, T, 3 * d), leaf.grad, 2 ** -6, 1e-2 * float(leaf.grad.abs().max()), "attn dqkv")
