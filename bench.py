@@ -404,7 +404,9 @@ def main():
         lp = model.last_pack
         lm_frac = (lp.n_loss / float(B * Tlen)) if (lp is not None and lp.n_loss > 0 and model.lm_head_selected_rows) else 1.0
         fpt = 3 * flops_per_token_fwd(d=D, layers=L, t=Tlen, lm_rows_frac=lm_frac)
-        dom = time_dominant_kernel(model, min(4096, B * Tlen))
+        # the launch the step itself makes: every loss row of the batch in one logits GEMM, up to lm_head_chunk_rows
+        n_rows = (max(64, (lp.n_loss + 63) // 64 * 64) if (lp is not None and lp.n_loss > 0 and model.lm_head_selected_rows) else B * Tlen)
+        dom = time_dominant_kernel(model, min(model.lm_head_chunk_rows, n_rows))
         # HBM bytes per launch of that kernel: PMC counters cannot be collected from inside the timed process, so the
         # number is the committed rocprofv3 --pmc measurement of the same call (tools/pmc_lmhead.sh), null if absent
         traffic, traffic_src = None, None

@@ -585,7 +585,7 @@ def lm_head_loss(Hp: HeadParams, hf16: torch.Tensor, target: torch.Tensor, sel: 
     dev = hf16.device
     weight = sel / count.clamp(min=1.0)
     loss_rows = torch.empty(M, dtype=F32, device=dev)
-    R = min(chunk_rows, M)
+    R = min(chunk_rows if want_grad else min(chunk_rows, 4096), M)      # without a gradient the logits live in an R-row scratch buffer
     # the GEMM writes bf16 logits straight into the gradient buffer and the CE kernel turns them into dlogits in place
     # (fp32 logits never reach HBM); without a gradient one chunk-sized scratch buffer is reused
     dlogits = torch.empty(M if want_grad else R, Hp.Vpad, dtype=BF16, device=dev)

@@ -447,7 +447,11 @@ class GatoPolicy(nn.Module):
         self.use_pos_encoding = use_pos_encoding
         self.pos_embed_observation = nn.Embedding(context_len, embed_dim)            # :149
 
-        self.lm_head_chunk_rows = int(os.environ.get("NEKO_LM_CHUNK_ROWS", "4096"))
+        # rows per LM-head logits / cross-entropy launch.  Training writes the logits straight into the (already allocated)
+        # dlogits buffer, so the chunk costs no memory: 32768 = one or two launches per step measured 0.2-0.3 ms ahead of 4096
+        # on the m-mix step (39.28 / 39.35 -> 39.12 / 39.05 ms, profiles/r03_step_ab.txt); a forward without gradient keeps a
+        # 4096-row scratch (engine.lm_head_loss)
+        self.lm_head_chunk_rows = int(os.environ.get("NEKO_LM_CHUNK_ROWS", "32768"))
         self.lm_head_selected_rows = True   # LM head only at loss positions when they are known on the host
         #: > 0: training forwards (compute_loss=True, return_logits=False) pack the batch into at most this many length
         #: buckets instead of left-padding every example to the longest one (misc/todo.md:11);

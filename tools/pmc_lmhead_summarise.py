@@ -27,7 +27,8 @@ fcorr = cast_read / (res["FETCH_SIZE"]["cast"] * 1024)
 wcorr = cast_write / (res["WRITE_SIZE"]["cast"] * 1024)
 fetch = res["FETCH_SIZE"]["gemm"] * 1024 * fcorr
 write = res["WRITE_SIZE"]["gemm"] * 1024 * wcorr
-M, V, VP, K = 4096, 52305, 52352, 768
+M = int(sys.argv[2]) if len(sys.argv) > 2 else 22720      # rows of the probed launch (tools/lmhead_probe.py)
+V, VP, K = 52305, 52352, 768
 out = {
     "kernel": "gemm_glds_kernel<A k-contig, B k-contig> (LM head logits, bf16 out, N = Vpad)",
     "shape_MNK": [M, V, K], "computed_columns": VP,

@@ -12,6 +12,8 @@ b = lambda n: json.load(open(os.path.join(root, "profiles", f"{tag}_{n}_bench.js
 mm, m32, mt, c2, c3, c4 = b("mmix"), b("mmix_b32"), b("mtext"), b("c2"), b("c3"), b("c4")
 g12, c5p, c5r = b("gato1p2b_mtext_b8"), b("c5mix_pad"), b("c5mix_rag4")
 rm = {e["kernel"]: e for e in mm["roofline_more"]}
+traffic = mm['roofline']['traffic'] or json.load(open(os.path.join(root, 'profiles', f'{tag}_lmhead_traffic.json')))['traffic_bytes_per_launch']
+shape = mm['roofline'].get('shape_MNK', [4096, 52305, 768])
 
 design = f"""<!-- bench:begin -->
 | workload (1 x MI355X, dropout 0.1, fwd + bwd + clip + AdamW, synthetic data; `profiles/{tag}_*`) | ms / step | tokens/s | step MFMA fraction |
@@ -23,8 +25,8 @@ design = f"""<!-- bench:begin -->
 | configs[4] Gato-1.2B (2048d x 24L x 16H, hd = 128), m-text, 8 x 1024 (r02: 84.5 ms, 0.318) | {g12['ms_per_step']:.2f} | {g12['value']/1e6:.3f} M | {g12['step_mfma_frac']:.3f} |
 | c5-mix (1024 / 494 / 289 / 240-token examples, 8 each): padded layout / 4 length groups, varlen attention | {c5p['ms_per_step']:.2f} / {c5r['ms_per_step']:.2f} | {c5p['real_tokens_per_sec']/1e6:.2f} / {c5r['real_tokens_per_sec']/1e6:.2f} M real tokens/s | {c5p['step_mfma_frac']:.3f} / {c5r['step_mfma_frac']:.3f} |
 
-`roofline` of the bench line (LM-head logits GEMM, HIP events): {mm['roofline']['achieved']:.0f} TFLOP/s = {mm['roofline']['frac']:.3f} of 2.5 PFLOP/s, {mm['roofline']['traffic']/1e6:.0f} MB of
-fabric traffic per launch; `cpu_baseline`: {mm['cpu_baseline']['value']:.0f} tokens/s on {mm['cpu_baseline']['cores']} threads; `roofline_more` (live, B*T = 65536 rows):
+`roofline` of the bench line (LM-head logits GEMM {shape[0]} x {shape[1]} x {shape[2]}, HIP events): {mm['roofline']['achieved']:.0f} TFLOP/s = {mm['roofline']['frac']:.3f} of 2.5 PFLOP/s, {traffic/1e6:.0f} MB of
+fabric traffic per launch (`profiles/{tag}_lmhead_traffic.json`); `cpu_baseline`: {mm['cpu_baseline']['value']:.0f} tokens/s on {mm['cpu_baseline']['cores']} threads; `roofline_more` (live, B*T = 65536 rows):
 
 | kernel | us | TFLOP/s (useful) | of 2.5 PF |
 |---|---|---|---|
