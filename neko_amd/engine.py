@@ -134,7 +134,14 @@ class SideStream:
     fork(fn, *temps): fn's launches run on the side stream after everything enqueued so far on the current stream;
     `temps` are tensors that may be freed before join() (their blocks must not be recycled under the side kernels).
     join(): the current stream waits for the side stream.  NEKO_WGRAD_STREAM=0 keeps everything on one stream."""
-    enabled = os.environ.get("NEKO_WGRAD_STREAM", "1") != "0"
+    enabled = os.environ.get("NEKO_WGRAD_STREAM", "auto") != "0"
+    # "auto" (default): the side stream is used only for steps of fewer than ONE_STREAM_ROWS rows.  Round 3, same-box A/B: at
+    # 65536 rows one stream is 0.4 ms FASTER (38.38 vs 38.78 ms; 32768 rows: 21.02 vs 21.15), at 7680 / 8192 rows the side stream
+    # wins (c2 5.90 vs 6.07 ms, Gato-1.2B 78.7 vs 80.8) -- the chip runs these kernels at its power limit, so a second GEMM
+    # beside a full-grid one only adds L2 contention; it pays where the chain's launches leave CUs idle (profiles/r03_step_ab.txt).
+    auto = os.environ.get("NEKO_WGRAD_STREAM", "auto") == "auto"
+    ONE_STREAM_ROWS = int(os.environ.get("NEKO_WGRAD_ONE_STREAM_ROWS", "20000"))
+    rows_hint = 0            # rows of the step being differentiated (set by the backward entry points)
     _streams: dict = {}
     _dirty: dict = {}
 
@@ -148,7 +155,7 @@ class SideStream:
     @classmethod
     def fork(cls, fn: Callable[[], None], *temps: torch.Tensor) -> None:
         dev = temps[0].device if temps else torch.device("cuda", torch.cuda.current_device())
-        if not cls.enabled or dev.type != "cuda":
+        if not cls.enabled or dev.type != "cuda" or (cls.auto and cls.rows_hint >= cls.ONE_STREAM_ROWS):
             fn()
             return
         side = cls._get(dev)
@@ -342,6 +349,7 @@ def stack_backward(P: StackParams, ctx: StackCtx, dhf: torch.Tensor,
     the data-parallel reducer hooks its bucket launches there."""
     B, T = ctx.B, ctx.T
     M = B * T
+    SideStream.rows_hint = M
     d, H = P.d, P.heads
     hd = d // H
     dev = dhf.device

@@ -290,6 +290,7 @@ class _PolicyCoreFn(torch.autograd.Function):
         names = policy.transformer._param_names() + ["predict_token.weight"]
         f.prepare_backward(names)
         dp = policy._dp
+        engine.SideStream.rows_hint = B * T        # rows of this step: decides whether weight gradients fork onto the side stream
         if ctx.sel_idx is not None:
             dhf = engine.lm_head_backward_selected(policy._head_params(), ctx.hf16, ctx.dlogits, g_loss, ctx.sel_idx,
                                                    ctx.sel_n, B * T)
