@@ -18,7 +18,7 @@ for w in m-mix m-text; do
   rm -rf gpurun_out/prof_${tag}_$s
   NEKO_WGRAD_STREAM=0 rocprofv3 --kernel-trace -d gpurun_out/prof_${tag}_$s -o $s -- python3 bench.py --workload $w --steps 3 --warmup 10 --no-cpu-baseline > gpurun_out/prof_${tag}_$s.log 2>&1
   db=$(find gpurun_out/prof_${tag}_$s -name "*.db" | head -1)
-  { echo "# NEKO_WGRAD_STREAM=0 (one stream: kernels do not overlap; the bench lines of this round use the default two streams); B = 64 x T = 1024 per step"; python3 tools/rocpd_stats.py $db 45; } > gpurun_out/${tag}_m${s}_kernel_stats.txt 2>&1
+  { echo "# NEKO_WGRAD_STREAM=0 (one stream: kernels do not overlap; the default (auto) is one stream too at these 65536 rows per step); B = 64 x T = 1024 per step"; python3 tools/rocpd_stats.py $db 45; } > gpurun_out/${tag}_m${s}_kernel_stats.txt 2>&1
   rm -rf gpurun_out/prof_${tag}_$s
 done
 bash tools/pmc_step.sh $tag > gpurun_out/${tag}_pmc_step.log 2>&1
