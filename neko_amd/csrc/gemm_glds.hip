@@ -203,7 +203,10 @@ __device__ __forceinline__ void wait_dma_only_and_barrier() {
 // nearly every panel of every slice: the fc / proj weight gradients moved 730 MB over the fabric for 250 MB of operands.)
 template <int BM, int BN>
 __device__ __forceinline__ void tile_coords(const GemmArgs& p, int& tm, int& tn, int& slice) {
-  constexpr int GROUP_M = 8;
+#ifndef NEKO_GEMM_GROUP_M
+#define NEKO_GEMM_GROUP_M 8        // row panels per rasterisation group (4 / 16 measured in round 3: profiles/r03_step_ab.txt)
+#endif
+  constexpr int GROUP_M = NEKO_GEMM_GROUP_M;
   const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
   int bid = xcd_remap(blockIdx.x, gridDim.x);
   slice = bid / (nbm * nbn);
