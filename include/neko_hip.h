@@ -33,7 +33,7 @@ extern "C" {
 #define NEKO_ERR_UNSUPPORTED (-2)
 #define NEKO_ERR_LAUNCH (-3)
 
-#define NEKO_ABI_VERSION 14
+#define NEKO_ABI_VERSION 15
 
 int neko_abi_version(void);
 /* human-readable text for a return code (static storage) */
@@ -208,6 +208,14 @@ int neko_pack_embed_fwd(const int* desc, const float* cont_vals, const int* disc
                         int disc_start, void* stream);
 int neko_pack_embed_bwd(const int* desc, const long long* tokens, const float* dx, float* d_embed, float* d_pos,
                         float* d_sep, float* d_img, int ntok, int d, void* stream);
+/* The same gradients WITHOUT atomics (ABI v15): the tokens are sorted by destination row (stable radix sort) and every row of
+ * d_embed / d_pos / d_sep is the sum of its tokens' gradient rows IN TOKEN ORDER -- bit-identical from run to run, where the fp32
+ * atomics of neko_pack_embed_bwd differ in the last bits (enough to separate two identical AdamW runs after a few steps).
+ * vocab_rows = rows of d_embed; workspace: neko_pack_embed_bwd_det_ws_bytes(ntok, d) bytes (256-B aligned). */
+long neko_pack_embed_bwd_det_ws_bytes(int ntok, int d);
+int neko_pack_embed_bwd_det(const int* desc, const long long* tokens, const float* dx, float* d_embed, float* d_pos,
+                            float* d_sep, float* d_img, int ntok, int d, int vocab_rows, void* workspace, long ws_bytes,
+                            void* stream);
 /* ContinuousTokenizer.encode on a flat array (input_tokenizers.py:17-30) */
 int neko_tokenize_continuous(const float* x, int* ids, long n, int use_mu_law, float mu, float M, int n_bins,
                              int offset, void* stream);
@@ -278,6 +286,10 @@ int neko_patch_pos_add(float* out, const int* hpos, const int* wpos, const float
                        int P, int d, void* stream);
 int neko_patch_pos_add_bwd(const float* dout, const int* hpos, const int* wpos, float* d_row_emb,
                            float* d_col_emb, int P, int d, void* stream);
+/* ... and without atomics (ABI v15; same method as neko_pack_embed_bwd_det): rows summed in patch order.  nrows = rows of each table */
+long neko_patch_pos_add_bwd_det_ws_bytes(int P, int d);
+int neko_patch_pos_add_bwd_det(const float* dout, const int* hpos, const int* wpos, float* d_row_emb, float* d_col_emb,
+                               int P, int d, int nrows, void* workspace, long ws_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -41,6 +41,10 @@ SIGNATURES = {
     "neko_ce_bf16_inplace": [_vp, _l, _i, _i, _vp, _vp, _vp, _i, _i, _vp],
     "neko_pack_embed_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _i, _i, _i, _vp],
     "neko_pack_embed_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
+    "neko_pack_embed_bwd_det_ws_bytes": [_i, _i],
+    "neko_pack_embed_bwd_det": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _l, _vp],
+    "neko_patch_pos_add_bwd_det_ws_bytes": [_i, _i],
+    "neko_patch_pos_add_bwd_det": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _l, _vp],
     "neko_tokenize_continuous": [_vp, _vp, _l, _i, _f, _f, _i, _i, _vp],
     "neko_cast_f32_bf16": [_vp, _vp, _l, _vp],
     "neko_colsum_bf16": [_vp, _l, _i, _i, _vp, _i, _vp],
@@ -84,6 +88,8 @@ def load() -> C.CDLL:
         fn.restype = _i
     lib.neko_attn_mask_dwords.restype = C.c_long
     lib.neko_gemm_colsum_ws_floats.restype = C.c_long
+    lib.neko_pack_embed_bwd_det_ws_bytes.restype = C.c_long
+    lib.neko_patch_pos_add_bwd_det_ws_bytes.restype = C.c_long
     lib.neko_status_string.argtypes = [_i]
     lib.neko_status_string.restype = C.c_char_p
     _lib = lib

@@ -204,5 +204,15 @@ int neko_patch_pos_add_bwd(const float* dout, const int* hpos, const int* wpos, 
                            int P, int d, void* stream) {
   return neko_patch_pos_add_bwd_impl(dout, hpos, wpos, d_row_emb, d_col_emb, P, d, S(stream));
 }
+long neko_patch_pos_add_bwd_det_ws_bytes(int P, int d) { return neko_patch_pos_add_bwd_det_ws_bytes_impl(P, d); }
+int neko_patch_pos_add_bwd_det(const float* dout, const int* hpos, const int* wpos, float* d_row_emb, float* d_col_emb, int P, int d,
+                               int nrows, void* workspace, long ws_bytes, void* stream) {
+  return neko_patch_pos_add_bwd_det_impl(dout, hpos, wpos, d_row_emb, d_col_emb, P, d, nrows, workspace, ws_bytes, S(stream));
+}
+long neko_pack_embed_bwd_det_ws_bytes(int ntok, int d) { return neko_pack_embed_bwd_det_ws_bytes_impl(ntok, d); }
+int neko_pack_embed_bwd_det(const int* desc, const long long* tokens, const float* dx, float* d_embed, float* d_pos, float* d_sep,
+                            float* d_img, int ntok, int d, int vocab_rows, void* workspace, long ws_bytes, void* stream) {
+  return neko_pack_embed_bwd_det_impl(desc, tokens, dx, d_embed, d_pos, d_sep, d_img, ntok, d, vocab_rows, workspace, ws_bytes, S(stream));
+}
 
 }  // extern "C"

@@ -120,5 +120,16 @@ int neko_patch_resblock_bwd_blocks_impl(int P);
 int neko_patch_resblock_ws_stride_impl();
 int neko_patch_pos_add_impl(float* out, const int* hpos, const int* wpos, const float* row_emb, const float* col_emb,
                             int P, int d, hipStream_t s);
+// segsum.hip: out[keys[i], :] += src[i, :] in index order (no atomics); keys >= NEKO_SEGSUM_KEY_NONE are skipped, key == nrows -> `extra`
+#define NEKO_SEGSUM_KEY_NONE 0xFFFFFu
+size_t neko_segsum_ws_bytes_impl(int n, int d);
+int neko_segsum_rows_impl(const float* src, long ld_src, const unsigned* keys, int n, int d, float* out, long ld_out, int nrows,
+                          float* extra, void* ws, size_t ws_bytes, hipStream_t s);
+long neko_pack_embed_bwd_det_ws_bytes_impl(int ntok, int d);
+int neko_pack_embed_bwd_det_impl(const int* desc, const long long* tokens, const float* dx, float* d_embed, float* d_pos, float* d_sep,
+                                 float* d_img, int ntok, int d, int vocab_rows, void* ws, long ws_bytes, hipStream_t s);
+long neko_patch_pos_add_bwd_det_ws_bytes_impl(int P, int d);
+int neko_patch_pos_add_bwd_det_impl(const float* dout, const int* hpos, const int* wpos, float* d_row_emb, float* d_col_emb, int P,
+                                    int d, int nrows, void* ws, long ws_bytes, hipStream_t s);
 int neko_patch_pos_add_bwd_impl(const float* dout, const int* hpos, const int* wpos, float* d_row_emb,
                                 float* d_col_emb, int P, int d, hipStream_t s);

@@ -754,3 +754,14 @@ int neko_patch_pos_add_bwd_impl(const float* dout, const int* hpos, const int* w
   NEKO_CHECK_LAUNCH();
   return NEKO_OK;
 }
+
+long neko_patch_pos_add_bwd_det_ws_bytes_impl(int P, int d) { return P > 0 ? (long)neko_segsum_ws_bytes_impl(P, d) : 0; }
+// the same two gradients without atomics (segsum.hip): every table row is the sum of its patches' rows in patch order
+int neko_patch_pos_add_bwd_det_impl(const float* dout, const int* hpos, const int* wpos, float* d_row_emb, float* d_col_emb, int P,
+                                    int d, int nrows, void* ws, long ws_bytes, hipStream_t s) {
+  if (P <= 0) return NEKO_OK;
+  if (!dout || !hpos || !wpos || !d_row_emb || !d_col_emb || !ws || nrows <= 0) return NEKO_ERR_ARG;
+  int rc = neko_segsum_rows_impl(dout, d, reinterpret_cast<const unsigned*>(hpos), P, d, d_row_emb, d, nrows + 1, nullptr, ws, (size_t)ws_bytes, s);
+  if (rc != NEKO_OK) return rc;
+  return neko_segsum_rows_impl(dout, d, reinterpret_cast<const unsigned*>(wpos), P, d, d_col_emb, d, nrows + 1, nullptr, ws, (size_t)ws_bytes, s);
+}

@@ -339,8 +339,21 @@ def pack_embed_fwd(desc, cont_vals, disc_vals, img_emb, embed, pos_embed, sep, n
     return x, tokens, tmask, pmask
 
 
+#: NEKO_DETERMINISTIC=1: the embedding-table gradients (token / position / separator embeddings, patch position tables) are summed in
+#: sorted, fixed order (ABI v15, segsum.hip) instead of by fp32 atomics -- the only order-dependent sums of a step: with it a training run
+#: is bit-reproducible (tools/trajectory_noise_probe.py: identical losses over repeated runs).  Costs 0.15 ms per m-mix step (two stable
+#: sorts of 65536 keys + the ordered row sums, against 0.29 + 0.21 ms of contended atomics), hence off by default.
+SCATTER_DET = os.environ.get("NEKO_DETERMINISTIC", "0") == "1"
+
+
 def pack_embed_bwd(desc, tokens, dx, d_embed, d_pos, d_sep, d_img, ntok, d):
     _chk(dx, torch.float32, "dx")
+    if SCATTER_DET and d_embed.shape[0] < 0xFFFFF:
+        n = int(_lib.load().neko_pack_embed_bwd_det_ws_bytes(ntok, d))
+        ws = torch.empty(n, dtype=torch.uint8, device=dx.device)
+        _lib.call("neko_pack_embed_bwd_det", _p(desc), _p(tokens), _p(dx), _p(d_embed), _p(d_pos), _p(d_sep), _p(d_img),
+                  ntok, d, int(d_embed.shape[0]), _p(ws), n, _stream())
+        return
     _lib.call("neko_pack_embed_bwd", _p(desc), _p(tokens), _p(dx), _p(d_embed), _p(d_pos), _p(d_sep), _p(d_img),
               ntok, d, _stream())
 
@@ -447,4 +460,10 @@ def patch_pos_add(out, hpos, wpos, row_emb, col_emb):
 
 def patch_pos_add_bwd(dout, hpos, wpos, d_row, d_col):
     P, d = dout.shape
+    if SCATTER_DET and P > 0:
+        n = int(_lib.load().neko_patch_pos_add_bwd_det_ws_bytes(P, d))
+        ws = torch.empty(n, dtype=torch.uint8, device=dout.device)
+        _lib.call("neko_patch_pos_add_bwd_det", _p(dout), _p(hpos), _p(wpos), _p(d_row), _p(d_col), P, d, int(d_row.shape[0]),
+                  _p(ws), n, _stream())
+        return
     _lib.call("neko_patch_pos_add_bwd", _p(dout), _p(hpos), _p(wpos), _p(d_row), _p(d_col), P, d, _stream())

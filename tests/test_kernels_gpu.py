@@ -631,6 +631,41 @@ def test_patch_pos_add(ops):
     close(dr, ref_r, 1e-5, 1e-5, "pos bwd row"); close(dc, ref_c, 1e-5, 1e-5, "pos bwd col")
 
 
+@pytest.mark.parametrize("P,d,nrows", [(12289, 768, 128), (500, 72, 37), (1, 768, 128), (97, 64, 3), (4099, 2048, 128)])
+def test_patch_pos_add_bwd_sorted_sums_are_exact_in_order_and_reproducible(ops, P, d, nrows):
+    """The atomic-free table gradients (ABI v15, segsum.hip: stable sort by destination row, runs summed in patch order, chunk
+    partials in chunk order): against an fp64 reference, accumulating onto an existing gradient, bit-identical from run to run, and
+    agreeing with the atomic kernel to fp32 summation noise."""
+    g = torch.Generator().manual_seed(P + d)
+    out = torch.randn(P, d, generator=g)
+    hp = torch.randint(0, nrows, (P,), generator=g, dtype=torch.int32)
+    wp = torch.randint(0, nrows, (P,), generator=g, dtype=torch.int32)
+    if P > 1000:
+        hp[: P // 2] = 1                       # one hot row: a run that spans hundreds of chunks
+    base_r, base_c = torch.randn(nrows, d, generator=g), torch.randn(nrows, d, generator=g)
+    prev, ops.SCATTER_DET = ops.SCATTER_DET, True
+    runs = []
+    try:
+        for _ in range(3):
+            dr, dc = base_r.clone().to(DEV), base_c.clone().to(DEV)
+            ops.patch_pos_add_bwd(out.to(DEV), hp.to(DEV), wp.to(DEV), dr, dc)
+            runs.append((dr.cpu(), dc.cpu()))
+    finally:
+        ops.SCATTER_DET = prev
+    assert all(torch.equal(runs[0][0], r[0]) and torch.equal(runs[0][1], r[1]) for r in runs[1:])
+    ref_r = base_r.double().index_add_(0, hp.long(), out.double())
+    ref_c = base_c.double().index_add_(0, wp.long(), out.double())
+    tol = 4e-6 * (P / 2 + 8) ** 0.5
+    close(runs[0][0], ref_r.float(), 1e-5, tol, "pos bwd row"); close(runs[0][1], ref_c.float(), 1e-5, tol, "pos bwd col")
+    prev, ops.SCATTER_DET = ops.SCATTER_DET, False
+    try:
+        dr, dc = base_r.clone().to(DEV), base_c.clone().to(DEV)
+        ops.patch_pos_add_bwd(out.to(DEV), hp.to(DEV), wp.to(DEV), dr, dc)
+    finally:
+        ops.SCATTER_DET = prev
+    close(dr, ref_r.float(), 1e-5, tol, "atomic row"); close(dc, ref_c.float(), 1e-5, tol, "atomic col")
+
+
 @pytest.mark.parametrize("drop_p", [0.0, 0.1])
 def test_attention_schedules_agree_at_metric_shape(ops, drop_p):
     """Head-resident and streaming kernels on the bench shape (32 x 1024 x 24 heads of 32, left padding on a third of the

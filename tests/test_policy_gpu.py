@@ -7,6 +7,7 @@ Tolerances (bf16 MFMA operands, fp32 accumulation/statistics; SURVEY.md 8(d) par
   loss: 1e-3 relative (one batch), 100-step trace: see test;  per-parameter grad norms: 2e-2 relative.
 """
 import math
+import os
 
 import pytest
 import torch
@@ -270,3 +271,38 @@ def test_gradient_accumulation_two_micro_batches():
             continue
         assert named[k].grad is not None, k
         assert relerr(named[k].grad, gref) < 8e-2, (k, relerr(named[k].grad, gref))
+
+
+def test_training_step_is_bit_reproducible_and_matches_the_atomic_scatter():
+    """With the embedding-table gradients summed in sorted order (ABI v15, NEKO_DETERMINISTIC=1) nothing in a step depends on
+    execution order: repeated forward + backward passes of the same batch give bit-identical gradients for EVERY parameter, and the
+    default atomic form of the two scatters agrees with them to fp32 summation noise."""
+    from neko_amd import ops
+    f = torch.load(os.path.join(os.path.dirname(__file__), "golden", "g7_trace.pt"), weights_only=False)
+    cfg = O.OracleConfig(**f["cfg"])
+    m, _ = make_policy(cfg, f["seed"], train=False)
+    batch = to_dev(f["batches"][0])
+
+    def grads():
+        m.zero_grad(set_to_none=True)
+        m._flat.zero_grad()
+        _, loss = m(batch, compute_loss=True, return_logits=False)
+        loss.backward()
+        torch.cuda.synchronize()
+        return float(loss), {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
+
+    prev, ops.SCATTER_DET = ops.SCATTER_DET, True           # what NEKO_DETERMINISTIC=1 selects
+    try:
+        l0, g0 = grads()
+        for _ in range(3):
+            l1, g1 = grads()
+            assert l1 == l0
+            for k in g0:
+                assert torch.equal(g0[k], g1[k]), k
+        ops.SCATTER_DET = False
+        _, ga = grads()
+    finally:
+        ops.SCATTER_DET = prev
+    for k in g0:
+        sc = float(g0[k].abs().max())
+        assert float((ga[k] - g0[k]).abs().max()) <= 2e-6 * sc + 1e-12, k

@@ -2,7 +2,8 @@
 """How far do two EAGER runs of the captured-step test's recipe drift apart (same seeds, same batches)?  The only run-to-run
 difference of a step is the order of the fp32 atomics in the embedding scatters (~1e-7 of a gradient entry); AdamW divides by
 sqrt(v), so an entry whose gradient IS rounding noise moves by +-lr with a noise-dependent sign and the trajectories separate.
-Prints the relative loss difference per step over N runs against run 0."""
+Prints the relative loss difference per step over N runs against run 0.  With NEKO_DETERMINISTIC=1 (sorted, fixed-order table
+gradients, ABI v15) every difference is exactly 0."""
 import os
 import sys
 
