@@ -10,8 +10,11 @@
  *
  * Conventions
  *  - plain C: raw device pointers, explicit sizes / leading dimensions (in ELEMENTS), a HIP stream
- *    passed as void* (hipStream_t).  No torch types, no global state, no allocation: every buffer
- *    (inputs, outputs, workspaces) is owned by the caller for the duration of the enqueued work.
+ *    passed as void* (hipStream_t).  No torch types, no allocation: every buffer (inputs, outputs,
+ *    workspaces) is owned by the caller for the duration of the enqueued work.  Process-wide state is
+ *    limited to three documented knobs -- neko_gemm_set_mainloop, neko_attn_set_path (schedule
+ *    selectors: they pick between kernels with the same contract) and neko_set_drop_salt (the
+ *    device word a captured training step advances) -- none of which changes what a call computes.
  *  - every call only ENQUEUES kernels on `stream` and returns immediately.
  *  - return value: 0 = ok; NEKO_ERR_ARG (-1) bad argument; NEKO_ERR_UNSUPPORTED (-2) shape outside
  *    the supported set; <= -3: launch failure, value = -3 - hipError_t.  Nothing throws.
@@ -33,7 +36,7 @@ extern "C" {
 #define NEKO_ERR_UNSUPPORTED (-2)
 #define NEKO_ERR_LAUNCH (-3)
 
-#define NEKO_ABI_VERSION 15
+#define NEKO_ABI_VERSION 16
 
 int neko_abi_version(void);
 /* human-readable text for a return code (static storage) */
@@ -71,12 +74,14 @@ int neko_gemm_bf16(const uint16_t* A, long lda, int a_kstrided, const uint16_t* 
                    int accumulate, uint16_t* Cb, long ldcb, int splitk, int k_per_split, float* splitk_ws,
                    int drop_thr, unsigned drop_key, float drop_scale, int safe_transpose, void* stream);
 
-/* neko_gemm_bf16 has a second schedule for bf16-output launches whose tiles are all interior 256 x 256 ones (A k-contiguous,
- * K >= 608, at least two rounds of tiles): a persistent kernel that streams k-tiles across tile boundaries and drains half of
- * each tile's epilogue under the next tile's k-loop (neko_amd/csrc/gemm_pers.hip).  It measured level with the default tiles
- * on the step's shapes and is OFF unless the environment says NEKO_GEMM_PERS=1; neko_gemm_set_persistent(1 / 0) forces it on /
- * off for the process, (-1) returns to the environment's choice; returns the previous mode (-1, 0, 1).  (ABI v14) */
-int neko_gemm_set_persistent(int mode);
+/* neko_gemm_bf16 has two main loops behind one contract.  The default one (neko_amd/csrc/gemm_glds.hip) serves every shape; the
+ * long-contraction loop (neko_amd/csrc/gemm_a16.hip: 4 waves x 128 x 128 per wave on v_mfma_f32_16x16x32_bf16 with the accumulators
+ * in AGPRs, instruction stream placed by hand) takes launches whose tiles are all interior 256 x 256 ones and whose contraction
+ * range is a multiple of 128, where it measured faster (long K).  neko_gemm_set_mainloop(1) sends every launch it can serve to
+ * the second loop, (0) none, (-1) returns to the built-in per-shape choice (also: environment NEKO_GEMM_A16=0/1); returns the
+ * previous mode.  The choice never changes which products are summed into an output element; the two loops add them in a
+ * different order (fp32).  (ABI v16; replaces v14's neko_gemm_set_persistent, whose kernel moved to tools/probe/) */
+int neko_gemm_set_mainloop(int mode);
 
 /* Backward of the MLP's first Linear + GELU in one launch (trajectory_gpt2.py:266,274: h = act(c_fc(x)); autograd's
  * d_pre = (d_h . W_proj^T) * gelu'(pre) and the c_fc bias gradient sum_rows d_pre):

@@ -17,9 +17,11 @@ import sys
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 BUILD = os.path.join(CSRC, "build")
 LIB = os.path.join(CSRC, "libneko_hip.so")
-SOURCES = ["gemm_bf16.hip", "gemm_glds.hip", "gemm_pers.hip", "gemv_bf16.hip", "layernorm.hip", "attention.hip", "attention_res.hip", "attention_stream.hip", "attention_decode.hip", "cross_entropy.hip", "elementwise.hip",
+SOURCES = ["gemm_bf16.hip", "gemm_glds.hip", "gemm_a16.hip", "gemv_bf16.hip", "layernorm.hip", "attention.hip", "attention_res.hip", "attention_stream.hip", "attention_decode.hip", "cross_entropy.hip", "elementwise.hip",
            "pack_embed.hip", "patch_embed.hip", "rows.hip", "segsum.hip", "dropout.hip", "neko_capi.hip"]
 HEADERS = ["neko_common.h", "neko_kernels.h", os.path.join("..", "..", "include", "neko_hip.h")]
+# headers only some sources include (a change rebuilds just those)
+EXTRA_DEPS = {"gemm_glds.hip": ["gemm_epi.h"], "gemm_a16.hip": ["gemm_epi.h", "gemm_a16_loop.inc"]}
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=on", "-Wno-unused-result"]
 FLAGS += os.environ.get("NEKO_EXTRA_HIPCC_FLAGS", "").split()
@@ -41,7 +43,7 @@ def _stale(target: str, deps) -> bool:
 
 def _compile(src: str, force: bool) -> str:
     obj = os.path.join(BUILD, src.replace(".hip", ".o"))
-    deps = [os.path.join(CSRC, src)] + [os.path.join(CSRC, h) for h in HEADERS]
+    deps = [os.path.join(CSRC, src)] + [os.path.join(CSRC, h) for h in HEADERS + EXTRA_DEPS.get(src, [])]
     if force or _stale(obj, deps):
         cmd = [_hipcc(), *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)

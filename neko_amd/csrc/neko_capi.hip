@@ -28,7 +28,7 @@ int neko_gemm_bf16(const uint16_t* A, long lda, int a_kstrided, const uint16_t* 
   return neko_gemm_bf16_full(a, a_kstrided, b_kstrided, safe_transpose, S(stream));
 }
 
-int neko_gemm_set_persistent(int mode) { return neko_gemm_set_persistent_impl(mode); }
+int neko_gemm_set_mainloop(int mode) { return neko_gemm_set_mainloop_impl(mode); }
 long neko_gemm_colsum_ws_floats(int M, int N) { return (long)((M + 63) / 64) * (long)N; }
 int neko_gemm_dgrad_gelu_colsum(const uint16_t* dY, long lda, const uint16_t* W, long ldb, int M, int N, int K,
                                 const uint16_t* act_in, long ldact, int act_in_is_factor, uint16_t* Cb, long ldcb,

@@ -38,8 +38,8 @@ int neko_gather_rows_bf16_impl(const bf16_t* src, const int* idx, bf16_t* dst, i
 int neko_scatter_rows_f32_impl(const float* src, const int* idx, float* dst, int n, int d, hipStream_t s);
 int neko_splitk_reduce_impl(const float* ws, int S, int M, int N, float* C, long ldc, int accumulate, hipStream_t s);
 int neko_gemm_glds_try(const GemmArgs& a, int a_kstrided, int b_kstrided, hipStream_t s);   // 1 = not applicable
-int neko_gemm_pers_try(const GemmArgs& a, int b_kstrided, hipStream_t s);                   // 1 = not applicable (gemm_pers.hip)
-int neko_gemm_set_persistent_impl(int mode);
+int neko_gemm_a16_try(const GemmArgs& a, int a_kstrided, int b_kstrided, hipStream_t s);    // 1 = not applicable (gemm_a16.hip)
+int neko_gemm_set_mainloop_impl(int mode);
 // bands of colsum_ws the last neko_gemm_glds_try() of this thread filled (0: the column sums were not folded into it)
 int neko_gemm_glds_colsum_bands();
 int neko_colsum_bands_reduce_impl(const float* ws, int bands, int N, float* out, hipStream_t s);   // out[N] += sum over bands, fixed order

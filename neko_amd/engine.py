@@ -616,7 +616,9 @@ def lm_head_loss_selected(Hp: HeadParams, hf16: torch.Tensor, target: torch.Tens
     host from the packing descriptors) go through the LM head -- the HIP counterpart of the reference's
     boolean-mask gather (gato_policy.py:183-185), done before the GEMM instead of after it.
     Returns (loss, hsel bf16 [npad,d], dlogits bf16 [npad,Vpad] | None)."""
-    npad = max(64, (n + 63) // 64 * 64)        # multiple of 64: keeps the wgrad contraction on the fast GEMM path
+    # multiple of 64: keeps the wgrad contraction on the fast GEMM path; of 256 once the batch is large: whole 256-row tiles for
+    # the dH product and a contraction of whole loop trips for dW (gemm_a16.hip); the padding rows are zero rows with weight 0
+    npad = max(64, (n + 63) // 64 * 64) if n < 2048 else (n + 255) // 256 * 256
     dev = hf16.device
     hsel = ops.gather_rows_bf16(hf16, idx, n, npad)
     tsel = torch.zeros(npad, dtype=torch.int64, device=dev)

@@ -74,7 +74,8 @@ def pick_splitk(M: int, N: int, K: int, target_blocks: int = 256) -> tuple:
     """Split-K factor for skinny-output / long-K GEMMs (weight gradients, LM-head dH).  Split-K launches run the
     256x256 tile, one block per CU (gemm_glds.hip: launch()), so the model is: rounds of `target_blocks` tiles,
     each k-step of 32 costing ~1.05 us per round, plus the fixed-order workspace reduce (write + read at ~4 TB/s).
-    Returns (splitk, k_per_split) with k_per_split a multiple of 64, or (1, 0)."""
+    Returns (splitk, k_per_split) with k_per_split a multiple of 64 (of 128 when K is: every slice is then a whole number of
+    trips of the long-contraction loop, gemm_a16.hip), or (1, 0)."""
     if K < 4096:
         return 1, 0
     tiles = ((M + 255) // 256) * ((N + 255) // 256)
@@ -82,7 +83,8 @@ def pick_splitk(M: int, N: int, K: int, target_blocks: int = 256) -> tuple:
         return 1, 0
     best_t, best = None, (1, 0)
     for sk in range(1, 33):
-        kps = ((K + sk - 1) // sk + 63) // 64 * 64
+        q = 128 if K % 128 == 0 else 64
+        kps = ((K + sk - 1) // sk + q - 1) // q * q
         if (K + kps - 1) // kps != sk:
             continue
         if sk > 1 and kps < 1024:
@@ -187,10 +189,10 @@ def mask_bias(mask: torch.Tensor):
     return kb, ks
 
 
-def gemm_set_persistent(mode: int) -> int:
-    """1 / 0: force the persistent deferred-epilogue GEMM schedule on / off where it applies, -1: the environment's choice
-    (NEKO_GEMM_PERS, default off); returns the previous mode (neko_gemm_set_persistent)."""
-    return int(_lib.load().neko_gemm_set_persistent(int(mode)))
+def gemm_set_mainloop(mode: int) -> int:
+    """1 / 0: send every launch the hand-placed long-contraction main loop (gemm_a16.hip) can serve to it / none, -1: the
+    built-in per-shape choice; returns the previous mode (neko_gemm_set_mainloop)."""
+    return int(_lib.load().neko_gemm_set_mainloop(int(mode)))
 
 
 def attn_set_path(mode: int) -> int:

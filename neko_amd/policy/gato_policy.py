@@ -32,7 +32,7 @@ from .input_tokenizers import ContinuousTokenizer
 
 # descriptor kinds (neko_amd/csrc/pack_embed.hip)
 K_PAD, K_TOKEN, K_CONT_OBS, K_CONT_ACT, K_DISC, K_SEP, K_IMAGE, K_DEVID = 0, 1, 2, 3, 4, 5, 6, 7
-VPAD_ALIGN = 128
+VPAD_ALIGN = 256      # predict_token rows padded with zeros to whole 256-row GEMM tiles (LM-head dW takes the long-contraction loop)
 
 
 class PackedBatch:

@@ -24,7 +24,7 @@ def test_abi_exports_every_declared_symbol():
         assert hasattr(lib, name), f"libneko_hip.so lacks {name}"
     # every binding in _lib.SIGNATURES is a declared symbol and vice versa (status_string is bound separately)
     assert set(_lib.SIGNATURES) | {"neko_status_string"} == declared
-    assert lib.neko_abi_version() == 15
+    assert lib.neko_abi_version() == 16
     assert lib.neko_status_string(-1).decode().startswith("invalid argument")
 
 
@@ -54,7 +54,7 @@ def test_state_dict_matches_reference_layout(golden):
     # parameters are views of one flat buffer, 64-element aligned, predict_token padded to a multiple of 128 rows
     flat = m._flat
     assert all(off % 64 == 0 for off, _, _ in flat.offsets.values())
-    assert m.Vpad % 128 == 0 and m.Vpad >= m.vocab_size
+    assert m.Vpad % 256 == 0 and m.Vpad >= m.vocab_size
     p = dict(m.named_parameters())["transformer.h.0.mlp.c_fc.weight"]
     assert p.data_ptr() == flat.view("transformer.h.0.mlp.c_fc.weight").data_ptr()
     # reference init distributions (trajectory_gpt2.py:375-385): N(0, .02) inside the transformer, zeros for SEP

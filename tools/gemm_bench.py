@@ -11,7 +11,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from neko_amd import ops  # noqa: E402
 
-M, D, V, VP = 32768, 768, 52305, 52352
+M, D, V, VP = 32768, 768, 52305, 52480
 BF = torch.bfloat16
 
 # name, M, N, K, a_kstrided, b_kstrided, extras
