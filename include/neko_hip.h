@@ -216,11 +216,13 @@ int neko_pack_embed_bwd(const int* desc, const long long* tokens, const float* d
 /* The same gradients WITHOUT atomics (ABI v15): the tokens are sorted by destination row (stable radix sort) and every row of
  * d_embed / d_pos / d_sep is the sum of its tokens' gradient rows IN TOKEN ORDER -- bit-identical from run to run, where the fp32
  * atomics of neko_pack_embed_bwd differ in the last bits (enough to separate two identical AdamW runs after a few steps).
- * vocab_rows = rows of d_embed; workspace: neko_pack_embed_bwd_det_ws_bytes(ntok, d) bytes (256-B aligned). */
+ * vocab_rows = rows of d_embed, pos_rows = rows of d_pos (ABI v16): a token id / position outside its table is dropped, never
+ * written; tables of 2^20 - 1 rows or more are refused (NEKO_ERR_UNSUPPORTED: the sort orders on 20 key bits).
+ * workspace: neko_pack_embed_bwd_det_ws_bytes(ntok, d) bytes (256-B aligned). */
 long neko_pack_embed_bwd_det_ws_bytes(int ntok, int d);
 int neko_pack_embed_bwd_det(const int* desc, const long long* tokens, const float* dx, float* d_embed, float* d_pos,
-                            float* d_sep, float* d_img, int ntok, int d, int vocab_rows, void* workspace, long ws_bytes,
-                            void* stream);
+                            float* d_sep, float* d_img, int ntok, int d, int vocab_rows, int pos_rows, void* workspace,
+                            long ws_bytes, void* stream);
 /* ContinuousTokenizer.encode on a flat array (input_tokenizers.py:17-30) */
 int neko_tokenize_continuous(const float* x, int* ids, long n, int use_mu_law, float mu, float M, int n_bins,
                              int offset, void* stream);

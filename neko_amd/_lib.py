@@ -42,7 +42,7 @@ SIGNATURES = {
     "neko_pack_embed_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _i, _i, _i, _vp],
     "neko_pack_embed_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "neko_pack_embed_bwd_det_ws_bytes": [_i, _i],
-    "neko_pack_embed_bwd_det": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _l, _vp],
+    "neko_pack_embed_bwd_det": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _l, _vp],
     "neko_patch_pos_add_bwd_det_ws_bytes": [_i, _i],
     "neko_patch_pos_add_bwd_det": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _l, _vp],
     "neko_tokenize_continuous": [_vp, _vp, _l, _i, _f, _f, _i, _i, _vp],

@@ -17,6 +17,7 @@
 //     the hardware transposes 4 x 4 blocks of 16-bit values inside each 16-lane group, no transposed copy is ever written).
 // The DMA writes 1 KiB per wave instruction at consecutive LDS addresses, so the swizzle is applied on the GLOBAL side:
 // lane L of a piece fetches the chunk whose swizzled position is L.
+#include <atomic>
 #include "neko_kernels.h"
 
 extern int neko_attn_path_mode();
@@ -1179,6 +1180,20 @@ __global__ __launch_bounds__(64 * NW, 1) void attn_dkv_stream_kernel(const bf16_
   }
 }
 
+// The > 64 KiB dynamic-LDS limit is a per-device property of the kernel: one bit per device ordinal, set after the attribute call
+// succeeded on that device (setting it twice from two threads is harmless, skipping it is a launch failure)
+typedef std::atomic<unsigned long long> LdsLimitDone;
+template <typename K>
+int set_lds_limit(K kernel, LdsLimitDone& done) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return NEKO_ERR_LAUNCH;
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (done.load(std::memory_order_acquire) & bit) return NEKO_OK;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+    return NEKO_ERR_LAUNCH;
+  done.fetch_or(bit, std::memory_order_release);
+  return NEKO_OK;
+}
 template <int HD, int NW, int NST>
 int fwd_launch(const bf16_t* qkv, const float* kbias, const int* kstart, bf16_t* out, float* lse, int B, int T, int H,
                int thr, unsigned key, float dscale, hipStream_t s) {
@@ -1187,15 +1202,10 @@ int fwd_launch(const bf16_t* qkv, const float* kbias, const int* kstart, bf16_t*
   dim3 grid((unsigned)((long)((G + 1) / 2) * H * B), 1, 1);      // (sequence, head, tile pair) decoded by xcd_remap
   const int ntile = (T + KT - 1) / KT;
   const size_t lds = (size_t)NST * 2 * SC<HD>::TILE + (size_t)ntile * KT * 4 + (size_t)ntile * 4;
-  static bool attr_set[2] = {false, false};
-  if (!attr_set[thr ? 1 : 0]) {
-    hipError_t e = thr ? hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_stream_kernel<HD, true, NW, NST>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
-                       : hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_stream_kernel<HD, false, NW, NST>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return NEKO_ERR_LAUNCH;
-    attr_set[thr ? 1 : 0] = true;
-  }
+  static LdsLimitDone attr_set[2];
+  if ((thr ? set_lds_limit(&attn_fwd_stream_kernel<HD, true, NW, NST>, attr_set[1])
+           : set_lds_limit(&attn_fwd_stream_kernel<HD, false, NW, NST>, attr_set[0])) != NEKO_OK)
+    return NEKO_ERR_LAUNCH;
   if (thr)
     hipLaunchKernelGGL((attn_fwd_stream_kernel<HD, true, NW, NST>), grid, dim3(64 * NW), lds, s, qkv, kbias, kstart, out, lse,
                        B, T, H, scale, (uint32_t)thr, key, dscale);
@@ -1236,14 +1246,6 @@ __global__ __launch_bounds__(256) void attn_D_kernel(const bf16_t* __restrict__ 
   }
 }
 
-template <typename K>
-int set_lds_limit(K kernel, bool& done) {
-  if (done) return NEKO_OK;
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-    return NEKO_ERR_LAUNCH;
-  done = true;
-  return NEKO_OK;
-}
 template <int HD, int NWQ, int NSTQ, int NWK, int NSTK>
 int bwd_launch(const bf16_t* qkv, const bf16_t* dout, const float* kbias, const int* kstart, const float* lse, const float* D,
                bf16_t* dqkv, int B, int T, int H, int thr, unsigned key, float dscale, hipStream_t s) {
@@ -1253,7 +1255,7 @@ int bwd_launch(const bf16_t* qkv, const bf16_t* dout, const float* kbias, const 
     const int G = (T + 32 * NWQ - 1) / (32 * NWQ);
     dim3 grid((unsigned)((long)((G + 1) / 2) * H * B), 1, 1);
     const size_t lds = (size_t)NSTQ * 2 * SC<HD>::TILE + (size_t)ntile * KT * 4 + (size_t)ntile * 4;
-    static bool done[2] = {false, false};
+    static LdsLimitDone done[2];
     if (thr) {
       if (set_lds_limit(&attn_dq_stream_kernel<HD, true, NWQ, NSTQ>, done[1]) != NEKO_OK) return NEKO_ERR_LAUNCH;
       hipLaunchKernelGGL((attn_dq_stream_kernel<HD, true, NWQ, NSTQ>), grid, dim3(64 * NWQ), lds, s, qkv, dout, kbias, kstart, lse, D,
@@ -1269,7 +1271,7 @@ int bwd_launch(const bf16_t* qkv, const bf16_t* dout, const float* kbias, const 
     const int G = (T + 32 * NWK - 1) / (32 * NWK);
     dim3 grid((unsigned)((long)((G + 1) / 2) * H * B), 1, 1);
     const size_t lds = (size_t)NSTK * 2 * SC<HD>::TILE + (size_t)ntile * KT * 4 * 3 + (size_t)ntile * 4;
-    static bool done[2] = {false, false};
+    static LdsLimitDone done[2];
     if (thr) {
       if (set_lds_limit(&attn_dkv_stream_kernel<HD, true, NWK, NSTK>, done[1]) != NEKO_OK) return NEKO_ERR_LAUNCH;
       hipLaunchKernelGGL((attn_dkv_stream_kernel<HD, true, NWK, NSTK>), grid, dim3(64 * NWK), lds, s, qkv, dout, kbias, lse, D, dqkv, B,

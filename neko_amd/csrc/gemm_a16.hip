@@ -63,38 +63,50 @@ __global__ __launch_bounds__(256, 1) void gemm_a16_kernel(GemmArgs p) {
   const unsigned nkt = (unsigned)(kend - kbeg) / 32u;
 
   // per-lane DMA source offsets (bytes from the operand's tile origin) and LDS read addresses; layouts: gen_gemm_a16.py
-  unsigned voa[4], vob[4];
-#pragma unroll
-  for (int pc = 0; pc < 4; ++pc) {
-    const int pidx = wave * 4 + pc;
-    if (A_KC) {
-      const int row = pidx * 16 + (lane >> 2);
-      voa[pc] = (unsigned)((row * p.lda + (((lane & 3) ^ kc_swz(row)) << 3)) * 2);
-    } else {
-      const int kr = pidx * 2 + (lane >> 5);
-      voa[pc] = (unsigned)((kr * p.lda + (((lane & 31) ^ (ks_hh(kr) << 1)) << 3)) * 2);
-    }
-    if (B_KC) {
-      const int row = pidx * 16 + (lane >> 2);
-      vob[pc] = (unsigned)((row * p.ldb + (((lane & 3) ^ kc_swz(row)) << 3)) * 2);
-    } else {
-      const int kr = pidx * 2 + (lane >> 5);
-      vob[pc] = (unsigned)((kr * p.ldb + (((lane & 31) ^ (ks_hh(kr) << 1)) << 3)) * 2);
-    }
-  }
+  constexpr bool KC64 = NEKO_A16_KC_MODE == 64;
   const unsigned lds0 = __builtin_amdgcn_readfirstlane(
       (unsigned)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)smem));
   const int c16 = lane & 15, g4 = lane >> 4;
   const int krd = 8 * g4 + (c16 >> 2);                                       // k-row a lane's transposing read starts at
-  unsigned ra, rb, ha = (unsigned)ks_hh(krd), hb = ha;
-  if (A_KC) ra = lds0 + (unsigned)((wm * 128 + c16) * 64 + ((g4 ^ kc_swz(c16)) << 4));
-  else ra = lds0 + (unsigned)(krd * 512 + (wm * 16 + ((c16 & 3) >> 1)) * 16 + (c16 & 1) * 8);
-  if (B_KC) rb = lds0 + 65536u + (unsigned)((wn * 128 + c16) * 64 + ((g4 ^ kc_swz(c16)) << 4));
-  else rb = lds0 + 65536u + (unsigned)(krd * 512 + (wn * 16 + ((c16 & 3) >> 1)) * 16 + (c16 & 1) * 8);
+  unsigned vo[2][8], rd[2][2], hh[2], ldsw[2], step[2];
+#pragma unroll
+  for (int x = 0; x < 2; ++x) {
+    const bool kc = x ? B_KC : A_KC;
+    const long ld = x ? p.ldb : p.lda;
+    const int half = x ? wn : wm;                                            // which 128 rows / columns of the tile this wave reads
+    const unsigned region = lds0 + (x ? 65536u : 0u);
+    hh[x] = (unsigned)ks_hh(krd);
+#pragma unroll
+    for (int pc = 0; pc < 8; ++pc) {
+      if (kc && KC64) {                      // piece = 8 rows x 128 B, wave w requests pieces 8w .. 8w+7 of a slot
+        const int row = (wave * 8 + pc) * 8 + (lane >> 3);
+        vo[x][pc] = (unsigned)((row * ld + (((lane & 7) ^ ((row >> 1) & 7)) << 3)) * 2);
+      } else if (kc) {                       // piece = 16 rows x 64 B, pieces 4w .. 4w+3 of a stage
+        const int row = (wave * 4 + (pc & 3)) * 16 + (lane >> 2);
+        vo[x][pc] = (unsigned)((row * ld + (((lane & 3) ^ kc_swz(row)) << 3)) * 2);
+      } else {                               // piece = 2 k-rows x 512 B
+        const int kr = (wave * 4 + (pc & 3)) * 2 + (lane >> 5);
+        vo[x][pc] = (unsigned)((kr * ld + (((lane & 31) ^ (ks_hh(kr) << 1)) << 3)) * 2);
+      }
+    }
+    if (kc && KC64) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        rd[x][h] = region + (unsigned)((half * 128 + c16) * 128 + (((g4 + 4 * h) ^ ((c16 >> 1) & 7)) << 4));
+      ldsw[x] = lds0 + (unsigned)wave * 8192u;
+      step[x] = 128u;
+    } else if (kc) {
+      rd[x][0] = rd[x][1] = region + (unsigned)((half * 128 + c16) * 64 + ((g4 ^ kc_swz(c16)) << 4));
+      ldsw[x] = lds0 + (unsigned)wave * 4096u;
+      step[x] = 64u;
+    } else {
+      rd[x][0] = rd[x][1] = region + (unsigned)(krd * 512 + (half * 16 + ((c16 & 3) >> 1)) * 16 + (c16 & 1) * 8);
+      ldsw[x] = lds0 + (unsigned)wave * 4096u;
+      step[x] = (unsigned)(64 * ld);
+    }
+  }
   const bf16_t* gA = A_KC ? p.A + (long)m0 * p.lda + kbeg : p.A + (long)kbeg * p.lda + m0;
   const bf16_t* gB = B_KC ? p.B + (long)n0 * p.ldb + kbeg : p.B + (long)kbeg * p.ldb + n0;
-  const unsigned sa = A_KC ? 64u : (unsigned)(64 * p.lda), sb = B_KC ? 64u : (unsigned)(64 * p.ldb);     // bytes per k-tile
-  const unsigned ldsw = lds0 + (unsigned)wave * 4096u;
   const unsigned long long gAu = reinterpret_cast<unsigned long long>(gA), gBu = reinterpret_cast<unsigned long long>(gB);
   const unsigned galo = __builtin_amdgcn_readfirstlane((unsigned)gAu), gahi = __builtin_amdgcn_readfirstlane((unsigned)(gAu >> 32));
   const unsigned gblo = __builtin_amdgcn_readfirstlane((unsigned)gBu), gbhi = __builtin_amdgcn_readfirstlane((unsigned)(gBu >> 32));
@@ -103,9 +115,12 @@ __global__ __launch_bounds__(256, 1) void gemm_a16_kernel(GemmArgs p) {
 #define NEKO_A16_OPERANDS                                                                                                  \
   "={a[0:31]}"(acc[0]), "={a[32:63]}"(acc[1]), "={a[64:95]}"(acc[2]), "={a[96:127]}"(acc[3]), "={a[128:159]}"(acc[4]),        \
       "={a[160:191]}"(acc[5]), "={a[192:223]}"(acc[6]), "={a[224:255]}"(acc[7])                                               \
-  : [voa0] "v"(voa[0]), [voa1] "v"(voa[1]), [voa2] "v"(voa[2]), [voa3] "v"(voa[3]), [vob0] "v"(vob[0]), [vob1] "v"(vob[1]),     \
-    [vob2] "v"(vob[2]), [vob3] "v"(vob[3]), [ra] "v"(ra), [rb] "v"(rb), [ha] "v"(ha), [hb] "v"(hb), [galo] "s"(galo),          \
-    [gahi] "s"(gahi), [gblo] "s"(gblo), [gbhi] "s"(gbhi), [sa] "s"(sa), [sb] "s"(sb), [nkt] "s"(nkt), [ldsw] "s"(ldsw)        \
+  : [voa0] "v"(vo[0][0]), [voa1] "v"(vo[0][1]), [voa2] "v"(vo[0][2]), [voa3] "v"(vo[0][3]), [voa4] "v"(vo[0][4]),              \
+    [voa5] "v"(vo[0][5]), [voa6] "v"(vo[0][6]), [voa7] "v"(vo[0][7]), [vob0] "v"(vo[1][0]), [vob1] "v"(vo[1][1]),              \
+    [vob2] "v"(vo[1][2]), [vob3] "v"(vo[1][3]), [vob4] "v"(vo[1][4]), [vob5] "v"(vo[1][5]), [vob6] "v"(vo[1][6]),              \
+    [vob7] "v"(vo[1][7]), [ra0] "v"(rd[0][0]), [ra1] "v"(rd[0][1]), [rb0] "v"(rd[1][0]), [rb1] "v"(rd[1][1]), [ha] "v"(hh[0]), \
+    [hb] "v"(hh[1]), [galo] "s"(galo), [gahi] "s"(gahi), [gblo] "s"(gblo), [gbhi] "s"(gbhi), [sa] "s"(step[0]),                \
+    [sb] "s"(step[1]), [nkt] "s"(nkt), [ldswa] "s"(ldsw[0]), [ldswb] "s"(ldsw[1])                                              \
   : NEKO_A16_CLOBBERS
   if constexpr (A_KC && B_KC) asm volatile(NEKO_A16_LOOP_KC_KC : NEKO_A16_OPERANDS);
   else if constexpr (A_KC && !B_KC) asm volatile(NEKO_A16_LOOP_KC_KS : NEKO_A16_OPERANDS);
@@ -163,8 +178,14 @@ int neko_gemm_a16_try(const GemmArgs& a, int a_kstrided, int b_kstrided, hipStre
   if (!fast_epi_supported(fast_epi_mask(a, true, to_ws, to_ws || a.Cf != nullptr))) return 1;
   if (to_ws && !fast_epi_supported(fast_epi_mask(a, false, to_ws, true))) return 1;
   if (mode < 0) {
-    // per-shape choice (tools/gemm_bench.py, profiles/r04_gemm_a16_ab.txt): long contractions only
-    if (klen < 1536) return 1;
+    // per-shape choice (tools/gemm_bench.py at 32768 / 65536 rows, profiles/r04_gemm_a16_ab.txt): every long contraction; short ones
+    // (K = 768) only with a plain bf16 store behind them and at least two rounds of tiles (forward qkv, dgrad attention out, LM-head
+    // logits: +3..10 %) -- the GELU / residual epilogues are VALU- and store-bound and prefer the 8-wave kernel's two waves per SIMD
+    if (klen < 1536) {
+      const unsigned f = fast_epi_mask(a, true, to_ws, to_ws || a.Cf != nullptr);
+      const long tiles = (long)(a.M / 256) * (a.N / 256);
+      if (!(f == F_CB || f == (F_BIAS | F_CB)) || tiles < 512) return 1;
+    }
   }
   if (a_kstrided && b_kstrided) return launch_a16<false, false>(a, s);
   if (a_kstrided) return launch_a16<false, true>(a, s);

@@ -211,8 +211,9 @@ int neko_patch_pos_add_bwd_det(const float* dout, const int* hpos, const int* wp
 }
 long neko_pack_embed_bwd_det_ws_bytes(int ntok, int d) { return neko_pack_embed_bwd_det_ws_bytes_impl(ntok, d); }
 int neko_pack_embed_bwd_det(const int* desc, const long long* tokens, const float* dx, float* d_embed, float* d_pos, float* d_sep,
-                            float* d_img, int ntok, int d, int vocab_rows, void* workspace, long ws_bytes, void* stream) {
-  return neko_pack_embed_bwd_det_impl(desc, tokens, dx, d_embed, d_pos, d_sep, d_img, ntok, d, vocab_rows, workspace, ws_bytes, S(stream));
+                            float* d_img, int ntok, int d, int vocab_rows, int pos_rows, void* workspace, long ws_bytes, void* stream) {
+  return neko_pack_embed_bwd_det_impl(desc, tokens, dx, d_embed, d_pos, d_sep, d_img, ntok, d, vocab_rows, pos_rows, workspace, ws_bytes,
+                                      S(stream));
 }
 
 }  // extern "C"

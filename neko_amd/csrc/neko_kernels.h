@@ -127,7 +127,7 @@ int neko_segsum_rows_impl(const float* src, long ld_src, const unsigned* keys, i
                           float* extra, void* ws, size_t ws_bytes, hipStream_t s);
 long neko_pack_embed_bwd_det_ws_bytes_impl(int ntok, int d);
 int neko_pack_embed_bwd_det_impl(const int* desc, const long long* tokens, const float* dx, float* d_embed, float* d_pos, float* d_sep,
-                                 float* d_img, int ntok, int d, int vocab_rows, void* ws, long ws_bytes, hipStream_t s);
+                                 float* d_img, int ntok, int d, int vocab_rows, int pos_rows, void* ws, long ws_bytes, hipStream_t s);
 long neko_patch_pos_add_bwd_det_ws_bytes_impl(int P, int d);
 int neko_patch_pos_add_bwd_det_impl(const float* dout, const int* hpos, const int* wpos, float* d_row_emb, float* d_col_emb, int P,
                                     int d, int nrows, void* ws, long ws_bytes, hipStream_t s);

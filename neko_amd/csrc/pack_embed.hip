@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void pack_embed_bwd_kernel(PackBwdArgs a) {
 // destinations of the packing backward as sort keys (segsum.hip): embedding-table row (the separator's own parameter = row `sep_key`)
 // and local-position row, NEKO_SEGSUM_KEY_NONE where a token has none; image rows are copied here (each is written once)
 __global__ __launch_bounds__(256) void pack_embed_bwd_keys_kernel(PackBwdArgs a, unsigned* __restrict__ key_e, unsigned* __restrict__ key_p,
-                                                                  unsigned sep_key) {
+                                                                  unsigned sep_key, unsigned pos_rows) {
   const int lane = threadIdx.x & 63;
   const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (tok >= a.ntok) return;
@@ -138,9 +138,12 @@ __global__ __launch_bounds__(256) void pack_embed_bwd_keys_kernel(PackBwdArgs a,
   const int kind = ds.x, src = ds.y, pos = ds.z;
   unsigned ke = NEKO_SEGSUM_KEY_NONE, kp = NEKO_SEGSUM_KEY_NONE;
   if (kind != K_PAD) {
-    if ((kind >= K_TOKEN && kind <= K_DISC) || kind == K_DEVID) ke = (unsigned)a.tokens[tok];
-    else if (kind == K_SEP) ke = sep_key;
-    if (pos >= 0) kp = (unsigned)pos;
+    // ids / positions outside their table get no key at all (dropped), so nothing above 20 bits reaches the sort
+    if ((kind >= K_TOKEN && kind <= K_DISC) || kind == K_DEVID) {
+      const unsigned long long t = (unsigned long long)a.tokens[tok];
+      if (t < sep_key) ke = (unsigned)t;
+    } else if (kind == K_SEP) ke = sep_key;
+    if (pos >= 0 && (unsigned)pos < pos_rows) kp = (unsigned)pos;
     if (kind == K_IMAGE && a.d_img) {
       const float* g = a.dx + (long)tok * a.d;
       float* dimg = a.d_img + (long)src * a.d;
@@ -196,10 +199,10 @@ long neko_pack_embed_bwd_det_ws_bytes_impl(int ntok, int d) {
 }
 // the gradients of neko_pack_embed_bwd without atomics: every table row is the sum of its tokens' gradient rows in token order
 int neko_pack_embed_bwd_det_impl(const int* desc, const long long* tokens, const float* dx, float* d_embed, float* d_pos, float* d_sep,
-                                 float* d_img, int ntok, int d, int vocab_rows, void* ws, long ws_bytes, hipStream_t s) {
+                                 float* d_img, int ntok, int d, int vocab_rows, int pos_rows, void* ws, long ws_bytes, hipStream_t s) {
   if (ntok <= 0) return NEKO_OK;
-  if (!desc || !tokens || !dx || !d_embed || !d_pos || !d_sep || !ws || (d & 3) || vocab_rows <= 0) return NEKO_ERR_ARG;
-  if ((unsigned)vocab_rows >= NEKO_SEGSUM_KEY_NONE) return NEKO_ERR_UNSUPPORTED;
+  if (!desc || !tokens || !dx || !d_embed || !d_pos || !d_sep || !ws || (d & 3) || vocab_rows <= 0 || pos_rows <= 0) return NEKO_ERR_ARG;
+  if ((unsigned)vocab_rows >= NEKO_SEGSUM_KEY_NONE || (unsigned)pos_rows >= NEKO_SEGSUM_KEY_NONE) return NEKO_ERR_UNSUPPORTED;
   if (ws_bytes < neko_pack_embed_bwd_det_ws_bytes_impl(ntok, d)) return NEKO_ERR_ARG;
   const size_t kb = ((size_t)ntok * 4 + 255) / 256 * 256;
   unsigned* key_e = static_cast<unsigned*>(ws);
@@ -207,11 +210,11 @@ int neko_pack_embed_bwd_det_impl(const int* desc, const long long* tokens, const
   void* sws = static_cast<char*>(ws) + 2 * kb;
   const size_t sws_bytes = (size_t)ws_bytes - 2 * kb;
   PackBwdArgs a{reinterpret_cast<const int4*>(desc), tokens, dx, d_embed, d_pos, d_sep, d_img, ntok, d};
-  hipLaunchKernelGGL(pack_embed_bwd_keys_kernel, dim3((ntok + 3) / 4), dim3(256), 0, s, a, key_e, key_p, (unsigned)vocab_rows);
+  hipLaunchKernelGGL(pack_embed_bwd_keys_kernel, dim3((ntok + 3) / 4), dim3(256), 0, s, a, key_e, key_p, (unsigned)vocab_rows, (unsigned)pos_rows);
   NEKO_CHECK_LAUNCH();
   int rc = neko_segsum_rows_impl(dx, d, key_e, ntok, d, d_embed, d, vocab_rows, d_sep, sws, sws_bytes, s);
   if (rc != NEKO_OK) return rc;
-  return neko_segsum_rows_impl(dx, d, key_p, ntok, d, d_pos, d, 1 << 19, nullptr, sws, sws_bytes, s);
+  return neko_segsum_rows_impl(dx, d, key_p, ntok, d, d_pos, d, pos_rows, nullptr, sws, sws_bytes, s);
 }
 
 int neko_tokenize_continuous_impl(const float* x, int* ids, long n, int use_mu_law, float mu, float M, int n_bins,

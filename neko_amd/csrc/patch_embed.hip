@@ -761,7 +761,8 @@ int neko_patch_pos_add_bwd_det_impl(const float* dout, const int* hpos, const in
                                     int d, int nrows, void* ws, long ws_bytes, hipStream_t s) {
   if (P <= 0) return NEKO_OK;
   if (!dout || !hpos || !wpos || !d_row_emb || !d_col_emb || !ws || nrows <= 0) return NEKO_ERR_ARG;
-  int rc = neko_segsum_rows_impl(dout, d, reinterpret_cast<const unsigned*>(hpos), P, d, d_row_emb, d, nrows + 1, nullptr, ws, (size_t)ws_bytes, s);
+  if ((unsigned)nrows >= NEKO_SEGSUM_KEY_NONE) return NEKO_ERR_UNSUPPORTED;     // the sort orders on 20 key bits
+  int rc = neko_segsum_rows_impl(dout, d, reinterpret_cast<const unsigned*>(hpos), P, d, d_row_emb, d, nrows, nullptr, ws, (size_t)ws_bytes, s);
   if (rc != NEKO_OK) return rc;
-  return neko_segsum_rows_impl(dout, d, reinterpret_cast<const unsigned*>(wpos), P, d, d_col_emb, d, nrows + 1, nullptr, ws, (size_t)ws_bytes, s);
+  return neko_segsum_rows_impl(dout, d, reinterpret_cast<const unsigned*>(wpos), P, d, d_col_emb, d, nrows, nullptr, ws, (size_t)ws_bytes, s);
 }

@@ -27,9 +27,11 @@ __global__ void iota_kernel(int* idx, int n) {
 
 struct ChunkMeta { unsigned first_key, last_key; int nruns, pad; };
 
-// destination row of key k: out + k * ld, or the extra row for k == nrows (the separator token's own parameter)
+// destination row of key k: out + k * ld, or the extra row for k == nrows (the separator token's own parameter); null for a key
+// outside the table (k > nrows, or k == nrows without an extra row): such entries are dropped, never written anywhere
 __device__ __forceinline__ float* dest_row(float* out, long ld, int nrows, float* extra, unsigned k) {
-  return k == (unsigned)nrows ? extra : out + (long)k * ld;
+  if (k < (unsigned)nrows) return out + (long)k * ld;
+  return k == (unsigned)nrows ? extra : nullptr;
 }
 
 __global__ __launch_bounds__(64) void segsum_chunk_kernel(const float* __restrict__ src, long ld_src, const unsigned* __restrict__ keys,
@@ -69,10 +71,13 @@ __global__ __launch_bounds__(64) void segsum_chunk_kernel(const float* __restric
         if (kk[u] != cur) {                            // wave-uniform: a run ends
           if (run == 0) { if (ok) *reinterpret_cast<float4*>(pfirst + c) = acc; }
           else if (run > 0 && ok) {                    // a run inside the chunk: this wave is its row's only writer
-            float4* dst = reinterpret_cast<float4*>(dest_row(out, ld_out, nrows, extra, cur) + c);
-            float4 o = *dst;
-            o.x += acc.x; o.y += acc.y; o.z += acc.z; o.w += acc.w;
-            *dst = o;
+            float* drow = dest_row(out, ld_out, nrows, extra, cur);
+            if (drow) {
+              float4* dst = reinterpret_cast<float4*>(drow + c);
+              float4 o = *dst;
+              o.x += acc.x; o.y += acc.y; o.z += acc.z; o.w += acc.w;
+              *dst = o;
+            }
           }
           acc = make_float4(0.f, 0.f, 0.f, 0.f);
           cur = kk[u];
@@ -115,6 +120,7 @@ __global__ __launch_bounds__(64) void segsum_chain_kernel(const ChunkMeta* __res
       if (meta[stop - 1].nruns > 1) break;
     }
   float* dst_row = dest_row(out, ld_out, nrows, extra, key);
+  if (!dst_row) return;                                                      // key outside the table
   for (int c = 4 * lane; c < d; c += 256) {
     const float4 a = *reinterpret_cast<const float4*>(part + ((long)chunk * 2 + (which == 1 ? 1 : 0)) * d + c);
     float4 acc = a;

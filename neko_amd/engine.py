@@ -228,7 +228,7 @@ def _varlen_of(segs: List[Segment], H: int, hd: int, device) -> Optional[Varlen]
     if not ATTN_VARLEN or len(segs) < 2 or not ops.attn_varlen_supported(max(s.T for s in segs), hd):
         return None
     lengths = [s.T for s in segs for _ in range(s.B)]
-    return Varlen(geom=ops.VarlenGeom(lengths, H, device), kbias=torch.cat([s.kbias.reshape(-1) for s in segs]),
+    return Varlen(geom=ops.VarlenGeom.get(lengths, H, device), kbias=torch.cat([s.kbias.reshape(-1) for s in segs]),
                   kstart=torch.cat([s.kstart.reshape(-1) for s in segs]))
 
 

@@ -226,7 +226,15 @@ def attn_fwd(qkv, kbias, kstart, B, T, H, hd, drop=None, out=None, want_mask=Fal
 
 class VarlenGeom:
     """Packed sequences for the single-launch attention (neko_attn_*_varlen): lengths (host ints, in row order) -> row offsets,
-    keep-mask offsets and sizes; the two offset arrays live on the device."""
+    keep-mask offsets and sizes; the two offset arrays live on the device.
+
+    Geometries are built once per (lengths, H, device) and kept (`VarlenGeom.get`): the two uploads go from PINNED host buffers
+    that the object owns, so a training step that is being captured into a HIP graph either finds the device arrays ready or
+    records copies whose source stays alive and constant for every replay -- never a copy from a temporary pageable tensor
+    (that form stalls the host in eager mode and leaves a dangling host pointer in a captured graph)."""
+
+    _cache: "dict" = {}
+    _CACHE_MAX = 256
 
     def __init__(self, lengths, H: int, device):
         self.lengths = [int(t) for t in lengths]
@@ -237,8 +245,23 @@ class VarlenGeom:
             nb = (t + 31) // 32
             moff.append(moff[-1] + self.H * nb * nb * 32)
         self.rows, self.mask_dwords = off[-1], moff[-1]
-        self.seq_off = torch.tensor(off, dtype=torch.int32).to(device, non_blocking=True)
-        self.mask_off = torch.tensor(moff[:-1], dtype=torch.int64).to(device, non_blocking=True)
+        pin = torch.device(device).type == "cuda"
+        self._host_off = torch.tensor(off, dtype=torch.int32)
+        self._host_moff = torch.tensor(moff[:-1], dtype=torch.int64)
+        if pin:
+            self._host_off, self._host_moff = self._host_off.pin_memory(), self._host_moff.pin_memory()
+        self.seq_off = self._host_off.to(device, non_blocking=True)
+        self.mask_off = self._host_moff.to(device, non_blocking=True)
+
+    @classmethod
+    def get(cls, lengths, H: int, device) -> "VarlenGeom":
+        key = (tuple(int(t) for t in lengths), int(H), str(device))
+        g = cls._cache.get(key)
+        if g is None:
+            if len(cls._cache) >= cls._CACHE_MAX:
+                cls._cache.pop(next(iter(cls._cache)))
+            g = cls._cache[key] = cls(lengths, H, device)
+        return g
 
 
 def attn_varlen_supported(Tmax: int, hd: int) -> bool:
@@ -350,11 +373,11 @@ SCATTER_DET = os.environ.get("NEKO_DETERMINISTIC", "0") == "1"
 
 def pack_embed_bwd(desc, tokens, dx, d_embed, d_pos, d_sep, d_img, ntok, d):
     _chk(dx, torch.float32, "dx")
-    if SCATTER_DET and d_embed.shape[0] < 0xFFFFF:
+    if SCATTER_DET and d_embed.shape[0] < 0xFFFFF and d_pos.shape[0] < 0xFFFFF:
         n = int(_lib.load().neko_pack_embed_bwd_det_ws_bytes(ntok, d))
         ws = torch.empty(n, dtype=torch.uint8, device=dx.device)
         _lib.call("neko_pack_embed_bwd_det", _p(desc), _p(tokens), _p(dx), _p(d_embed), _p(d_pos), _p(d_sep), _p(d_img),
-                  ntok, d, int(d_embed.shape[0]), _p(ws), n, _stream())
+                  ntok, d, int(d_embed.shape[0]), int(d_pos.shape[0]), _p(ws), n, _stream())
         return
     _lib.call("neko_pack_embed_bwd", _p(desc), _p(tokens), _p(dx), _p(d_embed), _p(d_pos), _p(d_sep), _p(d_img),
               ntok, d, _stream())

@@ -139,3 +139,41 @@ def test_train_py_with_capture_step(tmp_path, monkeypatch):
         train.main(a)
     finally:
         ops.set_drop_salt(None)
+
+
+def test_captured_ragged_batch_replays_like_eager_steps():
+    """A length-bucketed batch at hd = 32 runs ONE packed attention launch (neko_attn_*_varlen) whose row / mask offset arrays are
+    built on the host.  They must be ready device tensors (or copies from a live pinned buffer) when the step is captured
+    (a copy from a temporary pageable tensor inside the capture would replay from freed host memory): eager steps
+    and replays of the same ragged step agree, and every replay of the captured step keeps using the packed launch."""
+    from neko_amd import engine
+    from neko_amd.tasks import synthetic as S
+    from neko_amd.training.captured import CapturedTrainStep
+    batch = (S.SyntheticTextTask(90, 256, seed=4, device=DEV).sample_batch(3)
+             + S.SyntheticControlTask(5, 2, 9, seed=1, device=DEV).sample_batch(4)
+             + S.SyntheticTextTask(40, 256, seed=5, device=DEV).sample_batch(2))
+    assert engine.ATTN_VARLEN
+    m0 = _policy(0.0)
+    m0.ragged_groups = 3
+    opt0, sch0 = _opt(m0)
+    ref = []
+    for _ in range(6):
+        _, loss = m0.forward(inputs=batch, compute_loss=True, return_logits=False)
+        loss.backward()
+        opt0.clip_grad_norm_(1.0)
+        opt0.step(); sch0.step(); opt0.zero_grad()
+        ref.append(loss.detach())
+    m1 = _policy(0.0)
+    opt1, sch1 = _opt(m1)
+    cap = CapturedTrainStep(m1, opt1, sch1, grad_norm_clip=1.0)
+    got = []
+    try:
+        for _ in range(6):
+            got.append(cap.step(batch, ragged_groups=3)[0])
+        torch.cuda.synchronize()
+        assert cap.replays == 5 and len(cap.entries) == 1
+    finally:
+        cap.close()
+    ref, got = torch.stack(ref).cpu(), torch.stack(got).cpu()
+    assert torch.allclose(got[:4], ref[:4], rtol=2e-5, atol=0), (got, ref)
+    assert torch.allclose(got, ref, rtol=2e-3, atol=0), (got, ref)

@@ -53,9 +53,12 @@ def _batches_rank1_without_loss():
     return _batches()[0], b1
 
 
-def _worker(rank, world, port, out, batches_fn=None):
+def _worker(rank, world, port, out, batches_fn=None, det=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     torch.cuda.set_device(0)
+    if det:
+        from neko_amd import ops
+        ops.SCATTER_DET = True
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from neko_amd.dp import GradReducer
@@ -90,8 +93,9 @@ def _worker(rank, world, port, out, batches_fn=None):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("det", [False, True], ids=["atomic-scatters", "deterministic-scatters"])
 @pytest.mark.parametrize("batches_fn", [_batches, _batches_rank1_without_loss], ids=["both-ranks-have-targets", "rank1-has-no-loss-position"])
-def test_dp_two_ranks_match_single_process_average(batches_fn):
+def test_dp_two_ranks_match_single_process_average(batches_fn, det):
     """Second case: a rank whose batch has no loss position still runs the whole backward (zero
     dlogits) and therefore issues the same per-range collectives in the same order; a mismatch would hang this test."""
     from neko_amd.training.optim import NekoAdamW
@@ -99,7 +103,7 @@ def test_dp_two_ranks_match_single_process_average(batches_fn):
     ctx = mp.get_context("spawn")
     with ctx.Manager() as mgr:
         out = mgr.dict()
-        procs = [ctx.Process(target=_worker, args=(r, world, port, out, batches_fn)) for r in range(world)]
+        procs = [ctx.Process(target=_worker, args=(r, world, port, out, batches_fn, det)) for r in range(world)]
         for p in procs:
             p.start()
         for p in procs:
@@ -114,18 +118,32 @@ def test_dp_two_ranks_match_single_process_average(batches_fn):
     # after ONE step: the first Adam update is lr * g / |g| per element, so an element whose gradient is rounding noise around
     # zero moves by +-lr with a sign that depends on the summation order (gradient accumulation here, all-reduce there) -- from
     # the second step on the two runs are different trajectories at the 1e-4 level (tools/determinism_probe.py).
-    m = _make()
-    opt = NekoAdamW(m, lr=1e-2, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.1)
-    opt.grad_scale = torch.full((1,), 0.5, device="cuda")
-    b0, b1 = (_to_dev(b) for b in batches_fn())
-    for b in (b0, b1):
-        _, loss = m.forward(inputs=b, compute_loss=True, return_logits=False)
-        loss.backward()                      # accumulates into the flat gradient
-    gn = opt.clip_grad_norm_(0.5)
-    opt.step()
-    opt.zero_grad()
-    ref = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    from neko_amd import ops
+    prev_det = ops.SCATTER_DET
+    ops.SCATTER_DET = bool(det)
+    try:
+        m = _make()
+        opt = NekoAdamW(m, lr=1e-2, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.1)
+        opt.grad_scale = torch.full((1,), 0.5, device="cuda")
+        b0, b1 = (_to_dev(b) for b in batches_fn())
+        for b in (b0, b1):
+            _, loss = m.forward(inputs=b, compute_loss=True, return_logits=False)
+            loss.backward()                      # accumulates into the flat gradient
+        gn = opt.clip_grad_norm_(0.5)
+        opt.step()
+        opt.zero_grad()
+        ref = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    finally:
+        ops.SCATTER_DET = prev_det
     assert abs(float(gn) - gnf0) < 1e-5 * gnf0, (float(gn), gnf0)
+    if det:
+        # with the table gradients summed in a fixed order (NEKO_DETERMINISTIC, ABI v15) every gradient of a rank is a
+        # deterministic function of its batch, and fl(g0 + g1) is what both the all-reduce of two ranks and the accumulating
+        # kernels of one process compute: the first update must then agree entry by entry, no noise allowance
+        worst = max(float((v - ref[k]).abs().max()) for k, v in f0.items())
+        nbad = sum(int((~torch.isclose(v, ref[k], rtol=2e-4, atol=2e-6)).sum()) for k, v in f0.items())
+        assert nbad == 0 and worst <= 2e-5, (nbad, worst)
+        return
     bad = 0
     for k, v in f0.items():
         close_ = torch.isclose(v, ref[k], rtol=2e-4, atol=2e-6)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Writes neko_amd/csrc/gemm_a16_loop.inc: the hand-placed main loop of gemm_a16.hip, one instruction stream per operand-layout pair.
 
-    python tools/gen_gemm_a16.py            # regenerate (the .inc is committed; build.py does not run this)
+    python tools/gen_gemm_a16.py [--kc 32|64]           # regenerate (the .inc is committed; build.py does not run this)
 
 Why a generator: the loop is written instruction by instruction (registers, waits and the position of every LDS read and DMA piece
 between the MFMAs are chosen here, not by hipcc), and the four layout variants x 4 unrolled k-tiles differ only in operand-read
@@ -13,168 +13,251 @@ Geometry (one workgroup = 4 waves = one 256 x 256 output tile, one wave per SIMD
   four consecutive columns 4(l>>4)..+3 of a block (one 16-B piece of an output row).
   k-tile = 32: 64 MFMAs per wave between block barriers, one fragment set (8 A + 8 B fragments = 64 VGPRs) per k-tile, two sets
   (v[128:191], v[192:255]) alternating: the next tile's fragments are read from LDS between this tile's MFMAs.
-LDS ring: 4 stages; A stages at s * 16 KB, B stages at 64 KB + s * 16 KB (every read offset fits the 16-bit immediate).
-  k-contiguous operand tile [256 rows][32 k] (64-B rows): 16-B chunk c of row r sits at slot c ^ g[(r>>2)&3], g = [0,2,3,1]:
-      a 16x16x32 fragment is ONE ds_read_b128 per lane (row l&15, chunk l>>4) and all four 16-lane groups of the instruction
-      spread over the 16 slots of a 256-B bank row.
-  k-strided operand tile [32 k][256 cols] (512-B rows): 16-B piece p of k-row k sits at piece p ^ (2 hh(k)),
-      hh(k) = (k&3) | ((k>>3)&1)<<2: a fragment is two ds_read_b64_tr_b16 (k-rows 8(l>>4) + (c>>2) and +4) and the eight k-rows
-      a 32-lane half touches land in eight different 32-B bank segments.
-DMA: global_load_lds_dwordx4, 8 pieces (1 KiB each) per wave per k-tile, three tiles ahead; M0 rewritten per piece (s_add_u32 from
-  the wave's LDS base), the piece's source = 64-bit SGPR base (advanced per tile, frozen at the last tile: the three surplus
-  requests at the end re-fetch the last tile into slots nobody reads) + a loop-invariant per-lane VGPR offset.
-Per tile:  s_waitcnt vmcnt(8) [tile kt+1 landed: this wave's pieces] ; s_waitcnt lgkmcnt(0) [fragment set of tile kt complete] ;
-  s_barrier [tile kt+1 visible from every wave; every wave is past the reads of tile kt-1, whose slot tile kt+3 refills] ;
-  64 MFMAs with the reads of tile kt+1 and the DMA pieces of tile kt+3 placed in fixed gaps.
+LDS: 64 KB per operand (A at 0, B at 64 KB), organised per operand layout:
+  k-strided operand ("ks", rows of the source are k): ring of 4 stages x [32 k][256 cols] (512-B rows); 16-B piece p of k-row k
+      sits at piece p ^ (2 hh(k)), hh(k) = (k&3) | ((k>>3)&1)<<2: a fragment is two ds_read_b64_tr_b16 (k-rows 8(l>>4) + (c>>2)
+      and +4) and the eight k-rows a 32-lane half touches land in eight different 32-B bank segments.  DMA piece = 2 k-rows.
+  k-contiguous operand, --kc 64 ("kc64", the default): TWO slots x [256 rows][64 k] (128-B rows = whole cache lines: with 64-B
+      rows every line of the operand was requested twice, by two consecutive k-tiles, and the L2 -> LDS traffic of the NT form
+      ran near the L2's limit); 16-B chunk c (0..7) of row r sits at position c ^ ((r>>1)&7); a fragment of the k-tile in half h
+      of the slot is ONE ds_read_b128 per lane (row l&15, chunk (l>>4) + 4h) and every 16-lane group of the instruction covers
+      all 16 slots of a 256-B bank row.  DMA piece = 8 rows; a slot (two k-tiles) is requested in one go during an odd tile.
+  k-contiguous operand, --kc 32 ("kc32", the first version, kept for A/B runs): ring of 4 stages x [256 rows][32 k] (64-B rows),
+      chunk c at slot c ^ g[(r>>2)&3], g = [0,2,3,1].  DMA piece = 16 rows.
+DMA: global_load_lds_dwordx4 (1 KiB per wave-instruction); M0 rewritten per piece (s_add_u32 from the wave's LDS base), the
+  piece's source = 64-bit SGPR base (advanced per stage / slot, frozen at the last one: surplus requests at the end re-fetch the
+  last stage into LDS nobody reads any more) + a loop-invariant per-lane VGPR offset.  ks / kc32: tile t+3 is requested during tile
+  t; kc64: the slot of tiles (t+3, t+4) during odd tile t (its previous content, tiles (t-1, t), was last read during tile t-1).
+Per tile:  s_waitcnt vmcnt(N) [tile t+1's data landed: this wave's pieces; N = pieces issued after the last one it needs, computed
+  below by replaying the issue order] ; s_waitcnt lgkmcnt(0) [fragment set of tile t complete] ; s_barrier [tile t+1 visible from
+  every wave; every wave is past the reads of tile t] ; 64 MFMAs with the reads of tile t+1 and the DMA pieces in fixed gaps.
 """
+import argparse
 import os
 import sys
 
-NSTAGE = 4
-A_ALL = 0
-B_ALL = 65536
-STAGE = 16384          # per operand per stage
-NPIECE = 4             # DMA pieces per wave per operand per k-tile
+REGION = {"a": 0, "b": 65536}
 
 # fixed registers (all listed as clobbers in gemm_a16.hip)
-S_GA, S_GB, S_KT, S_CNT, S_M0, S_TA, S_TB = 84, 86, 88, 89, 90, 91, 92
-V_KSA, V_KSB = 96, 104          # 8 address registers each (k-strided operand, one per 16-column / 16-row block)
+S_G = {"a": 84, "b": 86}        # 64-bit DMA source bases
+S_NEXT = {"a": 88, "b": 89}     # index of the next stage / slot to request
+S_LIM = {"a": 90, "b": 91}      # number of stages / slots
+S_CNT, S_M0, S_T = 92, 93, 94
+S_LAST = 95
+V_KS = {"a": 96, "b": 104}      # 8 address registers each (k-strided operand, one per 16-wide block)
 V_FRAG = 128                    # two fragment sets of 64
 
 
-def frag(setp, which, t):
-    """first VGPR of fragment t (0..7) of operand which ('a'/'b') in set setp"""
-    return V_FRAG + 64 * setp + (0 if which == "a" else 32) + 4 * t
+class Op:
+    """one operand: layout mode, LDS addressing, DMA pieces"""
+
+    def __init__(self, which, mode):
+        self.w, self.mode = which, mode
+        self.npiece = 8 if mode == "kc64" else 4              # per wave per request unit (stage or slot)
+
+    def frag(self, setp, t):
+        return V_FRAG + 64 * setp + (0 if self.w == "a" else 32) + 4 * t
+
+    def reads(self, tile_u, setp):
+        """LDS reads of the 8 fragments of tile tile_u (mod 4) into fragment set setp"""
+        out = []
+        for t in range(8):
+            r = self.frag(setp, t)
+            if self.mode == "kc64":
+                slot, half = (tile_u >> 1) & 1, tile_u & 1
+                out.append(f"ds_read_b128 v[{r}:{r + 3}], %[r{self.w}{half}] offset:{slot * 32768 + t * 2048}")
+            elif self.mode == "kc32":
+                out.append(f"ds_read_b128 v[{r}:{r + 3}], %[r{self.w}0] offset:{tile_u * 16384 + t * 1024}")
+            else:
+                base = V_KS[self.w] + t
+                out.append(f"ds_read_b64_tr_b16 v[{r}:{r + 1}], v{base} offset:{tile_u * 16384}")
+                out.append(f"ds_read_b64_tr_b16 v[{r + 2}:{r + 3}], v{base} offset:{tile_u * 16384 + 2048}")
+        return out
+
+    def unit_of_tile(self, t):
+        """request unit (slot index for kc64, stage index otherwise) holding tile t"""
+        return t >> 1 if self.mode == "kc64" else t
+
+    def pieces(self, unit):
+        """[(set M0, issue)] of request unit `unit` (absolute index; its LDS place is unit mod 2 / mod 4)"""
+        out = []
+        for pc in range(self.npiece):
+            if self.mode == "kc64":
+                dst = REGION[self.w] + (unit % 2) * 32768 + pc * 1024
+            else:
+                dst = REGION[self.w] + (unit % 4) * 16384 + pc * 1024
+            sg = S_G[self.w]
+            out.append((f"s_add_u32 m0, %[ldsw{self.w}], {dst}", f"global_load_lds_dwordx4 %[vo{self.w}{pc}], s[{sg}:{sg + 1}]"))
+        return out
+
+    def advance(self):
+        """the base moves on only while unit index + 1 < number of units (afterwards the last unit is re-fetched)"""
+        sg, nx, lim = S_G[self.w], S_NEXT[self.w], S_LIM[self.w]
+        return [f"s_add_u32 s{nx}, s{nx}, 1",
+                f"s_cmp_lt_u32 s{nx}, s{lim}",
+                f"s_cselect_b32 s{S_T}, %[s{self.w}], 0",
+                f"s_add_u32 s{sg}, s{sg}, s{S_T}",
+                f"s_addc_u32 s{sg + 1}, s{sg + 1}, 0"]
+
+    def units_requested_in_tile(self, t):
+        """absolute unit indices requested during tile t of the steady state"""
+        if self.mode == "kc64":
+            return [(t + 3) >> 1] if t % 2 == 1 else []
+        return [t + 3]
 
 
-def reads_for(which, kc, stage, setp):
-    """LDS reads of the 8 fragments of one operand of the tile in ring stage `stage` into set setp"""
-    out = []
-    for t in range(8):
-        r = frag(setp, which, t)
-        if kc:
-            out.append(f"ds_read_b128 v[{r}:{r + 3}], %[r{which}] offset:{stage * STAGE + t * 1024}")
-        else:
-            base = (V_KSA if which == "a" else V_KSB) + t
-            out.append(f"ds_read_b64_tr_b16 v[{r}:{r + 1}], v{base} offset:{stage * STAGE}")
-            out.append(f"ds_read_b64_tr_b16 v[{r + 2}:{r + 3}], v{base} offset:{stage * STAGE + 2048}")
-    return out
-
-
-def dma_piece(which, pc, stage):
-    """(set M0, issue) of one DMA piece; the two must not be adjacent (SALU write of M0 -> LDS-DMA needs one wait state)"""
-    region = A_ALL if which == "a" else B_ALL
-    sg = S_GA if which == "a" else S_GB
-    return (f"s_add_u32 m0, %[ldsw], {region + stage * STAGE + pc * 1024}",
-            f"global_load_lds_dwordx4 %[vo{which}{pc}], s[{sg}:{sg + 1}]")
-
-
-def advance():
-    """next DMA tile: the bases move on only while tile index + 1 < nkt (afterwards the last tile is re-fetched)"""
-    return [f"s_add_u32 s{S_KT}, s{S_KT}, 1",
-            f"s_cmp_lt_u32 s{S_KT}, %[nkt]",
-            f"s_cselect_b32 s{S_TA}, %[sa], 0",
-            f"s_cselect_b32 s{S_TB}, %[sb], 0",
-            f"s_add_u32 s{S_GA}, s{S_GA}, s{S_TA}",
-            f"s_addc_u32 s{S_GA + 1}, s{S_GA + 1}, 0",
-            f"s_add_u32 s{S_GB}, s{S_GB}, s{S_TB}",
-            f"s_addc_u32 s{S_GB + 1}, s{S_GB + 1}, 0"]
-
-
-def mfma(ti, tj, setp):
+def mfma(A, B, ti, tj, setp):
     acc = 4 * (8 * ti + tj)
-    a, b = frag(setp, "a", ti), frag(setp, "b", tj)
+    a, b = A.frag(setp, ti), B.frag(setp, tj)
     return f"v_mfma_f32_16x16x32_bf16 a[{acc}:{acc + 3}], v[{b}:{b + 3}], v[{a}:{a + 3}], a[{acc}:{acc + 3}]"
 
 
-def tile_body(u, a_kc, b_kc, sched):
-    """k-tile with ring stage u (of the 4 unrolled): MFMAs on set u&1, reads of stage u+1 into the other set, DMA into stage u+3"""
-    setp, nxt, dst = u & 1, (u + 1) % NSTAGE, (u + 3) % NSTAGE
-    lines = ["s_waitcnt vmcnt(8)", "s_waitcnt lgkmcnt(0)", "s_barrier"]
-    reads = reads_for("b", b_kc, nxt, setp ^ 1) + reads_for("a", a_kc, nxt, setp ^ 1)
-    pieces = [dma_piece("a", pc, dst) for pc in range(NPIECE)] + [dma_piece("b", pc, dst) for pc in range(NPIECE)]
+class Issue:
+    """replays the DMA issue order to derive the s_waitcnt vmcnt counts"""
+
+    def __init__(self):
+        self.log = []
+
+    def add(self, tag):
+        self.log.append(tag)
+
+    def wait_count(self, needed):
+        """pieces issued after the last piece carrying any of the `needed` (operand, unit) tags"""
+        last = max((i for i, tag in enumerate(self.log) if tag in needed), default=-1)
+        return len(self.log) - 1 - last
+
+
+def tile_body(A, B, t, sched, issue):
+    """k-tile t (absolute, steady state): MFMAs on set t&1, reads of tile t+1 into the other set, DMA requests, wait count"""
+    u, setp = t % 4, t & 1
+    need = {("a", A.unit_of_tile(t + 1)), ("b", B.unit_of_tile(t + 1))}
+    n = issue.wait_count(need)
+    lines = [f"s_waitcnt vmcnt({n})", "s_waitcnt lgkmcnt(0)", "s_barrier"]
+    reads = B.reads((u + 1) % 4, setp ^ 1) + A.reads((u + 1) % 4, setp ^ 1)
+    pieces, adv_after = [], {}
+    for op in (A, B):
+        for unit in op.units_requested_in_tile(t):
+            ps = op.pieces(unit)
+            for p in ps:
+                pieces.append((p, (op.w, unit)))
+            adv_after[len(pieces) - 1] = op.advance()
     fill = {m: [] for m in range(64)}
-    # fragment reads: evenly over MFMAs [0, read_span)
     span = sched["read_span"]
     for i, r in enumerate(reads):
         fill[(i * span) // len(reads)].append(r)
-    # DMA pieces: M0 write after MFMA m, the request after MFMA m+1
-    first, step = sched["dma_first"], sched["dma_step"]
-    for i, (setm0, issue) in enumerate(pieces):
-        m = first + i * step
-        fill[m].append(setm0)
-        fill[m + 1].append(issue)
-    adv = advance()
-    for i, ins in enumerate(adv):
-        fill[min(63, first + len(pieces) * step + i)].append(ins)
+    if pieces:
+        first = sched["dma_first"]
+        step = min(sched["dma_step"], max(2, (60 - first) // len(pieces)))
+        for i, ((setm0, req), tag) in enumerate(pieces):
+            m = first + i * step
+            fill[m].append(setm0)
+            fill[m + 1].append(("DMA", req, tag))
+            if i in adv_after:
+                for k, ins in enumerate(adv_after[i]):
+                    fill[min(63, m + 2 + k // 3)].append(ins)
     order = [(ti, tj) for ti in range(8) for tj in (range(8) if ti % 2 == 0 or not sched["snake"] else range(7, -1, -1))]
     for m, (ti, tj) in enumerate(order):
-        lines.append(mfma(ti, tj, setp))
-        lines += fill[m]
-    return lines
+        lines.append(mfma(A, B, ti, tj, setp))
+        for f in fill[m]:
+            if isinstance(f, tuple):
+                issue.add(f[2])
+                lines.append(f[1])
+            else:
+                lines.append(f)
+    return lines, n
 
 
-def stream(a_kc, b_kc, sched):
-    L = []
-    L += ["s_nop 4",
-          f"s_mov_b32 s{S_M0}, m0",
-          f"s_mov_b32 s{S_GA}, %[galo]", f"s_mov_b32 s{S_GA + 1}, %[gahi]",
-          f"s_mov_b32 s{S_GB}, %[gblo]", f"s_mov_b32 s{S_GB + 1}, %[gbhi]",
-          f"s_mov_b32 s{S_KT}, 0",
-          f"s_lshr_b32 s{S_CNT}, %[nkt], 2"]
-    # per-block LDS addresses of a k-strided operand: base + ((t ^ hh) << 5)
-    for which, kc, vb in (("a", a_kc, V_KSA), ("b", b_kc, V_KSB)):
-        if not kc:
+def stream(a_mode, b_mode, sched):
+    A, B = Op("a", a_mode), Op("b", b_mode)
+    issue = Issue()
+    L = ["s_nop 4", f"s_mov_b32 s{S_M0}, m0"]
+    for op in (A, B):
+        sg = S_G[op.w]
+        L += [f"s_mov_b32 s{sg}, %[g{op.w}lo]", f"s_mov_b32 s{sg + 1}, %[g{op.w}hi]", f"s_mov_b32 s{S_NEXT[op.w]}, 0",
+              f"s_lshr_b32 s{S_LIM[op.w]}, %[nkt], 1" if op.mode == "kc64" else f"s_mov_b32 s{S_LIM[op.w]}, %[nkt]"]
+    L += [f"s_lshr_b32 s{S_CNT}, %[nkt], 2"]
+    for op in (A, B):
+        if op.mode == "ks":                      # per-block LDS addresses: base + ((t ^ hh) << 5)
+            vb = V_KS[op.w]
             for t in range(8):
-                L += [f"v_xor_b32 v{vb + t}, {t}, %[h{which}]", f"v_lshl_add_u32 v{vb + t}, v{vb + t}, 5, %[r{which}]"]
-    # prologue: tiles 0..2 requested, accumulators zeroed underneath
+                L += [f"v_xor_b32 v{vb + t}, {t}, %[h{op.w}]", f"v_lshl_add_u32 v{vb + t}, v{vb + t}, 5, %[r{op.w}0]"]
+    # prologue requests (tile 0's data first), accumulators zeroed underneath
     zero = [f"v_accvgpr_write_b32 a{i}, 0" for i in range(256)]
     zi = 0
-    for t in range(NSTAGE - 1):
-        for which in ("a", "b"):
-            for pc in range(NPIECE):
-                setm0, issue = dma_piece(which, pc, t)
-                L += [setm0, zero[zi], issue] + zero[zi + 1:zi + 8]
-                zi += 8
-        L += advance()
+    # in the order the steady state would have issued them during tiles -3, -2, -1 (the loop body's wait counts assume it)
+    units = [(op, u) for t in (-3, -2, -1) for op in (A, B) for u in op.units_requested_in_tile(t) if u >= 0]
+    for op, u in units:
+        for setm0, req in op.pieces(u):
+            L += [setm0, zero[zi], req] + zero[zi + 1:zi + 4]
+            zi += 4
+            issue.add((op.w, u))
+        L += op.advance()
     L += zero[zi:]
-    # tile 0 landed and visible; its fragments into set 0
-    L += ["s_waitcnt vmcnt(16)", "s_barrier"]
-    L += reads_for("b", b_kc, 0, 0) + reads_for("a", a_kc, 0, 0)
-    L += ["LOOP_%=:"]
-    for u in range(NSTAGE):
-        L += tile_body(u, a_kc, b_kc, sched)
+    n0 = issue.wait_count({("a", 0), ("b", 0)})
+    L += [f"s_waitcnt vmcnt({n0})", "s_barrier"]
+    L += B.reads(0, 0) + A.reads(0, 0)
+    # two trips replayed: the second one's counts are the steady state (the first trip follows the prologue's issue order, which
+    # must give the same counts for the loop to be one body)
+    trips = []
+    for trip in range(3):
+        body, counts = [], []
+        for u in range(4):
+            lines, n = tile_body(A, B, 4 * trip + u, sched, issue)
+            body += lines
+            counts.append(n)
+        trips.append((body, counts))
+    assert trips[0][1] == trips[1][1] == trips[2][1], f"wait counts differ between trips: {[c for _, c in trips]}"
+    L += ["LOOP_%=:"] + trips[1][0]
     L += [f"s_sub_u32 s{S_CNT}, s{S_CNT}, 1", f"s_cmp_lg_u32 s{S_CNT}, 0", "s_cbranch_scc1 LOOP_%="]
     # surplus DMA landed, surplus fragment reads returned (their VGPRs go back to the compiler), accumulators readable
     L += ["s_waitcnt vmcnt(0)", "s_waitcnt lgkmcnt(0)", "s_nop 15", "s_nop 15", "s_barrier", f"s_mov_b32 m0, s{S_M0}"]
-    return L
+    check_scc(L)
+    return L, trips[1][1], n0
+
+
+def check_scc(L):
+    """SCC producer / consumer pairs must be adjacent (s_add_u32 m0 and the other scalar adds all write SCC)"""
+    for i, ins in enumerate(L):
+        if ins.startswith("s_addc_u32") or ins.startswith("s_cselect_b32") or ins.startswith("s_cbranch_scc"):
+            prev = L[i - 1]
+            ok = prev.startswith(("s_add_u32 s", "s_cmp_")) or (ins.startswith("s_cselect") and prev.startswith("s_cselect"))
+            assert ok, f"SCC consumer not behind its producer: {prev} / {ins}"
+        if ins.startswith("global_load_lds"):
+            assert not L[i - 1].startswith("s_add_u32 m0"), "M0 write directly in front of the LDS-DMA that reads it"
 
 
 def clobbers():
     c = ['"memory"', '"vcc"', '"scc"']
-    c += [f'"v{i}"' for i in range(V_KSA, 256)]
-    c += [f'"s{i}"' for i in range(S_GA, S_TB + 1)]
+    c += [f'"v{i}"' for i in range(V_KS["a"], 256)]
+    c += [f'"s{i}"' for i in range(S_G["a"], S_LAST + 1)]
     return ", ".join(c)
 
 
-SCHED = {"read_span": 40, "dma_first": 6, "dma_step": 6, "snake": True}
+SCHED = {"read_span": 40, "dma_first": 4, "dma_step": 6, "snake": True}
 
 
 def main():
-    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "neko_amd", "csrc", "gemm_a16_loop.inc")
-    txt = ["// GENERATED by tools/gen_gemm_a16.py -- do not edit; the generator is the source (design notes in its docstring).", ""]
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--kc", type=int, default=64, choices=(32, 64))
+    ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "neko_amd", "csrc",
+                                                  "gemm_a16_loop.inc"))
+    args = ap.parse_args()
+    kc = f"kc{args.kc}"
+    txt = ["// GENERATED by tools/gen_gemm_a16.py -- do not edit; the generator is the source (design notes in its docstring).",
+           f"#define NEKO_A16_KC_MODE {args.kc}", ""]
     for a_kc in (True, False):
         for b_kc in (True, False):
             name = f"NEKO_A16_LOOP_{'KC' if a_kc else 'KS'}_{'KC' if b_kc else 'KS'}"
-            L = stream(a_kc, b_kc, SCHED)
+            L, counts, n0 = stream(kc if a_kc else "ks", kc if b_kc else "ks", SCHED)
+            txt.append(f"// {name}: vmcnt at the prologue wait {n0}, at the four tiles of a trip {counts}")
             txt.append(f"#define {name} \\")
             txt += [f'  "{ins}\\n\\t" \\' for ins in L[:-1]]
             txt.append(f'  "{L[-1]}"')
             txt.append("")
     txt.append(f"#define NEKO_A16_CLOBBERS {clobbers()}")
     txt.append("")
-    open(out, "w").write("\n".join(txt))
-    print(out, sum(len(t) for t in txt), "bytes")
+    open(args.out, "w").write("\n".join(txt))
+    print(args.out, sum(len(t) for t in txt), "bytes")
 
 
 if __name__ == "__main__":
