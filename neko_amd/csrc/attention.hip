@@ -744,9 +744,9 @@ int bwd_launch(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const f
                const float* lse, float* D, int* qflags, bf16_t* dqkv, int B, int T, int H, int thr, unsigned key,
                float dscale, const uint32_t* dmask, hipStream_t s) {
   const float scale = 1.0f / sqrtf((float)HD);
-  if (neko_attn_path_mode() == 0 && neko_attn_res_applicable(T, HD))
+  if (neko_attn_path_mode() != 1 && neko_attn_res_applicable(T, HD))
     return neko_attn_bwd_res_impl(qkv, out, dout, kbias, kstart, lse, D, dqkv, B, T, H, thr, key, dscale, dmask, s);
-  if (neko_attn_path_mode() == 0 && neko_attn_stream_applicable(T, HD))      // hd = 64 / 128: DMA-ring kernels (attention_stream.hip)
+  if (neko_attn_path_mode() != 1 && neko_attn_stream_applicable(T, HD))      // hd = 64 / 128: DMA-ring kernels (attention_stream.hip)
     return neko_attn_bwd_stream_impl(qkv, out, dout, kbias, kstart, lse, D, dqkv, B, T, H, HD, thr, key, dscale, s);
   const long total = (long)B * T * H;
   hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, out, dout, kbias, D,
@@ -772,28 +772,29 @@ int bwd_launch(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const f
 
 }  // namespace
 
-// schedule selection: 0 = automatic (head-resident kernels of attention_res.hip when they apply), 1 = always the
+// schedule selection: 0 = automatic (head-resident kernels of attention_res.hip when they apply, their backward in one pass), 2 = the same
+// with the two-kernel backward (bit-reproducible: no LDS float atomics), 1 = always the
 // streaming kernels of this file.  A tuning / test knob, not part of the numerics: both schedules compute the same sums.
 static int g_attn_path = 0;
 int neko_attn_path_mode() { return g_attn_path; }
 int neko_attn_set_path_impl(int mode) {
   const int prev = g_attn_path;
-  if (mode == 0 || mode == 1) g_attn_path = mode;
+  if (mode >= 0 && mode <= 2) g_attn_path = mode;
   return prev;
 }
 
 // dwords of the dropout keep-mask buffer neko_attn_fwd fills for neko_attn_bwd (0: the schedule in use re-hashes instead)
 long neko_attn_mask_dwords_impl(int B, int T, int H, int hd) {
-  return g_attn_path == 0 ? neko_attn_res_mask_dwords(B, T, H, hd) : 0;
+  return g_attn_path != 1 ? neko_attn_res_mask_dwords(B, T, H, hd) : 0;
 }
 
 int neko_attn_fwd_impl(const bf16_t* qkv, const float* kbias, const int* kstart, bf16_t* out, float* lse, int B, int T,
                        int H, int hd, int drop_thr, unsigned drop_key, float drop_scale, uint32_t* dmask, hipStream_t s) {
   if (B <= 0 || T <= 0) return NEKO_OK;
   if (!qkv || !kbias || !out || !lse || H <= 0 || drop_thr < 0 || drop_thr > 255) return NEKO_ERR_ARG;
-  if (g_attn_path == 0 && neko_attn_res_applicable(T, hd))
+  if (g_attn_path != 1 && neko_attn_res_applicable(T, hd))
     return neko_attn_fwd_res_impl(qkv, kbias, kstart, out, lse, B, T, H, drop_thr, drop_key, drop_scale, dmask, s);
-  if (g_attn_path == 0 && neko_attn_stream_applicable(T, hd))       // hd = 64 / 128: DMA-ring kernels (attention_stream.hip)
+  if (g_attn_path != 1 && neko_attn_stream_applicable(T, hd))       // hd = 64 / 128: DMA-ring kernels (attention_stream.hip)
     return neko_attn_fwd_stream_impl(qkv, kbias, kstart, out, lse, B, T, H, hd, drop_thr, drop_key, drop_scale, s);
   switch (hd) {
     case 32: return fwd_launch<32>(qkv, kbias, kstart, out, lse, B, T, H, drop_thr, drop_key, drop_scale, s);

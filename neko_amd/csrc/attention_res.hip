@@ -18,6 +18,8 @@
 //     the [B*T, 3d] qkv matrix) run on the same XCD.
 #include "neko_kernels.h"
 
+extern int neko_attn_path_mode();
+
 namespace {
 
 constexpr float MASK_VAL = -10000.0f;
@@ -39,6 +41,9 @@ extern "C" int neko_attn_diag_trace(void* buf) {
 #endif
 #ifndef NEKO_DKV_WAVES
 #define NEKO_DKV_WAVES 12    // waves per dK/dV workgroup; 16 (4 per SIMD, 128 VGPRs: 60 spilled) measured 347 -> 401 us for the backward
+#endif
+#ifndef NEKO_ATTN_FUSED_ABL
+#define NEKO_ATTN_FUSED_ABL 0   // one-pass backward ablations (wrong results): 1 read-add-write without the lock, 2 no dQ accumulation
 #endif
 #ifndef NEKO_ATTN_ABL
 #define NEKO_ATTN_ABL 0      // dK/dV ablations for tools/attn_bench.py (wrong results): 1 no elementwise math in interior
@@ -854,6 +859,363 @@ __global__ __launch_bounds__(NEKO_DKV_WAVES * 64) void attn_dkv_res_kernel(const
   NEKO_ATRACE(3, ntiles_traced);
 }
 
+// =====================================================================================================
+// backward in ONE pass over S / dP (round 4): lanes own keys, dK / dV in registers, dQ through LDS
+// =====================================================================================================
+// The two kernels above each rebuild S = Q.K^T, the exponentials, the dropout decisions and dP = dO.V^T for every 32 x 32
+// sub-tile (6 + 8 MFMAs, 2 x 16 v_exp_f32, twice the elementwise block).  Here every sub-tile is visited once, by the wave that
+// owns its KEY block: P^T.dO and dS^T.Q accumulate in registers as in attn_dkv_res_kernel, and the sub-tile's dQ contribution
+// dS.K -- a contraction over the keys, which are the LANES of this layout -- goes through a per-wave 2 KB LDS scratch: the packed
+// bf16 dS fragments (the very registers the dK MFMA consumes) are stored as [key][query], read back transposed with
+// ds_read_b64_tr_b16 as the A operand of two more MFMAs against K^T (the key block's own K rows, transposed once through the same
+// scratch), and the 32 x 32 fp32 result is added into an LDS accumulator dQ[query][32] (four 16-B read-add-writes per lane under a
+// per-query-block lock).  10 MFMAs and one elementwise block per sub-tile instead of 14 and two.
+// LDS: Q and dO images and the fp32 dQ accumulator for 512 queries = 128 KB, so a head of up to 1024 positions runs in two
+// phases (queries 0..511, then 512..1023); the eight waves own key blocks w and 15 - w across both phases (their dK / dV partial
+// sums stay in registers over the phase boundary: 17 + 32 sub-tiles each, balanced), the key blocks from 16 on are handed out from
+// a queue in the second phase, longest first.  Shorter heads (T <= 512) are one phase with every key block from the queue.
+// The order in which the waves add to a dQ block depends on their timing: dQ is reproducible only to fp32 rounding (then rounded
+// to bf16); the two-kernel form stays available for bit-reproducible runs (neko_attn_set_path(2), NEKO_DETERMINISTIC).
+constexpr int FUSED_Q = 512;      // queries resident per phase
+constexpr int FUSED_W = 8;        // waves per workgroup (2 per SIMD)
+
+// frag_cols for the dS scratch: rows = keys, and inside a row the 8-byte units (4 queries each) sit where the writer's packed
+// accumulator fragments put them: piece 2 s2 + hh of the row holds queries 16 s2 + 4 hh + {0..3} and 16 s2 + 8 + 4 hh + {0..3}
+__device__ __forceinline__ bf16x8_v frag_cols_ds(const char* scr, int s, int lane) {
+  const int g = lane >> 4, c16 = lane & 15;
+  const int v = c16 & 3;                                          // natural unit inside the 16-query half g & 1
+  const int piece = 2 * (g & 1) + (v & 1), byte = 8 * (v >> 1);
+  const int r_lo = 16 * s + 4 * (g >> 1) + (c16 >> 2), r_hi = r_lo + 8;
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(scr + r_lo * 64 + ((piece ^ ((r_lo >> 2) & 3)) << 4) + byte));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(scr + r_hi * 64 + ((piece ^ ((r_hi >> 2) & 3)) << 4) + byte));
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  s16x8 r;
+  r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+  r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+  return __builtin_bit_cast(bf16x8_v, r);
+}
+
+template <bool DROP, bool MASK>
+__global__ __launch_bounds__(FUSED_W * 64) void attn_bwd_fused_res_kernel(
+    const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ outp, const bf16_t* __restrict__ dout, const float* __restrict__ kbias,
+    const float* __restrict__ lse, bf16_t* __restrict__ dqkv, int B, int T_uniform, int H, float scale, uint32_t drop_thr,
+    uint32_t drop_key, float drop_scale, const uint32_t* __restrict__ dmask, const int* __restrict__ seq_off,
+    const long long* __restrict__ mask_off, int T4_varlen, int Rmax) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  if (DROP) drop_key += neko_drop_salt();
+  const int hb = pair_remap(blockIdx.x, B * H);
+  const int b = hb / H, h = hb % H;
+  const SeqGeom sg = seq_geom(b, h, H, T_uniform, seq_off, mask_off, T4_varlen);
+  const int T = sg.T;
+  const int Tp = (T + 31) & ~31, nblk = Tp >> 5;
+  // LDS carve (Rmax = resident query rows the launch was sized for)
+  char* imgQ = smem;
+  char* imgdO = imgQ + Rmax * 64;
+  float* dQacc = reinterpret_cast<float*>(imgdO + Rmax * 64);
+  float* ldsLse = dQacc + Rmax * 32;
+  float* ldsD = ldsLse + Rmax;
+  char* scratch = reinterpret_cast<char*>(ldsD + Rmax);
+  int* queue = reinterpret_cast<int*>(scratch + FUSED_W * 2048);
+  int* locks = queue + 4;                                    // one per resident query block (16)
+  const int tid = threadIdx.x, lane = tid & 63, nthr = blockDim.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  char* scr = scratch + wave * 2048;
+  const int d = H * 32;
+  const long ld = 3L * d;
+  const bf16_t* qbase = qkv + sg.row0 * ld + h * 32;
+  const bf16_t* dobase = dout + sg.row0 * d + h * 32;
+  const bf16_t* obase = outp + sg.row0 * d + h * 32;
+  const float* kb = kbias + sg.row0;
+  const float* lse_b = lse + sg.hrow;
+
+  float padv[16];
+  pad_mask_load(kb, T, nblk, lane, padv);
+  const uint32_t padmask = pad_mask_ballot(padv);            // bit j: block j holds a padded position
+  const float scale2 = scale * LOG2E;
+  const uint32_t T4 = sg.T4;
+  const int nph = Tp > FUSED_Q ? 2 : 1;
+  const float inv_ds = DROP ? 1.0f / drop_scale : 1.0f;
+
+  f32x16 sdk0, sdv0, sdk1, sdv1;       // partial dK / dV of the wave's two static key blocks, carried over the phase boundary
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { sdk0[r] = 0.f; sdv0[r] = 0.f; sdk1[r] = 0.f; sdv1[r] = 0.f; }
+
+#pragma unroll 1
+  for (int ph = 0; ph < nph; ++ph) {
+    const int qlo = ph * FUSED_Q;
+    const int R = min(Tp - qlo, FUSED_Q);                    // resident rows of this phase (multiple of 32)
+    const int qb_lo = qlo >> 5, qb_hi = qb_lo + (R >> 5);    // query blocks [qb_lo, qb_hi)
+    if (ph) __syncthreads();                                 // every wave is past the previous phase's images and accumulator
+    if (tid == 0) *queue = 0;
+    if (tid < 16) locks[tid] = 0;
+    // ---- staging: Q, dO images (rows qlo ..), D = sum dO.O / s, -lse, zeroed dQ accumulator --------------------------------------
+    {
+      constexpr int NB = 4;                                  // 4 * 512 slots = 512 rows x 4 pieces: one round
+      const int total = R * 4;
+      for (int c0 = 0; c0 < total; c0 += nthr * NB) {
+        uint4 rq[NB], rdo[NB], ro[NB];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+          const int c = c0 + i * nthr + tid, row = c >> 2, pc = c & 3;
+          rq[i] = make_uint4(0, 0, 0, 0);
+          rdo[i] = make_uint4(0, 0, 0, 0);
+          ro[i] = make_uint4(0, 0, 0, 0);
+          if (c < total && qlo + row < T) {
+            rq[i] = *reinterpret_cast<const uint4*>(qbase + (long)(qlo + row) * ld + pc * 8);
+            rdo[i] = *reinterpret_cast<const uint4*>(dobase + (long)(qlo + row) * d + pc * 8);
+            ro[i] = *reinterpret_cast<const uint4*>(obase + (long)(qlo + row) * d + pc * 8);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+          const int c = c0 + i * nthr + tid, row = c >> 2, pc = c & 3;
+          float part = dot8_bf16(rdo[i], ro[i]);             // the 4 pieces of a row sit in the 4 lanes of a quad
+          part += __shfl_xor(part, 1, 64);
+          part += __shfl_xor(part, 2, 64);
+          if (c < total) {
+            *reinterpret_cast<uint4*>(imgQ + img_off(row, pc)) = rq[i];
+            *reinterpret_cast<uint4*>(imgdO + img_off(row, pc)) = rdo[i];
+            if (pc == 0) ldsD[row] = part * inv_ds;
+          }
+        }
+      }
+      for (int r = tid; r < R; r += nthr) ldsLse[r] = (qlo + r < T) ? -lse_b[qlo + r] * LOG2E : 0.f;
+      for (int i = tid; i < R * 8; i += nthr) reinterpret_cast<float4*>(dQacc)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    // bit j of qactive: query block j (of this phase's window) holds a masked row whose dO is not exactly zero -- only such rows
+    // reach keys beyond their diagonal (see attn_dkv_res_kernel)
+    uint32_t qactive = 0;
+    for (uint32_t m = padmask & (qb_hi >= 32 ? 0xffffffffu : ((1u << qb_hi) - 1u)) & ~((1u << qb_lo) - 1u); m; m &= m - 1) {
+      const int j = __ffs(m) - 1, row = (j - qb_lo) * 32 + (lane & 31);
+      const uint4 u0 = *reinterpret_cast<const uint4*>(imgdO + img_off(row, (lane >> 5) * 2));
+      const uint4 u1 = *reinterpret_cast<const uint4*>(imgdO + img_off(row, (lane >> 5) * 2 + 1));
+      const bool nz = ((u0.x | u0.y | u0.z | u0.w | u1.x | u1.y | u1.z | u1.w) != 0u) && qlo + row < T && kb[qlo + row] != 0.f;
+      if (__builtin_amdgcn_ballot_w64(nz) != 0) qactive |= 1u << j;
+    }
+
+    // ---- this wave's key blocks of the phase ---------------------------------------------------------------------------------
+#pragma unroll 1
+    for (int u = 0;; ++u) {
+      const bool is_static = nph == 2 && u < 2;
+      int kbw;
+      if (is_static) kbw = u == 0 ? wave : 15 - wave;
+      else {
+        if (nph == 2 && ph == 0) break;
+        kbw = (nph == 2 ? 16 : 0) + next_item(queue, lane);
+        if (kbw >= qb_hi) break;                             // key blocks beyond the window's last query block see none of it
+      }
+      const int kw0 = kbw * 32;
+      const int key = kw0 + (lane & 31);
+      const bool kvalid = key < T;
+      const float my_kb = (kvalid ? kb[key] : 0.f) * LOG2E;
+      bf16x8_v kf[2], vf[2];
+      row_frags(qbase + d + (long)key * ld, kvalid, lane, kf);
+      row_frags(qbase + 2 * d + (long)key * ld, kvalid, lane, vf);
+      const bool keys_plain = (kw0 + 31 < T) && !((padmask >> kbw) & 1);
+      // K^T of the block (head dim on the lanes) through the scratch: the B operand of the dQ products
+      *reinterpret_cast<uint4*>(scr + img_off(lane & 31, lane >> 5)) = __builtin_bit_cast(uint4, kf[0]);
+      *reinterpret_cast<uint4*>(scr + img_off(lane & 31, 2 + (lane >> 5))) = __builtin_bit_cast(uint4, kf[1]);
+      bf16x8_v kT[2];
+      kT[0] = frag_cols(scr, 0, 0, lane);
+      kT[1] = frag_cols(scr, 0, 1, lane);
+
+      f32x16 dk, dv;
+      if (is_static && ph == 1) {
+        if (u == 0) { dk = sdk0; dv = sdv0; } else { dk = sdk1; dv = sdv1; }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk[r] = 0.f; dv[r] = 0.f; }
+      }
+      const int ksh = 8 * (lane & 3);
+      auto next_qb = [&](int from) {                         // next visited query block >= from inside the window
+        int nq = max(from, qb_lo);
+        while (nq < kbw && nq < qb_hi && !((qactive >> nq) & 1)) ++nq;
+        return nq;
+      };
+      const uint32_t* mcol = (DROP && MASK) ? dmask + sg.mask0 + (long)kbw * 32 + mask_slot_of_key(lane & 31) : nullptr;
+      auto mask_word = [&](int q) { return (DROP && MASK) ? mcol[(long)min(q, nblk - 1) * nblk * 32] : 0xFFFFFFFFu; };
+      // this lane's row of a query block inside the accumulator: row (lane & 31), 16-B unit u of the row (4 head-dim columns) at
+      // unit u ^ ((row >> 1) & 7) -- the 16 lanes of a ds_read_b128 group then cover 16 different units of the 256-B bank row
+      const int dq_swz = ((lane & 31) >> 1) & 7;
+      float* dq_lane = dQacc + (lane & 31) * 32;                           // + local query block * 1024
+      auto sub_tile = [&](const int qb, const uint32_t wraw) {
+        const int q0 = qb * 32, ql0 = q0 - qlo;                 // global / resident first query of the block
+        const uint32_t wsh = wraw >> (4 * (lane >> 5));
+        f32x16 st, dpt;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { st[r] = 0.f; dpt[r] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(imgQ, ql0, ks, lane), kf[ks], st, 0, 0, 0);
+          dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(imgdO, ql0, ks, lane), vf[ks], dpt, 0, 0, 0);
+        }
+        uint32_t mine[4] = {0u, 0u, 0u, 0u};
+        if (DROP && !MASK) {
+          const uint32_t gq = ((uint32_t)sg.hrow + (uint32_t)(q0 + 4 * (lane >> 5) + (lane & 3))) * T4 + (uint32_t)(key >> 2);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) mine[j] = drop_word(gq + (uint32_t)(8 * j) * T4, drop_key);
+        }
+        const float* lq = ldsLse + ql0 + 4 * (lane >> 5);
+        const float* dq_ = ldsD + ql0 + 4 * (lane >> 5);
+        const bool interior = (qb > kbw) && (q0 + 31 < T) && keys_plain;
+        if (interior) {
+#pragma unroll
+          for (int r = 0; r < 16; r += 2) {
+            const int c = (r & 3) + 8 * (r >> 2);
+            const f32x2_v nlse_q = pk2(lq[c], lq[c + 1]), d_q = pk2(dq_[c], dq_[c + 1]);
+            const f32x2_v pv = exp2_fast2(__builtin_elementwise_fma(pk2(st[r], st[r + 1]), (f32x2_v)(scale2), nlse_q));
+            f32x2_v ds;
+            if (DROP) {
+              f32x2_v pd;
+              if (MASK) {
+                pd.x = __uint_as_float(__float_as_uint(pv.x) & keep_bits(wsh, c));
+                pd.y = __uint_as_float(__float_as_uint(pv.y) & keep_bits(wsh, c + 1));
+              } else {
+                pd.x = __builtin_amdgcn_ubfe(quad_bcast(mine[r >> 2], r & 3), ksh, 8) >= drop_thr ? pv.x : 0.f;
+                pd.y = __builtin_amdgcn_ubfe(quad_bcast(mine[r >> 2], (r + 1) & 3), ksh, 8) >= drop_thr ? pv.y : 0.f;
+              }
+              ds = __builtin_elementwise_fma(pd, pk2(dpt[r], dpt[r + 1]), -(pv * d_q));
+              st[r] = pd.x;
+              st[r + 1] = pd.y;
+            } else {
+              ds = pv * (pk2(dpt[r], dpt[r + 1]) - d_q);
+              st[r] = pv.x;
+              st[r + 1] = pv.y;
+            }
+            dpt[r] = ds.x;
+            dpt[r + 1] = ds.y;
+          }
+        } else {
+          const int lim_causal = q0 + 4 * (lane >> 5) - key;
+          const int lim_len = T - 1 - q0 - 4 * (lane >> 5);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int c = (r & 3) + 8 * (r >> 2);
+            const bool causal_ok = (-c) <= lim_causal;
+            const float sv = (causal_ok ? st[r] * scale2 : MASK_VAL * LOG2E) + my_kb;
+            const float nlse_q = lq[c], d_q = dq_[c];
+            const float pv = exp2_fast((c <= lim_len && kvalid) ? sv + nlse_q : -INFINITY);
+            float pd = pv, dpe = dpt[r];
+            if (DROP) {
+              if (MASK) {
+                const uint32_t km = (uint32_t)__builtin_amdgcn_sbfe((int)wsh, c, 1);
+                pd = __uint_as_float(__float_as_uint(pv) & km);
+                dpe = __uint_as_float(__float_as_uint(dpe) & km);
+              } else {
+                const bool keep = __builtin_amdgcn_ubfe(quad_bcast(mine[r >> 2], r & 3), ksh, 8) >= drop_thr;
+                pd = keep ? pv : 0.f;
+                dpe = keep ? dpe : 0.f;
+              }
+            }
+            st[r] = pd;
+            dpt[r] = causal_ok ? pv * (dpe - d_q) : 0.f;
+          }
+        }
+        const bf16x8_v dsf0 = frag_from_acc(dpt, 0), dsf1 = frag_from_acc(dpt, 1);
+        // dS as [key][query] into the scratch (one 16-B piece per fragment), ahead of the dV / dK products that hide the round trip
+        *reinterpret_cast<uint4*>(scr + img_off(lane & 31, lane >> 5)) = __builtin_bit_cast(uint4, dsf0);
+        *reinterpret_cast<uint4*>(scr + img_off(lane & 31, 2 + (lane >> 5))) = __builtin_bit_cast(uint4, dsf1);
+        dv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(imgdO, ql0, 0, lane), frag_from_acc(st, 0), dv, 0, 0, 0);
+        dk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(imgQ, ql0, 0, lane), dsf0, dk, 0, 0, 0);
+        dv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(imgdO, ql0, 1, lane), frag_from_acc(st, 1), dv, 0, 0, 0);
+        dk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(imgQ, ql0, 1, lane), dsf1, dk, 0, 0, 0);
+        // dQ^T[hd][query] += K^T[hd][key] . dS^T[key][query]: lanes = queries, registers = head-dim columns c(r) + 4 (lane / 32),
+        // i.e. four 16-B units of the lane's accumulator row.  The accumulator block of a query block is shared by the waves
+        // (one per key block): read-add-write under the block's lock, taken by lane 0 with a compare-and-swap that is issued
+        // BEFORE the products (its round trip hides under them); LDS float atomics are not an option -- ds_add_f32 retires about
+        // one lane per three cycles (16 of them per sub-tile: 4.4 ms per call instead of 0.65, profiles/r04_attn_fused.txt).
+        int* lock = locks + (ql0 >> 5);
+        int busy = 0;
+#if NEKO_ATTN_FUSED_ABL == 0
+        {
+          int expect = 0;
+          if (lane == 0) busy = __hip_atomic_compare_exchange_strong(lock, &expect, 1, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ? 0 : 1;
+        }
+#endif
+        f32x16 dqt;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dqt[r] = 0.f;
+        dqt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kT[0], frag_cols_ds(scr, 0, lane), dqt, 0, 0, 0);
+        dqt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kT[1], frag_cols_ds(scr, 1, lane), dqt, 0, 0, 0);
+#if NEKO_ATTN_FUSED_ABL == 0
+        busy = __builtin_amdgcn_readfirstlane(busy);
+        while (busy) {                                           // another wave is adding to this query block: a few hundred cycles
+          __builtin_amdgcn_s_sleep(2);
+          int expect = 0;
+          if (lane == 0) busy = __hip_atomic_compare_exchange_strong(lock, &expect, 1, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ? 0 : 1;
+          busy = __builtin_amdgcn_readfirstlane(busy);
+        }
+#endif
+        float* drow = dq_lane + ql0 * 32;
+#if NEKO_ATTN_FUSED_ABL != 2
+        float4 acc4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc4[j] = *reinterpret_cast<const float4*>(drow + (((2 * j + (lane >> 5)) ^ dq_swz) << 2));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc4[j].x += dqt[4 * j]; acc4[j].y += dqt[4 * j + 1]; acc4[j].z += dqt[4 * j + 2]; acc4[j].w += dqt[4 * j + 3];
+          *reinterpret_cast<float4*>(drow + (((2 * j + (lane >> 5)) ^ dq_swz) << 2)) = acc4[j];
+        }
+#else
+#pragma unroll
+        for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(dqt[r]));
+#endif
+#if NEKO_ATTN_FUSED_ABL == 0
+        if (lane == 0) __hip_atomic_store(lock, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+      };
+      int qb = next_qb(0);
+      uint32_t wnext = mask_word(qb);
+#pragma unroll 1
+      while (qb < qb_hi) {
+        const int qb_next = next_qb(qb + 1);
+        const uint32_t w = wnext;
+        wnext = mask_word(qb_next);
+        sub_tile(qb, w);
+        qb = qb_next;
+      }
+
+      if (is_static && ph == 0) {
+        if (u == 0) { sdk0 = dk; sdv0 = dv; } else { sdk1 = dk; sdv1 = dv; }
+      } else {
+        const float vsc = DROP ? drop_scale : 1.0f, ksc = scale * vsc;
+        if (kvalid) {
+          bf16_t* krow = dqkv + (sg.row0 + key) * ld + d + h * 32;
+          bf16_t* vrow = krow + d;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            uint2 pk;
+            pk.x = pack_bf16x2(dk[4 * g + 0] * ksc, dk[4 * g + 1] * ksc);
+            pk.y = pack_bf16x2(dk[4 * g + 2] * ksc, dk[4 * g + 3] * ksc);
+            *reinterpret_cast<uint2*>(krow + 8 * g + 4 * (lane >> 5)) = pk;
+            pk.x = pack_bf16x2(dv[4 * g + 0] * vsc, dv[4 * g + 1] * vsc);
+            pk.y = pack_bf16x2(dv[4 * g + 2] * vsc, dv[4 * g + 3] * vsc);
+            *reinterpret_cast<uint2*>(vrow + 8 * g + 4 * (lane >> 5)) = pk;
+          }
+        }
+      }
+    }
+    __syncthreads();                                         // every wave's ds_add_f32 has been issued and completed
+    // ---- dQ rows of the phase: fp32 accumulator -> bf16, scaled once ---------------------------------------------------------
+    {
+      const float qs = scale * (DROP ? drop_scale : 1.0f);
+      for (int c = tid; c < R * 4; c += nthr) {
+        const int row = c >> 2, pc = c & 3;
+        if (qlo + row < T) {
+          const int swz = ((row & 31) >> 1) & 7;
+          const float4 a = *reinterpret_cast<const float4*>(dQacc + row * 32 + (((2 * pc) ^ swz) << 2));
+          const float4 b4 = *reinterpret_cast<const float4*>(dQacc + row * 32 + (((2 * pc + 1) ^ swz) << 2));
+          const uint4 pk = make_uint4(pack_bf16x2(a.x * qs, a.y * qs), pack_bf16x2(a.z * qs, a.w * qs),
+                                      pack_bf16x2(b4.x * qs, b4.y * qs), pack_bf16x2(b4.z * qs, b4.w * qs));
+          *reinterpret_cast<uint4*>(dqkv + (sg.row0 + qlo + row) * ld + h * 32 + pc * 8) = pk;
+        }
+      }
+    }
+  }
+}
+
 template <typename K>
 int allow_lds(K kernel, size_t bytes) {
   return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) ==
@@ -904,6 +1266,24 @@ int neko_attn_bwd_res_impl(const bf16_t* qkv, const bf16_t* out, const bf16_t* d
                            float drop_scale, const uint32_t* dmask, hipStream_t s, const int* seq_off,
                            const long long* mask_off) {
   if (!D) return NEKO_ERR_ARG;          // f32 [rows * H]: the dQ kernel leaves sum_hd dO.O / s there for the dK/dV kernel
+  if (neko_attn_path_mode() != 2) {     // one pass over S / dP (attn_bwd_fused_res_kernel); path 2 keeps the two bit-reproducible kernels
+    const int Tp = (T + 31) & ~31, Rmax = min(Tp, FUSED_Q);
+    const size_t lds = (size_t)Rmax * (128 + 128 + 8) + FUSED_W * 2048 + 16 + 64;
+    const float scale = 1.0f / sqrtf(32.0f);
+    const int T4 = (T + 3) >> 2;
+    static const int once_f = allow_lds(attn_bwd_fused_res_kernel<true, true>, 160 * 1024) | allow_lds(attn_bwd_fused_res_kernel<true, false>, 160 * 1024) |
+                              allow_lds(attn_bwd_fused_res_kernel<false, false>, 160 * 1024);
+    if (once_f != NEKO_OK) return once_f;
+#define NEKO_BWD_FUSED(DROPV, MASKV, THR, MP)                                                                                       \
+    hipLaunchKernelGGL((attn_bwd_fused_res_kernel<DROPV, MASKV>), dim3(B * H), dim3(FUSED_W * 64), lds, s, qkv, out, dout, kbias, lse, \
+                       dqkv, B, T, H, scale, (uint32_t)(THR), drop_key, drop_scale, MP, seq_off, mask_off, T4, Rmax)
+    if (drop_thr && dmask) NEKO_BWD_FUSED(true, true, drop_thr, dmask);
+    else if (drop_thr) NEKO_BWD_FUSED(true, false, drop_thr, nullptr);
+    else NEKO_BWD_FUSED(false, false, 0, nullptr);
+#undef NEKO_BWD_FUSED
+    NEKO_CHECK_LAUNCH();
+    return NEKO_OK;
+  }
   const int Tp = (T + 31) & ~31, nblk = Tp / 32, nw = min(12, (nblk + 1) / 2), nw_kv = min(NEKO_DKV_WAVES, (nblk + 1) / 2);
   const size_t lds_q = (size_t)Tp * 128 + (size_t)Tp * 4 + 16, lds_kv = (size_t)Tp * 128 + (size_t)Tp * 8 + 16;
   const float scale = 1.0f / sqrtf(32.0f);

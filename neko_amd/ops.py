@@ -285,6 +285,24 @@ def attn_fwd_varlen(qkv, kbias, kstart, geom: VarlenGeom, hd, drop=None, out=Non
     return out, lse, mask
 
 
+class _DetAttnPath:
+    """Under NEKO_DETERMINISTIC (SCATTER_DET) the head-resident attention backward runs as its two kernels (neko_attn_set_path(2)):
+    the one-pass form adds dQ up through LDS float atomics in arrival order, the two-kernel form is bit-reproducible."""
+
+    def __enter__(self):
+        self.prev = None
+        if SCATTER_DET:
+            self.prev = attn_set_path(2)
+            if self.prev == 1:                   # a forced streaming schedule stays
+                attn_set_path(1)
+        return self
+
+    def __exit__(self, *exc):
+        if self.prev is not None and self.prev != 1:
+            attn_set_path(self.prev)
+        return False
+
+
 def attn_bwd_varlen(qkv, out, dout, kbias, kstart, lse, geom: VarlenGeom, hd, drop=None, dqkv=None, mask=None):
     _chk(dout, BF16, "dout")
     H = geom.H
@@ -293,8 +311,9 @@ def attn_bwd_varlen(qkv, out, dout, kbias, kstart, lse, geom: VarlenGeom, hd, dr
         dqkv = torch.empty_like(qkv)
     if mask is not None:
         _chk(mask, torch.int32, "mask"); assert mask.numel() == geom.mask_dwords
-    _lib.call("neko_attn_bwd_varlen", _p(qkv), _p(out), _p(dout), _p(kbias), _p(kstart), _p(geom.seq_off), _p(geom.mask_off),
-              _p(lse), _p(D), _p(dqkv), geom.nseq, geom.Tmax, H, hd, *_drop(drop), _p(mask), _stream())
+    with _DetAttnPath():
+        _lib.call("neko_attn_bwd_varlen", _p(qkv), _p(out), _p(dout), _p(kbias), _p(kstart), _p(geom.seq_off), _p(geom.mask_off),
+                  _p(lse), _p(D), _p(dqkv), geom.nseq, geom.Tmax, H, hd, *_drop(drop), _p(mask), _stream())
     return dqkv
 
 
@@ -313,8 +332,9 @@ def attn_bwd(qkv, out, dout, kbias, kstart, lse, B, T, H, hd, drop=None, dqkv=No
     if mask is not None:
         _chk(mask, torch.int32, "mask")
         assert mask.numel() == int(_lib.load().neko_attn_mask_dwords(B, T, H, hd)), "mask buffer of another call / schedule"
-    _lib.call("neko_attn_bwd", _p(qkv), _p(out), _p(dout), _p(kbias), _p(kstart), _p(lse), _p(D), _p(qflags),
-              _p(dqkv), B, T, H, hd, *_drop(drop), _p(mask), _stream())
+    with _DetAttnPath():
+        _lib.call("neko_attn_bwd", _p(qkv), _p(out), _p(dout), _p(kbias), _p(kstart), _p(lse), _p(D), _p(qflags),
+                  _p(dqkv), B, T, H, hd, *_drop(drop), _p(mask), _stream())
     return dqkv
 
 

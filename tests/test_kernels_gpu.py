@@ -392,10 +392,11 @@ def _masks(B, T, kind):
     return m
 
 
-@pytest.fixture(params=["auto", "streaming"])
+@pytest.fixture(params=["auto", "split", "streaming"])
 def attn_path(request, ops):
-    """Both attention schedules (head-resident for hd = 32 / T <= 1024, streaming for everything) against the oracle."""
-    prev = ops.attn_set_path(1 if request.param == "streaming" else 0)
+    """Every attention schedule against the oracle: head-resident for hd = 32 / T <= 1024 with the backward in ONE pass (auto),
+    the same with the two-kernel backward (split: neko_attn_set_path(2), the bit-reproducible form), streaming for everything."""
+    prev = ops.attn_set_path({"auto": 0, "split": 2, "streaming": 1}[request.param])
     yield request.param
     ops.attn_set_path(prev)
 
@@ -407,6 +408,8 @@ def attn_path(request, ops):
 def test_attention_fwd_bwd(ops, attn_path, B, T, H, hd, mask_kind):
     if attn_path == "streaming" and hd == 32 and T >= 1000 and mask_kind in ("right", "holes"):
         pytest.skip("large streaming cases are covered by the 'none' and 'left' masks")
+    if attn_path == "split" and hd != 32:
+        pytest.skip("the split / one-pass choice only exists for the head-resident kernels (hd = 32)")
     if T < 16 and mask_kind != "none":
         pytest.skip("mask pattern needs T >= 16")
     g = torch.Generator().manual_seed(B * 1000 + T + hd)
@@ -695,7 +698,9 @@ def test_patch_pos_add_bwd_sorted_sums_are_exact_in_order_and_reproducible(ops, 
         ops.patch_pos_add_bwd(out.to(DEV), hp.to(DEV), wp.to(DEV), dr, dc)
     finally:
         ops.SCATTER_DET = prev
-    close(dr, ref_r.float(), 1e-5, tol, "atomic row"); close(dc, ref_c.float(), 1e-5, tol, "atomic col")
+    # the atomic form adds in arrival order: its error on the hot row (P / 2 addends) is a random walk that differs from run to run
+    # (seen once outside 1 x tol in ~6 runs of this file), hence the wider allowance for it
+    close(dr, ref_r.float(), 1e-5, 3 * tol, "atomic row"); close(dc, ref_c.float(), 1e-5, 3 * tol, "atomic col")
 
 
 @pytest.mark.parametrize("drop_p", [0.0, 0.1])
@@ -714,7 +719,7 @@ def test_attention_schedules_agree_at_metric_shape(ops, drop_p):
     kb, ks = ops.mask_bias(mask)
     drop = ops.Drop(drop_p, 0x2468ACE) if drop_p > 0 else None
     res = {}
-    for path in (0, 1):
+    for path in (0, 1, 2):
         prev = ops.attn_set_path(path)
         try:
             out, lse = ops.attn_fwd(qkv, kb, ks, B, T, H, hd, drop=drop)
@@ -726,6 +731,11 @@ def test_attention_schedules_agree_at_metric_shape(ops, drop_p):
     assert float((res[0][0] - res[1][0]).abs().max()) < 2 ** -7 * so
     assert float((res[0][1] - res[1][1]).abs().max()) < 1e-4 * float(res[1][1].abs().max())
     assert float((res[0][2] - res[1][2]).abs().max()) < 2 ** -6 * sg
+    # one-pass against two-kernel head-resident backward: dV is the same sums in the same order (bit-equal); dK sees D = sum dO.O
+    # added up in another order (fp32 rounding), dQ is added up block by block in the order the waves arrive
+    assert torch.equal(res[0][0], res[2][0]) and torch.equal(res[0][1], res[2][1])
+    assert torch.equal(res[0][2][:, 2 * d:], res[2][2][:, 2 * d:]), "dV of the one-pass backward"
+    assert float((res[0][2][:, :2 * d] - res[2][2][:, :2 * d]).abs().max()) < 2 ** -7 * sg
 
 
 def test_lm_head_chunking_is_invisible(ops):
@@ -781,17 +791,27 @@ def test_attention_varlen_equals_per_sequence_calls(ops):
     geom = ops.VarlenGeom(lengths, H, DEV)
     assert geom.rows == rows
     kb_all, ks_all = torch.cat(kbs), torch.cat(kss)
-    out, lse, _ = ops.attn_fwd_varlen(qkv, kb_all, ks_all, geom, hd)
-    dqkv = ops.attn_bwd_varlen(qkv, out, do, kb_all, ks_all, lse, geom, hd)
-    r0 = 0
-    for i, T in enumerate(lengths):
-        q1 = qkv[r0:r0 + T].contiguous()
-        o1, l1 = ops.attn_fwd(q1, kbs[i].view(1, T), kss[i], 1, T, H, hd)
-        g1 = ops.attn_bwd(q1, o1, do[r0:r0 + T].contiguous(), kbs[i].view(1, T), kss[i], l1, 1, T, H, hd)
-        assert torch.equal(out[r0:r0 + T], o1), f"out of sequence {i}"
-        assert torch.equal(lse[r0 * H:(r0 + T) * H].view(H, T), l1.view(H, T)), f"lse of sequence {i}"
-        assert torch.equal(dqkv[r0:r0 + T], g1), f"dqkv of sequence {i}"
-        r0 += T
+    for path in (2, 0):        # 2: two-kernel backward, everything bit-equal; 0: one-pass backward, dQ added up in arrival order
+        prev = ops.attn_set_path(path)
+        try:
+            out, lse, _ = ops.attn_fwd_varlen(qkv, kb_all, ks_all, geom, hd)
+            dqkv = ops.attn_bwd_varlen(qkv, out, do, kb_all, ks_all, lse, geom, hd)
+            r0 = 0
+            for i, T in enumerate(lengths):
+                q1 = qkv[r0:r0 + T].contiguous()
+                o1, l1 = ops.attn_fwd(q1, kbs[i].view(1, T), kss[i], 1, T, H, hd)
+                g1 = ops.attn_bwd(q1, o1, do[r0:r0 + T].contiguous(), kbs[i].view(1, T), kss[i], l1, 1, T, H, hd)
+                assert torch.equal(out[r0:r0 + T], o1), f"out of sequence {i}"
+                assert torch.equal(lse[r0 * H:(r0 + T) * H].view(H, T), l1.view(H, T)), f"lse of sequence {i}"
+                if path == 2:
+                    assert torch.equal(dqkv[r0:r0 + T], g1), f"dqkv of sequence {i}"
+                else:
+                    assert torch.equal(dqkv[r0:r0 + T, d:], g1[:, d:]), f"dK / dV of sequence {i}"
+                    dq_a, dq_b = dqkv[r0:r0 + T, :d].float(), g1[:, :d].float()
+                    assert float((dq_a - dq_b).abs().max()) <= 2 ** -7 * float(dq_b.abs().max()), f"dQ of sequence {i}"
+                r0 += T
+        finally:
+            ops.attn_set_path(prev)
 
 
 def test_attention_varlen_dropout_masks_are_consistent(ops):
@@ -813,7 +833,16 @@ def test_attention_varlen_dropout_masks_are_consistent(ops):
     assert mk is not None and mk.numel() == geom.mask_dwords
     g_mask = ops.attn_bwd_varlen(qkv, out, do, kb, ks, lse, geom, hd, drop=drop, mask=mk)
     g_hash = ops.attn_bwd_varlen(qkv, out, do, kb, ks, lse, geom, hd, drop=drop, mask=None)
-    assert torch.equal(g_mask, g_hash)
+    assert torch.equal(g_mask[:, d:], g_hash[:, d:])             # one-pass backward: dK / dV bit-equal, dQ to fp32 summation order
+    assert float((g_mask[:, :d].float() - g_hash[:, :d].float()).abs().max()) <= 2 ** -7 * float(g_hash[:, :d].float().abs().max())
+    prev = ops.attn_set_path(2)
+    try:
+        g_mask2 = ops.attn_bwd_varlen(qkv, out, do, kb, ks, lse, geom, hd, drop=drop, mask=mk)
+        g_hash2 = ops.attn_bwd_varlen(qkv, out, do, kb, ks, lse, geom, hd, drop=drop, mask=None)
+    finally:
+        ops.attn_set_path(prev)
+    assert torch.equal(g_mask2, g_hash2)
+    assert torch.equal(g_mask2[:, d:], g_mask[:, d:])
     out0, _, _ = ops.attn_fwd_varlen(qkv, kb, ks, geom, hd)
     assert bool(torch.isfinite(out.float()).all())
     # dropped and undropped outputs differ, but agree in expectation: mean absolute difference well below the signal
