@@ -17,6 +17,7 @@
 // probabilities are already the B operand of the P.V MFMA (O^T = V^T.P^T) with the key order
 // permuted identically on the V^T side (LDS image [hd][key], 8-byte fragment reads).  K / V^T / Q^T / dO^T
 // tiles are staged through padded LDS images; everything is fp32 except MFMA operands.
+#include <cstdlib>
 #include "neko_kernels.h"
 
 extern int neko_attn_path_mode();
@@ -775,7 +776,11 @@ int bwd_launch(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const f
 // schedule selection: 0 = automatic (head-resident kernels of attention_res.hip when they apply, their backward in one pass), 2 = the same
 // with the two-kernel backward (bit-reproducible: no LDS float atomics), 1 = always the
 // streaming kernels of this file.  A tuning / test knob, not part of the numerics: both schedules compute the same sums.
-static int g_attn_path = 0;
+static int g_attn_path = [] {              // NEKO_ATTN_PATH=0/1/2 sets the initial mode (A/B runs of whole steps)
+  const char* e = getenv("NEKO_ATTN_PATH");
+  const int v = e ? atoi(e) : 0;
+  return v >= 0 && v <= 2 ? v : 0;
+}();
 int neko_attn_path_mode() { return g_attn_path; }
 int neko_attn_set_path_impl(int mode) {
   const int prev = g_attn_path;

@@ -484,7 +484,13 @@ def patch_resblock_fwd(images, w1, b1, gw, gb, w2, b2, mid, groups, want_x=True)
     if H % 16 or W % 16:
         raise AssertionError("Image dimensions must be divisible by patch size")
     P = n * (H // 16) * (W // 16)
-    y16 = torch.empty(P, 768, dtype=BF16, device=images.device)
+    # the patch rows are the CONTRACTION of the projection's weight gradient: storage padded with zero rows to a multiple of 128
+    # keeps that product on the LDS-DMA GEMMs (a patch count such as 12289 sent it to the register-staged fallback: 237 us)
+    Ppad = (P + 127) // 128 * 128
+    y16_all = torch.empty(Ppad, 768, dtype=BF16, device=images.device)
+    if Ppad > P:
+        y16_all[P:].zero_()
+    y16 = y16_all[:P]
     xp = torch.empty(P, 768, dtype=torch.float32, device=images.device) if want_x else None
     _lib.call("neko_patch_resblock_fwd", _p(images), int(images.dtype == torch.uint8), n, H, W, _p(w1), _p(b1),
               _p(gw), _p(gb), _p(w2), _p(b2), mid, groups, _p(y16), _p(xp), _stream())

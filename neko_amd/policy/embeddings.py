@@ -98,12 +98,18 @@ class _ImageEmbedFn(torch.autograd.Function):
         if mod.use_pos_encoding:
             ops.patch_pos_add_bwd(g, ctx.hpos, ctx.wpos, f.gview(pre + "patch_pos_encoding.height_pos_embedding.weight"),
                                   f.gview(pre + "patch_pos_encoding.width_pos_embedding.weight"))
-        g16 = torch.empty(P, d, dtype=torch.bfloat16, device=g.device)
+        # rows P .. Ppad of both operands of the weight gradient are zero (ops.patch_resblock_fwd pads y16's storage the same way)
+        y16_all = ctx.y16._base if ctx.y16._base is not None else ctx.y16      # the zero-padded storage y16 is a row prefix of
+        Ppad = y16_all.shape[0]
+        g16_all = torch.empty(Ppad, d, dtype=torch.bfloat16, device=g.device)
+        if Ppad > P:
+            g16_all[P:].zero_()
+        g16 = g16_all[:P]
         ops.cast_f32_bf16(g, g16)
         ops.colsum_bf16(g16, P, d, f.gview(pre + "post_embedding_projection.bias"))
         # dW[d,768] += g^T @ y ;  dy[P,768] = g @ W
-        sk, kps = ops.pick_splitk(d, 768, P)
-        ops.gemm(g16, ctx.y16, d, 768, P, a_kstrided=True, b_kstrided=True, lda=d, ldb=768,
+        sk, kps = ops.pick_splitk(d, 768, Ppad)
+        ops.gemm(g16_all, y16_all, d, 768, Ppad, a_kstrided=True, b_kstrided=True, lda=d, ldb=768,
                  out_f32=f.gview(pre + "post_embedding_projection.weight"), ldcf=768, accumulate=True,   # also with split-K: one call per image-shape group
                  splitk=sk, k_per_split=kps)
         dy = torch.empty(P, 768, dtype=torch.float32, device=g.device)

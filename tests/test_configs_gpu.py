@@ -177,15 +177,20 @@ def test_metric_shape_gradients_add_up():
         torch.cuda.synchronize()
         return f.grad.clone()
 
-    from neko_amd import engine
+    from neko_amd import engine, ops
     g1 = grads(1)
     g2 = grads(2)
+    # the fork / join comparison needs kernels whose sums do not depend on timing: the two-kernel attention backward (the one-pass
+    # form adds dQ up in the order its waves arrive, see attention_res.hip)
+    prev_path = ops.attn_set_path(2)
     was = engine.SideStream.enabled
-    engine.SideStream.enabled = False                   # everything on one stream: the reference for the fork / join ordering
     try:
+        g1s = grads(1)
+        engine.SideStream.enabled = False               # everything on one stream: the reference for the fork / join ordering
         g3 = grads(1)
     finally:
         engine.SideStream.enabled = was
+        ops.attn_set_path(prev_path)
     assert float(g1.abs().max()) > 0
     # compare range by range so that a small tensor cannot hide behind a large one
     for name, p in m.named_parameters():
@@ -194,11 +199,15 @@ def test_metric_shape_gradients_add_up():
         a = f.gview(name)
         off = a.data_ptr() - f.grad.data_ptr()
         i0, n = off // 4, a.numel()
-        r1, r2, r3 = g1[i0:i0 + n], g2[i0:i0 + n], g3[i0:i0 + n]
+        r1, r2, r1s, r3 = g1[i0:i0 + n], g2[i0:i0 + n], g1s[i0:i0 + n], g3[i0:i0 + n]
         den = float(r1.abs().max())
         if den == 0:
             continue
-        assert float((r1 - r2).abs().max()) / den < 2e-3, (name, "two half passes")
+        # (5e-3, not the 2e-3 of rounds 1-3: the one-pass attention backward adds dQ up in the order its waves arrive, so two runs differ
+        # by bf16 rounding flips of dQ elements -- 2^-9 each -- which the sums behind the small embedding tensors collect: measured
+        # 2.5e-3 on separator_token, < 1e-3 on every weight matrix)
+        assert float((r1 - r2).abs().max()) / den < 5e-3, (name, "two half passes")
         # same kernels, same order of every fixed-order reduction; only the atomically scattered embedding rows may differ
         # in their last bits
-        assert float((r1 - r3).abs().max()) / den < 1e-5, (name, "side stream vs one stream")
+        assert float((r1s - r3).abs().max()) / den < 1e-5, (name, "side stream vs one stream")
+        assert float((r1 - r1s).abs().max()) / den < 2e-3, (name, "one-pass vs two-kernel attention backward")

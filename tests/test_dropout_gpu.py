@@ -94,11 +94,27 @@ def test_gemm_epilogue_and_ln_bwd_masks():
     assert torch.equal(dx16.cpu(), ref16)
 
 
-@pytest.mark.parametrize("path", ["auto", "streaming"])
+def same_backward(a, b, d, what=""):
+    """Two attention backward results that must come from the same keep decisions.  The two-kernel head-resident backward and the
+    streaming kernels are bit-reproducible; the one-pass kernel (the default for hd = 32) forms dK / dV in a fixed order (bit-equal)
+    and adds dQ up block by block in the order its waves arrive: equal to fp32 rounding before the bf16 store."""
+    from neko_amd import ops
+    mode = ops.attn_set_path(-1)                    # -1 is not a mode: the call only reports the current one
+    if mode != 0 or a.shape[1] != 3 * d:
+        assert torch.equal(a, b), (what, float((a.float() - b.float()).abs().max()))
+        return
+    assert torch.equal(a[:, d:], b[:, d:]), (what, "dK / dV", float((a[:, d:].float() - b[:, d:].float()).abs().max()))
+    dq_a, dq_b = a[:, :d].float(), b[:, :d].float()
+    assert float((dq_a - dq_b).abs().max()) <= 2 ** -7 * float(dq_b.abs().max()), (what, "dQ")
+
+
+@pytest.mark.parametrize("path", ["auto", "split", "streaming"])
 @pytest.mark.parametrize("B,T,H,hd", [(2, 96, 2, 32), (1, 200, 2, 64), (2, 301, 3, 32), (1, 520, 2, 128), (2, 1024, 1, 128), (1, 777, 2, 64)])
 def test_attention_dropout_fwd_bwd(B, T, H, hd, path):
     from neko_amd import ops
-    prev = ops.attn_set_path(1 if path == "streaming" else 0)
+    if path == "split" and hd != 32:
+        pytest.skip("the split / one-pass choice only exists for the head-resident kernels (hd = 32)")
+    prev = ops.attn_set_path({"auto": 0, "split": 2, "streaming": 1}[path])
     try:
         _attention_dropout_case(ops, B, T, H, hd)
     finally:
@@ -129,18 +145,27 @@ def _attention_dropout_case(ops, B, T, H, hd):
     assert float((dqkv.view(B, T, 3 * d).float().cpu() - leaf.grad).abs().max()) < 2e-2 * gs
     if kept is not None:        # head-resident schedule: the backward reuses the forward's stored keep masks -- same bits
         dqkv2 = ops.attn_bwd(qd, out, dod, kb, ks, lse, B, T, H, hd, drop=drop, mask=kept)
-        assert torch.equal(dqkv2, dqkv)
+        same_backward(dqkv2, dqkv, d, "stored masks vs re-hashed")
     else:
         assert hd != 32 or ops.attn_set_path(-1) == 1
 
 
+@pytest.mark.parametrize("path", [0, 2], ids=["one-pass", "two-kernel"])
 @pytest.mark.parametrize("B,T,H,pad", [(2, 1024, 3, 0), (3, 1000, 2, 77), (2, 33, 2, 5), (1, 512, 4, 0)])
-def test_attention_backward_with_stored_keep_masks_is_bit_identical(B, T, H, pad):
+def test_attention_backward_with_stored_keep_masks_is_bit_identical(B, T, H, pad, path):
     """The forward's compares (hash byte >= threshold) are stored as 64-bit lane masks by scalar stores and applied by
     dQ (scalar loads, one v_cndmask per element) and dK/dV (one dword per key, bit tests): the gradients must be the
     very bits the re-hashing kernels produce, at the metric length, with left padding (masked query rows that see
     every key) and with a ragged last block; a second forward into the same buffer must leave no stale decision."""
     from neko_amd import ops
+    prev_path = ops.attn_set_path(path)
+    try:
+        _stored_masks_case(ops, B, T, H, pad)
+    finally:
+        ops.attn_set_path(prev_path)
+
+
+def _stored_masks_case(ops, B, T, H, pad):
     g = torch.Generator().manual_seed(T + pad)
     hd, d = 32, H * 32
     qkv = (torch.randn(B * T, 3 * d, generator=g) * 0.7).to(torch.bfloat16).to(DEV)
@@ -163,7 +188,7 @@ def test_attention_backward_with_stored_keep_masks_is_bit_identical(B, T, H, pad
         assert kept is not None and torch.equal(out, out_ref) and torch.equal(lse, lse_ref)
         ref = ops.attn_bwd(qkv, out, do, kb, ks, lse, B, T, H, hd, drop=drop)
         got = ops.attn_bwd(qkv, out, do, kb, ks, lse, B, T, H, hd, drop=drop, mask=kept)
-        assert torch.equal(got, ref), float((got.float() - ref.float()).abs().max())
+        same_backward(got, ref, d, "stored masks vs re-hashed")
 
 
 def test_policy_with_dropout_matches_oracle_with_same_masks():
@@ -279,9 +304,15 @@ def test_backward_does_not_depend_on_mask_words_the_forward_never_wrote():
         out, lse, mk = ops.attn_fwd(qkv, kb, ks, B, T, H, hd, drop=drop, want_mask=True, mask_buf=buf)
         res.append((out.clone(), ops.attn_bwd(qkv, out, do, kb, ks, lse, B, T, H, hd, drop=drop, mask=mk).clone()))
     assert torch.equal(res[0][0], res[1][0])
-    assert torch.equal(res[0][1], res[1][1])
+    same_backward(res[0][1], res[1][1], d, "zero-filled vs poisoned mask buffer")
     ref = ops.attn_bwd(qkv, res[0][0], do, kb, ks, lse, B, T, H, hd, drop=drop, mask=None)       # re-hashing kernels
-    assert torch.equal(ref, res[0][1])
+    same_backward(ref, res[0][1], d, "re-hashed vs stored")
+    prev_path = ops.attn_set_path(2)          # and bit for bit on the two-kernel backward
+    try:
+        r2 = [ops.attn_bwd(qkv, res[i][0], do, kb, ks, lse, B, T, H, hd, drop=drop, mask=mk if i == 0 else None) for i in range(2)]
+    finally:
+        ops.attn_set_path(prev_path)
+    assert torch.equal(r2[0], r2[1])
 
 
 def mask_attn_varlen(lengths, H, drop):

@@ -24,22 +24,30 @@ def main():
     ap.add_argument("--drop", type=float, default=0.0, help="attention dropout probability")
     ap.add_argument("--path", type=int, default=0, help="0 auto (head-resident when applicable), 1 streaming")
     ap.add_argument("--no-mask", action="store_true", help="backward re-hashes the dropout decisions instead of reusing the forward's")
+    ap.add_argument("--rotate", type=int, default=1, help="number of independent input sets cycled through (>= 4 at B = 64 defeats the 256 MB "
+                    "Infinity Cache: the kernels then see HBM-cold operands as they do inside a training step)")
     a = ap.parse_args()
     ops.attn_set_path(a.path)
     B, T, H, hd = a.B, a.T, a.H, a.hd
     d = H * hd
     dev = "cuda"
-    qkv = (torch.randn(B * T, 3 * d, device=dev)).to(torch.bfloat16)
-    do = torch.randn(B * T, d, device=dev).to(torch.bfloat16)
     mask = torch.ones(B, T, device=dev)
     if a.pad:
         mask[:, :a.pad] = 0
     kb, ks = ops.mask_bias(mask)
     drop = ops.Drop(a.drop, 0x1234567) if a.drop > 0 else None
-    out, lse, mask = ops.attn_fwd(qkv, kb, ks, B, T, H, hd, drop=drop, want_mask=True)
-    if a.no_mask:
-        mask = None
+    sets = []
+    for _ in range(max(1, a.rotate)):
+        qkv = (torch.randn(B * T, 3 * d, device=dev)).to(torch.bfloat16)
+        do = torch.randn(B * T, d, device=dev).to(torch.bfloat16)
+        out, lse, mk = ops.attn_fwd(qkv, kb, ks, B, T, H, hd, drop=drop, want_mask=True)
+        sets.append((qkv, do, out, lse, None if a.no_mask else mk))
     fl = 4.0 * T * T / 2 * hd * H * B
+    it = [0]
+
+    def nxt():
+        it[0] += 1
+        return sets[it[0] % len(sets)]
 
     def timeit(fn, name, flops):
         for _ in range(3):
@@ -54,9 +62,12 @@ def main():
         print(f"{name:10s} {us:9.1f} us  {flops / us / 1e6:7.1f} TFLOP/s (useful, causal)")
 
     if "bwd" not in a.only:
-        timeit(lambda: ops.attn_fwd(qkv, kb, ks, B, T, H, hd, drop=drop, want_mask=not a.no_mask), "attn fwd", fl)
+        timeit(lambda: ops.attn_fwd(nxt()[0], kb, ks, B, T, H, hd, drop=drop, want_mask=not a.no_mask), "attn fwd", fl)
     if "fwd" not in a.only:
-        timeit(lambda: ops.attn_bwd(qkv, out, do, kb, ks, lse, B, T, H, hd, drop=drop, mask=mask), "attn bwd", 2.5 * fl)
+        def bwd():
+            q, g, o, l, m = nxt()
+            ops.attn_bwd(q, o, g, kb, ks, l, B, T, H, hd, drop=drop, mask=m)
+        timeit(bwd, "attn bwd", 2.5 * fl)
 
 
 if __name__ == "__main__":
