@@ -608,8 +608,7 @@ __global__ __launch_bounds__(768) void attn_dq_res_kernel(const bf16_t* __restri
 // =====================================================================================================
 template <bool DROP, bool MASK>
 __global__ __launch_bounds__(NEKO_DKV_WAVES * 64) void attn_dkv_res_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
-                                                            const float* __restrict__ kbias, const int* __restrict__ kstart,
-                                                            const float* __restrict__ lse,
+                                                            const float* __restrict__ kbias, const float* __restrict__ lse,
                                                             const float* __restrict__ Din, bf16_t* __restrict__ dqkv, int B,
                                                             int T_uniform, int H, float scale, uint32_t drop_thr,
                                                             uint32_t drop_key, float drop_scale,
@@ -705,7 +704,6 @@ __global__ __launch_bounds__(NEKO_DKV_WAVES * 64) void attn_dkv_res_kernel(const
 
   const float scale2 = scale * LOG2E;
   const uint32_t T4 = sg.T4;
-  const int kb_first = kstart ? (kstart[b] >> 5) : 0;
   NEKO_ATRACE(1, __builtin_amdgcn_s_memrealtime());
   unsigned long long ntiles_traced = 0;
 #pragma unroll 1
@@ -717,8 +715,7 @@ __global__ __launch_bounds__(NEKO_DKV_WAVES * 64) void attn_dkv_res_kernel(const
     bf16x8_v kf[2], vf[2];
     row_frags(qbase + d + (long)key * ld, kvalid, lane, kf);
     row_frags(qbase + 2 * d + (long)key * ld, kvalid, lane, vf);
-    const bool keys_valid = kw0 + 31 < T;                       // every key of the block exists
-    const bool keys_biased = (padmask >> kbw) & 1;              // some key of the block is padded: its bias joins the exponent
+    const bool keys_plain = (kw0 + 31 < T) && !((padmask >> kbw) & 1);
 
     f32x16 dk, dv;
 #pragma unroll
@@ -728,12 +725,9 @@ __global__ __launch_bounds__(NEKO_DKV_WAVES * 64) void attn_dkv_res_kernel(const
     // query blocks this key block meets: the masked-and-live ones below the diagonal (qactive), then every block from the
     // diagonal on.  next_qb() is wave-uniform scalar work; the dropout mask dword of the NEXT visited block (this lane's
     // key, 32 query bits) is requested one sub-tile ahead.
-    // a key block that lies entirely in the left padding (keys < kstart) has P == 0 for every unmasked query row (the dQ
-    // kernel starts its key loop behind such blocks for the same reason): only masked-and-live query blocks visit it
-    const bool kpad_all = kbw < kb_first;
     auto next_qb = [&](int from) {
       int nq = from;
-      while (nq < nblk && (nq < kbw || kpad_all) && !((qactive >> nq) & 1)) ++nq;
+      while (nq < kbw && !((qactive >> nq) & 1)) ++nq;
       return nq;
     };
     // keep words of the forward pass for this lane's key: mask[(head, query block, this key block)][mask_slot_of_key], one
@@ -766,19 +760,14 @@ __global__ __launch_bounds__(NEKO_DKV_WAVES * 64) void attn_dkv_res_kernel(const
       const float* lq = ldsLse + q0 + 4 * (lane >> 5);
       const float* dq_ = ldsD + q0 + 4 * (lane >> 5);
       // wave-uniform fast path: every query of the block sees every key of this wave, no key is padded or invalid
-      // (a padded key needs no other treatment than its additive bias -- the reference ADDS the padding mask, trajectory_gpt2.py:
-      // 663-679 -- so such key blocks stay on this path: before round 4 they took the per-element path for every query block,
-      // which made key block 0 of every left-padded sequence ~1.5x as expensive as the others)
-      const bool interior = (qb > kbw) && (q0 + 31 < T) && keys_valid;
+      const bool interior = (qb > kbw) && (q0 + 31 < T) && keys_plain;
       if (interior && (NEKO_ATTN_ABL & 1)) {
         // ablation: no elementwise work at all
       } else if (interior) {
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
           const int c = (r & 3) + 8 * (r >> 2);          // r even: c + 1 is the column of r + 1
-          f32x2_v nlse_q = pk2(lq[c], lq[c + 1]);
-          const f32x2_v d_q = pk2(dq_[c], dq_[c + 1]);
-          if (keys_biased) nlse_q += (f32x2_v)(my_kb);            // wave-uniform branch
+          const f32x2_v nlse_q = pk2(lq[c], lq[c + 1]), d_q = pk2(dq_[c], dq_[c + 1]);
           const f32x2_v pv = exp2_fast2(__builtin_elementwise_fma(pk2(st[r], st[r + 1]), (f32x2_v)(scale2), nlse_q));
           f32x2_v ds;
           if (DROP) {
@@ -1073,7 +1062,11 @@ __global__ __launch_bounds__(FUSED_W * 64) void attn_bwd_fused_res_kernel(
         }
         const float* lq = ldsLse + ql0 + 4 * (lane >> 5);
         const float* dq_ = ldsD + ql0 + 4 * (lane >> 5);
-        const bool interior = (qb > kbw) && (q0 + 31 < T) && keys_valid;       // padded keys: additive bias, see attn_dkv_res_kernel
+        // a padded key needs no other treatment than its additive bias (the reference ADDS the padding mask, trajectory_gpt2.py:
+        // 663-679), so key blocks that hold padded keys stay on the fast path here; in attn_dkv_res_kernel they take the per-element
+        // path for every query block, which makes key block 0 of every left-padded sequence ~1.5x as expensive as the others (and
+        // with the static key-block ownership of this kernel that wave would hold up the whole phase)
+        const bool interior = (qb > kbw) && (q0 + 31 < T) && keys_valid;
         if (interior) {
 #pragma unroll
           for (int r = 0; r < 16; r += 2) {
@@ -1313,7 +1306,7 @@ int neko_attn_bwd_res_impl(const bf16_t* qkv, const bf16_t* out, const bf16_t* d
     hipLaunchKernelGGL((attn_dq_res_kernel<DROPV, MASKV>), dim3(B * H), dim3(64 * nw), lds_q, s, qkv, dout, kbias, kstart, lse,  \
                        out, D, dqkv, B, T, H, scale, (uint32_t)(THR), drop_key, drop_scale, MP, seq_off, mask_off, T4);          \
     NEKO_CHECK_LAUNCH();                                                                                                          \
-    hipLaunchKernelGGL((attn_dkv_res_kernel<DROPV, MASKV>), dim3(B * H), dim3(64 * nw_kv), lds_kv, s, qkv, dout, kbias, kstart, lse, D, \
+    hipLaunchKernelGGL((attn_dkv_res_kernel<DROPV, MASKV>), dim3(B * H), dim3(64 * nw_kv), lds_kv, s, qkv, dout, kbias, lse, D, \
                        dqkv, B, T, H, scale, (uint32_t)(THR), drop_key, drop_scale, MP, seq_off, mask_off, T4);                  \
   } while (0)
   if (drop_thr && dmask) NEKO_BWD_RES(true, true, drop_thr, dmask);

@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--drop", type=float, default=0.0, help="attention dropout probability")
     ap.add_argument("--path", type=int, default=0, help="0 auto (head-resident when applicable), 1 streaming")
     ap.add_argument("--no-mask", action="store_true", help="backward re-hashes the dropout decisions instead of reusing the forward's")
+    ap.add_argument("--zero-pad-grad", action="store_true", help="dO = 0 on the padded rows (training: no loss reaches a padded position)")
+    ap.add_argument("--mix-pad", action="store_true", help="left padding 0 / 16 / 36 on a third of the sequences each (the m-mix batch)")
     ap.add_argument("--rotate", type=int, default=1, help="number of independent input sets cycled through (>= 4 at B = 64 defeats the 256 MB "
                     "Infinity Cache: the kernels then see HBM-cold operands as they do inside a training step)")
     a = ap.parse_args()
@@ -34,12 +36,17 @@ def main():
     mask = torch.ones(B, T, device=dev)
     if a.pad:
         mask[:, :a.pad] = 0
+    if a.mix_pad:
+        for b in range(B):
+            mask[b, :(0, 16, 36)[b % 3]] = 0
     kb, ks = ops.mask_bias(mask)
     drop = ops.Drop(a.drop, 0x1234567) if a.drop > 0 else None
     sets = []
     for _ in range(max(1, a.rotate)):
         qkv = (torch.randn(B * T, 3 * d, device=dev)).to(torch.bfloat16)
         do = torch.randn(B * T, d, device=dev).to(torch.bfloat16)
+        if a.zero_pad_grad:
+            do = (do.view(B, T, d) * mask[:, :, None].to(torch.bfloat16)).view(B * T, d).contiguous()
         out, lse, mk = ops.attn_fwd(qkv, kb, ks, B, T, H, hd, drop=drop, want_mask=True)
         sets.append((qkv, do, out, lse, None if a.no_mask else mk))
     fl = 4.0 * T * T / 2 * hd * H * B
