@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """The dominant kernel of bench.py's `roofline` object, alone: the LM-head logits GEMM (ROWS x 768 @ 768 x 52305; ROWS = argv[2],
-default 22720 = the loss rows of the m-mix bench batch, one launch per step since round 3; 4096 until then),
+default 22784 = the loss rows of the m-mix bench batch padded to whole 256-row tiles, one launch per step since round 3),
 bf16 out into a Vpad-strided buffer, the call engine.lm_head_loss makes), plus a calibration kernel with a known
 byte count (neko_cast_f32_bf16 over 256 Mi elements: 1 GiB read, 0.5 GiB written).  Run under
 `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes, tools/pmc_lmhead.sh)."""
@@ -12,8 +12,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from neko_amd import ops  # noqa: E402
 
-D, V, VP = 768, 52305, 52352
-ROWS = int(sys.argv[2]) if len(sys.argv) > 2 else 22720
+D, V, VP = 768, 52305, 52480
+ROWS = int(sys.argv[2]) if len(sys.argv) > 2 else 22784
 dev = "cuda"
 a = torch.randn(ROWS, D, device=dev).to(torch.bfloat16)
 w = (torch.randn(VP, D, device=dev) * 0.02).to(torch.bfloat16)
