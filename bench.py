@@ -130,9 +130,11 @@ def time_dominant_kernel(model, rows: int, iters: int = 10):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
-    flops = 2.0 * rows * D * hp.V          # useful columns only (the call computes Vpad = V + 47 of them)
-    return {"kernel": "gemm_glds_kernel<A k-contig, B k-contig> (LM head logits)", "shape": [rows, hp.V, D],
-            "ms": ms, "tflops": flops / ms / 1e9}
+    flops = 2.0 * rows * D * hp.V          # useful columns only (the call computes Vpad = V + 175 of them)
+    # which main loop neko_gemm_bf16 takes for this call (gemm_a16.hip's per-shape rule): every tile interior, >= 512 tiles
+    a16 = rows % 256 == 0 and hp.Vpad % 256 == 0 and (rows // 256) * (hp.Vpad // 256) >= 512 and os.environ.get("NEKO_GEMM_A16", "-1") != "0"
+    return {"kernel": ("gemm_a16_kernel" if a16 else "gemm_glds_kernel") + "<A k-contig, B k-contig> (LM head logits)",
+            "shape": [rows, hp.V, D], "ms": ms, "tflops": flops / ms / 1e9}
 
 
 def _time_events(fn, iters: int = 10, warm: int = 2) -> float:
@@ -405,7 +407,9 @@ def main():
         lm_frac = (lp.n_loss / float(B * Tlen)) if (lp is not None and lp.n_loss > 0 and model.lm_head_selected_rows) else 1.0
         fpt = 3 * flops_per_token_fwd(d=D, layers=L, t=Tlen, lm_rows_frac=lm_frac)
         # the launch the step itself makes: every loss row of the batch in one logits GEMM, up to lm_head_chunk_rows
-        n_rows = (max(64, (lp.n_loss + 63) // 64 * 64) if (lp is not None and lp.n_loss > 0 and model.lm_head_selected_rows) else B * Tlen)
+        # (same padding rule as engine.lm_head_loss_selected: whole 256-row tiles once the batch is large)
+        pad_rows = lambda n: max(64, (n + 63) // 64 * 64) if n < 2048 else (n + 255) // 256 * 256
+        n_rows = (pad_rows(lp.n_loss) if (lp is not None and lp.n_loss > 0 and model.lm_head_selected_rows) else B * Tlen)
         dom = time_dominant_kernel(model, min(model.lm_head_chunk_rows, n_rows))
         # HBM bytes per launch of that kernel: PMC counters cannot be collected from inside the timed process, so the
         # number is the committed rocprofv3 --pmc measurement of the same call (tools/pmc_lmhead.sh), null if absent
@@ -438,6 +442,10 @@ def main():
                     break
         out = {
             "metric": METRIC, "value": value, "unit": "tokens/s",
+            # the driver's bench contract: `value` is the WHOLE-JOB aggregate over all N GPUs (it divides by N itself for the scaling
+            # curve); the metric's per-GPU figure is in `tokens_per_sec_per_gpu` / `value_per_gpu` (equal to `value` at N = 1)
+            "value_scope": "whole job: sum over all n_gpus ranks",
+            "value_per_gpu": value / world,
             "value_includes": "fwd + bwd + gradient all-reduce + clip + AdamW (whole job, all GPUs)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",

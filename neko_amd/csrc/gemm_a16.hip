@@ -181,11 +181,14 @@ int neko_gemm_a16_try(const GemmArgs& a, int a_kstrided, int b_kstrided, hipStre
     // per-shape choice (tools/gemm_bench.py at 32768 / 65536 rows, profiles/r04_gemm_a16_ab.txt): every long contraction; short ones
     // (K = 768) only with a plain bf16 store behind them and at least two rounds of tiles (forward qkv, dgrad attention out, LM-head
     // logits: +3..10 %) -- the GELU / residual epilogues are VALU- and store-bound and prefer the 8-wave kernel's two waves per SIMD
+    const long tiles = (long)(a.M / 256) * (a.N / 256) * (a.splitk > 1 ? a.splitk : 1);
     if (klen < 1536) {
       const unsigned f = fast_epi_mask(a, true, to_ws, to_ws || a.Cf != nullptr);
-      const long tiles = (long)(a.M / 256) * (a.N / 256);
       if (!(f == F_CB || f == (F_BIAS | F_CB)) || tiles < 512) return 1;
     }
+    // fewer 256 x 256 tiles than ~3/4 of the CUs (README batch sizes: 7680 rows x 768 columns = 90 tiles): gemm_glds.hip's smaller
+    // tiles fill the chip better than this loop's faster k-tiles pay back (c2: 6.03 -> 6.16 ms per step with 90-tile launches)
+    if (tiles < 192) return 1;
   }
   if (a_kstrided && b_kstrided) return launch_a16<false, false>(a, s);
   if (a_kstrided) return launch_a16<false, true>(a, s);
