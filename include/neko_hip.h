@@ -146,17 +146,19 @@ int neko_attn_set_path(int mode);
  * out / dout / dqkv / kbias are sequence b (seq_off: int32 [nseq + 1], device); kstart [nseq] is relative to its sequence.
  * lse and D are [rows * H] laid out [sequence][head][position] = seq_off[b] * H + h * T_b + q.  The keep masks of sequence b
  * start at mask_off[b] dwords (int64 [nseq], device): mask_off[b] = sum over b' < b of H * ceil(T_b' / 32)^2 * 32; the buffer holds
- * that sum over all sequences.  The dropout hash indexes (unique row id) * ceil(Tmax / 4) + key / 4.  Head-resident kernels only:
- * hd = 32 and Tmax <= 1024 (neko_attn_varlen_supported), otherwise NEKO_ERR_UNSUPPORTED (callers fall back to one launch per
- * length bucket).  Arithmetic, masks and dropout semantics are those of neko_attn_fwd / neko_attn_bwd.  (ABI v14) */
+ * that sum over all sequences.  The dropout hash indexes (unique row id) * ceil(Tmax / 4) + key / 4.  Served by the head-resident
+ * kernels (hd = 32, Tmax <= 1024) and, since ABI v16, by the DMA-ring kernels (hd = 64 / 128, Tmax <= 4096; these keep no stored
+ * masks: drop_mask and mask_off must be null); neko_attn_varlen_supported tells, otherwise NEKO_ERR_UNSUPPORTED (callers fall
+ * back to one launch per length bucket).  rows (ABI v16) = seq_off[nseq], the number of packed rows.  Arithmetic, masks and
+ * dropout semantics are those of neko_attn_fwd / neko_attn_bwd.  (ABI v14) */
 int neko_attn_varlen_supported(int Tmax, int hd);
 int neko_attn_fwd_varlen(const uint16_t* qkv, const float* kbias, const int* kstart, const int* seq_off, const long long* mask_off,
                          uint16_t* out, float* lse, int nseq, int Tmax, int H, int hd, int drop_thr, unsigned drop_key,
                          float drop_scale, uint32_t* drop_mask, void* stream);
 int neko_attn_bwd_varlen(const uint16_t* qkv, const uint16_t* out, const uint16_t* dout, const float* kbias, const int* kstart,
                          const int* seq_off, const long long* mask_off, const float* lse, float* D, uint16_t* dqkv, int nseq,
-                         int Tmax, int H, int hd, int drop_thr, unsigned drop_key, float drop_scale, const uint32_t* drop_mask,
-                         void* stream);
+                         long rows, int Tmax, int H, int hd, int drop_thr, unsigned drop_key, float drop_scale,
+                         const uint32_t* drop_mask, void* stream);
 int neko_mask_bias(const float* mask, float* kbias, int* kstart, int B, int T, void* stream);
 long neko_attn_mask_dwords(int B, int T, int H, int hd);
 int neko_attn_fwd(const uint16_t* qkv, const float* kbias, const int* kstart, uint16_t* out, float* lse, int B,

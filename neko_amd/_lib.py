@@ -33,7 +33,7 @@ SIGNATURES = {
     "neko_gemm_set_mainloop": [_i],
     "neko_attn_varlen_supported": [_i, _i],
     "neko_attn_fwd_varlen": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, C.c_uint, _f, _vp, _vp],
-    "neko_attn_bwd_varlen": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, C.c_uint, _f, _vp, _vp],
+    "neko_attn_bwd_varlen": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _l, _i, _i, _i, _i, C.c_uint, _f, _vp, _vp],
     "neko_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, C.c_uint, _f, _vp, _vp],
     "neko_gemv_bf16": [_vp, _l, _vp, _l, _i, _i, _i, _i, _vp, _vp, _l, _i, _vp, _l, _vp, _l, _vp],
     "neko_attn_decode": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],

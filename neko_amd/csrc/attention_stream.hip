@@ -175,6 +175,31 @@ __device__ __forceinline__ void xcd_remap(int P, int nbh, int& bh, int& pair) {
   }
 }
 
+// Where a (sequence, head) lives (same conventions as attention_res.hip's SeqGeom).  Uniform batches: sequence b = rows [b T, (b+1) T);
+// packed batches (neko_attn_*_varlen, ABI v16 for hd = 64 / 128): rows seq_off[b] .. seq_off[b+1]-1, every sequence with its own length,
+// ONE launch sized for the longest.  lse / D are [sequence][head][position] = row0 * H + h * T_b + q; the dropout hash walks that index
+// with the row stride of the longest sequence.  For a uniform batch every value below is what the kernels computed before (bit-identical).
+struct SeqG {
+  int b, T;          // sequence index, its length
+  long row0;         // first row of the sequence in the [rows, ...] matrices
+  long hrow;         // index of (b, h, position 0) in lse / D, and unique row id base of the dropout hash
+  uint32_t T4;       // dropout hash words per row
+};
+__device__ __forceinline__ SeqG seq_geom(int b, int h, int H, int T_launch, const int* __restrict__ seq_off) {
+  SeqG g;
+  g.b = b;
+  if (seq_off) {
+    g.row0 = seq_off[b];
+    g.T = seq_off[b + 1] - (int)g.row0;
+  } else {
+    g.row0 = (long)b * T_launch;
+    g.T = T_launch;
+  }
+  g.hrow = g.row0 * H + (long)h * g.T;
+  g.T4 = (uint32_t)((T_launch + 3) >> 2);
+  return g;
+}
+
 // key-bias image of the sequence + one "holds a padded key" flag per 64-key tile (both read by every wave all along)
 template <int NW>
 __device__ __forceinline__ void stage_kbias(const float* __restrict__ kb, int T, float* ldsKb, int* ldsPad, int tid, int lane, int wave) {
@@ -195,14 +220,14 @@ template <int HD, bool DROP, int NW, int NST>
 __device__ __forceinline__ void fwd_tile(char* ring, const float* ldsKb, const int* ldsPad, const bf16_t* __restrict__ qkv,
                                          const int* __restrict__ kstart, bf16_t* __restrict__ out, float* __restrict__ lse,
                                          int T, int H, float scale, uint32_t drop_thr, uint32_t drop_key, float drop_scale,
-                                         const int tile, const int b, const int h) {
+                                         const int tile, const SeqG g, const int h) {
   using C = SC<HD>;
   constexpr int QB = 32 * NW, PPW = C::PIECES / NW;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int d = H * HD;
   const long ld = 3L * d;
   const unsigned ldb = (unsigned)(ld * 2);
-  const bf16_t* qbase = qkv + (long)b * T * ld + h * HD;
+  const bf16_t* qbase = qkv + g.row0 * ld + h * HD;
   const char* kbase = reinterpret_cast<const char*>(qbase + d);
   const char* vbase = reinterpret_cast<const char*>(qbase + 2 * d);
   const unsigned ring_lds = lds_addr(ring);
@@ -220,7 +245,7 @@ __device__ __forceinline__ void fwd_tile(char* ring, const float* ldsKb, const i
   const int qmax = min(q0 + QB - 1, T - 1);
   const int ntile = (T + KT - 1) / KT;
   const int kt_end = full ? ntile : qmax / KT + 1;
-  const int kt_beg = full ? 0 : (kstart ? kstart[b] / KT : 0);
+  const int kt_beg = full ? 0 : (kstart ? kstart[g.b] / KT : 0);
 
   // per-lane addressing, computed once and kept small (the loop lives at the 256-register limit of two waves per SIMD):
   //   K fragments (natural reads): ONE base, k-step ks is base ^ (ks << 5) -- the swizzle XORs the chunk index and 2 ks + h differs
@@ -354,7 +379,7 @@ __device__ __forceinline__ void fwd_tile(char* ring, const float* ldsKb, const i
         }
         l_run += ps.x + ps.y;
         if (DROP) {
-          const uint32_t g0 = ((uint32_t)(b * H + h) * (uint32_t)T + (uint32_t)q) * (uint32_t)((T + 3) >> 2) +
+          const uint32_t g0 = ((uint32_t)g.hrow + (uint32_t)q) * g.T4 +
                               (uint32_t)((k0 + t * 32 + 4 * (lane >> 5)) >> 2);
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
@@ -493,7 +518,7 @@ __device__ __forceinline__ void fwd_tile(char* ring, const float* ldsKb, const i
       l_run += ps.x + ps.y;
       }
       if (DROP) {   // attn_dropout on the probabilities (trajectory_gpt2.py:179): the normaliser stays undropped
-        const uint32_t g0 = ((uint32_t)(b * H + h) * (uint32_t)T + (uint32_t)q_s) * (uint32_t)((T + 3) >> 2) +
+        const uint32_t g0 = ((uint32_t)g.hrow + (uint32_t)q_s) * g.T4 +
                             (uint32_t)((k0 + t * 32 + 4 * (lane_s >> 5)) >> 2);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {          // registers 4j..4j+3 = keys +8j .. +8j+3: one word
@@ -524,7 +549,7 @@ __device__ __forceinline__ void fwd_tile(char* ring, const float* ldsKb, const i
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   if (qvalid) {
     const float inv = (DROP ? drop_scale : 1.0f) / l_tot;
-    bf16_t* orow = out + ((long)b * T + q) * d + h * HD;
+    bf16_t* orow = out + (g.row0 + q) * d + h * HD;
 #pragma unroll
     for (int i = 0; i < C::IB; ++i)
 #pragma unroll
@@ -534,33 +559,39 @@ __device__ __forceinline__ void fwd_tile(char* ring, const float* ldsKb, const i
         pk.y = pack_bf16x2(o[i][4 * g + 2] * inv, o[i][4 * g + 3] * inv);
         *reinterpret_cast<uint2*>(orow + i * 32 + 8 * g + 4 * (lane >> 5)) = pk;
       }
-    if (lane < 32) lse[((long)b * H + h) * T + q] = m_run * LN2 + __logf(l_tot);
+    if (lane < 32) lse[g.hrow + q] = m_run * LN2 + __logf(l_tot);
   }
 }
 
 template <int HD, bool DROP, int NW, int NST>
 __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_stream_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ kbias,
                                                                      const int* __restrict__ kstart, bf16_t* __restrict__ out,
-                                                                     float* __restrict__ lse, int B, int T, int H, float scale,
-                                                                     uint32_t drop_thr, uint32_t drop_key, float drop_scale) {
+                                                                     float* __restrict__ lse, int B, int T_launch, int H, float scale,
+                                                                     uint32_t drop_thr, uint32_t drop_key, float drop_scale,
+                                                                     const int* __restrict__ seq_off) {
   extern __shared__ __attribute__((aligned(1024))) char dyn_smem[];
-  char* ring = dyn_smem;                                                        // NST stages of [K tile | V tile]
-  float* ldsKb = reinterpret_cast<float*>(dyn_smem + NST * 2 * SC<HD>::TILE);   // [round_up(T, 64)]
-  int* ldsPad = reinterpret_cast<int*>(ldsKb + (T + KT - 1) / KT * KT);         // [ceil(T / 64)]
   if (DROP) drop_key += neko_drop_salt();
   const int tid = threadIdx.x;
-  // one workgroup = a heavy and a light causal tile (G-1-p and p): every workgroup walks the same number of key tiles
-  const int G = (T + 32 * NW - 1) / (32 * NW);
+  // one workgroup = a heavy and a light causal tile (G-1-p and p): every workgroup walks the same number of key tiles.  T_launch is
+  // the (longest) sequence length the grid and the LDS block were sized for; a packed sequence shorter than that owns fewer tiles
+  const int G = (T_launch + 32 * NW - 1) / (32 * NW);
   int bh, p;
   xcd_remap((G + 1) / 2, B * H, bh, p);
   const int b = bh / H, h = bh - b * H;
-  stage_kbias<NW>(kbias + (long)b * T, T, ldsKb, ldsPad, tid, tid & 63, tid >> 6);
-  __syncthreads();
+  const SeqG g = seq_geom(b, h, H, T_launch, seq_off);
+  const int T = g.T;
+  char* ring = dyn_smem;                                                        // NST stages of [K tile | V tile]
+  float* ldsKb = reinterpret_cast<float*>(dyn_smem + NST * 2 * SC<HD>::TILE);   // [round_up(T, 64)]
+  int* ldsPad = reinterpret_cast<int*>(ldsKb + (T + KT - 1) / KT * KT);         // [ceil(T / 64)]
   const int first = G - 1 - p, second = p;
-  fwd_tile<HD, DROP, NW, NST>(ring, ldsKb, ldsPad, qkv, kstart, out, lse, T, H, scale, drop_thr, drop_key, drop_scale, first, b, h);
-  if (second != first) {
+  const bool do_first = first * 32 * NW < T, do_second = second != first && second * 32 * NW < T;
+  if (!do_first && !do_second) return;
+  stage_kbias<NW>(kbias + g.row0, T, ldsKb, ldsPad, tid, tid & 63, tid >> 6);
+  __syncthreads();
+  if (do_first) fwd_tile<HD, DROP, NW, NST>(ring, ldsKb, ldsPad, qkv, kstart, out, lse, T, H, scale, drop_thr, drop_key, drop_scale, first, g, h);
+  if (do_second) {
     __syncthreads();
-    fwd_tile<HD, DROP, NW, NST>(ring, ldsKb, ldsPad, qkv, kstart, out, lse, T, H, scale, drop_thr, drop_key, drop_scale, second, b, h);
+    fwd_tile<HD, DROP, NW, NST>(ring, ldsKb, ldsPad, qkv, kstart, out, lse, T, H, scale, drop_thr, drop_key, drop_scale, second, g, h);
   }
 }
 
@@ -606,13 +637,13 @@ __device__ __forceinline__ void dq_tile(char* ring, const float* ldsKb, const in
                                         const bf16_t* __restrict__ dout, const int* __restrict__ kstart,
                                         const float* __restrict__ lse, const float* __restrict__ Dv, bf16_t* __restrict__ dqkv,
                                         int T, int H, float scale, uint32_t drop_thr, uint32_t drop_key, float drop_scale,
-                                        const int tile, const int b, const int h) {
+                                        const int tile, const SeqG g, const int h) {
   using C = SC<HD>;
   constexpr int QB = 32 * NW, PPW = C::PIECES / NW;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int d = H * HD;
   const long ld = 3L * d;
-  const bf16_t* qbase = qkv + (long)b * T * ld + h * HD;
+  const bf16_t* qbase = qkv + g.row0 * ld + h * HD;
   const unsigned ring_lds = lds_addr(ring);
   TileStream<HD, NW> srcK, srcV;
   srcK.init(qbase + d, ld, lane);
@@ -623,9 +654,9 @@ __device__ __forceinline__ void dq_tile(char* ring, const float* ldsKb, const in
   const bool qvalid = q < T;
   bf16x8_v qf[C::KS], dof[C::KS];
   row_frags<HD>(qbase + (long)q * ld, qvalid, lane, qf);
-  row_frags<HD>(dout + ((long)b * T + q) * d + h * HD, qvalid, lane, dof);
-  const float my_lse = (qvalid ? lse[((long)b * H + h) * T + q] : 0.f) * LOG2E;
-  const float my_D = qvalid ? Dv[((long)b * H + h) * T + q] : 0.f;
+  row_frags<HD>(dout + (g.row0 + q) * d + h * HD, qvalid, lane, dof);
+  const float my_lse = (qvalid ? lse[g.hrow + q] : 0.f) * LOG2E;
+  const float my_D = qvalid ? Dv[g.hrow + q] : 0.f;
   const float scale2 = scale * LOG2E;
 
   int full = 0;
@@ -634,7 +665,7 @@ __device__ __forceinline__ void dq_tile(char* ring, const float* ldsKb, const in
   const int qmax = min(q0 + QB - 1, T - 1);
   const int ntile = (T + KT - 1) / KT;
   const int kt_end = full ? ntile : qmax / KT + 1;
-  const int kt_beg = full ? 0 : (kstart ? kstart[b] / KT : 0);
+  const int kt_beg = full ? 0 : (kstart ? kstart[g.b] / KT : 0);
 
   const unsigned nat0 = ring_lds + nat_off<HD, 0>(0, lane);      // K (and, + TILE, V) natural fragment of k-step 0; k-step ks: ^ (ks << 5)
   unsigned ktr[C::IB], ktr_hi[C::IB];                            // K^T fragment of head-dim block i, key step 0: lo / hi read
@@ -704,7 +735,7 @@ __device__ __forceinline__ void dq_tile(char* ring, const float* ldsKb, const in
       for (int i = 0; i < C::IB; ++i) ktf[i] = lds_read_tr(tlo[i] + ((2 * t) * 16 * C::ROWB), thi[i] + ((2 * t) * 16 * C::ROWB));
       __builtin_amdgcn_sched_barrier(0);
       // dS^T = P^T o (keep * dP^T - D / s); zero where the score was REPLACED by the causal constant
-      const uint32_t g0 = ((uint32_t)(b * H + h) * (uint32_t)T + (uint32_t)q) * (uint32_t)((T + 3) >> 2) +
+      const uint32_t g0 = ((uint32_t)g.hrow + (uint32_t)q) * g.T4 +
                           (uint32_t)((k0 + t * 32 + 4 * (lane >> 5)) >> 2);
       const bool interior = (k0 + t * 32 + 31 <= qw0) && !has_pad && (k0 + KT <= T);
       if (interior) {
@@ -760,7 +791,7 @@ __device__ __forceinline__ void dq_tile(char* ring, const float* ldsKb, const in
   // dS was formed as P o (keep * dP - D / s): the dropout survivor scale s multiplies the result once, here
   const float qs = scale * (DROP ? drop_scale : 1.0f);
   if (qvalid) {
-    bf16_t* orow = dqkv + ((long)b * T + q) * ld + h * HD;
+    bf16_t* orow = dqkv + (g.row0 + q) * ld + h * HD;
 #pragma unroll
     for (int i = 0; i < C::IB; ++i)
 #pragma unroll
@@ -779,25 +810,30 @@ template <int HD, bool DROP, int NW, int NST>
 __global__ __launch_bounds__(64 * NW, (HD <= 64 || DROP) ? 2 : 1) void attn_dq_stream_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                                     const float* __restrict__ kbias, const int* __restrict__ kstart,
                                                                     const float* __restrict__ lse, const float* __restrict__ Dv,
-                                                                    bf16_t* __restrict__ dqkv, int B, int T, int H, float scale,
-                                                                    uint32_t drop_thr, uint32_t drop_key, float drop_scale) {
+                                                                    bf16_t* __restrict__ dqkv, int B, int T_launch, int H, float scale,
+                                                                    uint32_t drop_thr, uint32_t drop_key, float drop_scale,
+                                                                    const int* __restrict__ seq_off) {
   extern __shared__ __attribute__((aligned(1024))) char dyn_smem[];
-  char* ring = dyn_smem;
-  float* ldsKb = reinterpret_cast<float*>(dyn_smem + NST * 2 * SC<HD>::TILE);
-  int* ldsPad = reinterpret_cast<int*>(ldsKb + (T + KT - 1) / KT * KT);
   if (DROP) drop_key += neko_drop_salt();
   const int tid = threadIdx.x;
-  const int G = (T + 32 * NW - 1) / (32 * NW);
+  const int G = (T_launch + 32 * NW - 1) / (32 * NW);
   int bh, p;
   xcd_remap((G + 1) / 2, B * H, bh, p);
   const int b = bh / H, h = bh - b * H;
-  stage_kbias<NW>(kbias + (long)b * T, T, ldsKb, ldsPad, tid, tid & 63, tid >> 6);
-  __syncthreads();
+  const SeqG g = seq_geom(b, h, H, T_launch, seq_off);
+  const int T = g.T;
+  char* ring = dyn_smem;
+  float* ldsKb = reinterpret_cast<float*>(dyn_smem + NST * 2 * SC<HD>::TILE);
+  int* ldsPad = reinterpret_cast<int*>(ldsKb + (T + KT - 1) / KT * KT);
   const int first = G - 1 - p, second = p;
-  dq_tile<HD, DROP, NW, NST>(ring, ldsKb, ldsPad, qkv, dout, kstart, lse, Dv, dqkv, T, H, scale, drop_thr, drop_key, drop_scale, first, b, h);
-  if (second != first) {
+  const bool do_first = first * 32 * NW < T, do_second = second != first && second * 32 * NW < T;
+  if (!do_first && !do_second) return;
+  stage_kbias<NW>(kbias + g.row0, T, ldsKb, ldsPad, tid, tid & 63, tid >> 6);
+  __syncthreads();
+  if (do_first) dq_tile<HD, DROP, NW, NST>(ring, ldsKb, ldsPad, qkv, dout, kstart, lse, Dv, dqkv, T, H, scale, drop_thr, drop_key, drop_scale, first, g, h);
+  if (do_second) {
     __syncthreads();
-    dq_tile<HD, DROP, NW, NST>(ring, ldsKb, ldsPad, qkv, dout, kstart, lse, Dv, dqkv, T, H, scale, drop_thr, drop_key, drop_scale, second, b, h);
+    dq_tile<HD, DROP, NW, NST>(ring, ldsKb, ldsPad, qkv, dout, kstart, lse, Dv, dqkv, T, H, scale, drop_thr, drop_key, drop_scale, second, g, h);
   }
 }
 
@@ -806,17 +842,17 @@ template <int HD, bool DROP, int NW, int NST>
 __device__ __forceinline__ void dkv_tile(char* ring, const float* ldsKb, const int* ldsPad, const float* ldsLse, const float* ldsD,
                                          const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout, bf16_t* __restrict__ dqkv,
                                          int T, int H, float scale, uint32_t drop_thr, uint32_t drop_key, float drop_scale,
-                                         const int tile, const int b, const int h) {
+                                         const int tile, const SeqG g, const int h) {
   using C = SC<HD>;
   constexpr int KB = 32 * NW, PPW = C::PIECES / NW;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int d = H * HD;
   const long ld = 3L * d;
-  const bf16_t* qbase = qkv + (long)b * T * ld + h * HD;
+  const bf16_t* qbase = qkv + g.row0 * ld + h * HD;
   const unsigned ring_lds = lds_addr(ring);
   TileStream<HD, NW> srcQ, srcO;
   srcQ.init(qbase, ld, lane);
-  srcO.init(dout + (long)b * T * d + h * HD, d, lane);
+  srcO.init(dout + g.row0 * d + h * HD, d, lane);
 
   const int k0 = tile * KB, kw0 = k0 + wave * 32;
   const int key = kw0 + (lane & 31);
@@ -885,8 +921,8 @@ __device__ __forceinline__ void dkv_tile(char* ring, const float* ldsKb, const i
     uint32_t mine[4] = {0u, 0u, 0u, 0u};
     const int ksh = 8 * (lane & 3);
     if (DROP) {
-      const uint32_t T4 = (uint32_t)((T + 3) >> 2);
-      const uint32_t gq = ((uint32_t)(b * H + h) * (uint32_t)T + (uint32_t)(q0 + t * 32 + 4 * (lane >> 5) + (lane & 3))) * T4 +
+      const uint32_t T4 = g.T4;
+      const uint32_t gq = ((uint32_t)g.hrow + (uint32_t)(q0 + t * 32 + 4 * (lane >> 5) + (lane & 3))) * T4 +
                           (uint32_t)(key >> 2);
 #pragma unroll
       for (int j = 0; j < 4; ++j) mine[j] = drop_word(gq + (uint32_t)(8 * j) * T4, drop_key);
@@ -1067,8 +1103,8 @@ __device__ __forceinline__ void dkv_tile(char* ring, const float* ldsKb, const i
       uint32_t mine[4] = {0u, 0u, 0u, 0u};
       const int ksh = 8 * (lane & 3);
       if (DROP) {
-        const uint32_t T4 = (uint32_t)((T + 3) >> 2);
-        const uint32_t gq = ((uint32_t)(b * H + h) * (uint32_t)T + (uint32_t)(q0 + t * 32 + 4 * (lane >> 5) + (lane & 3))) * T4 +
+        const uint32_t T4 = g.T4;
+        const uint32_t gq = ((uint32_t)g.hrow + (uint32_t)(q0 + t * 32 + 4 * (lane >> 5) + (lane & 3))) * T4 +
                             (uint32_t)(key >> 2);
 #pragma unroll
         for (int j = 0; j < 4; ++j) mine[j] = drop_word(gq + (uint32_t)(8 * j) * T4, drop_key);    // row c = (lane&3) + 8j
@@ -1130,7 +1166,7 @@ __device__ __forceinline__ void dkv_tile(char* ring, const float* ldsKb, const i
   // P and dP were masked but not scaled in the loop (D holds D / s): the survivor scale s is applied once, here
   const float vsc = DROP ? drop_scale : 1.0f, ksc = scale * vsc;
   if (kvalid) {
-    bf16_t* krow = dqkv + ((long)b * T + key) * ld + d + h * HD;
+    bf16_t* krow = dqkv + (g.row0 + key) * ld + d + h * HD;
     bf16_t* vrow = krow + d;
 #pragma unroll
     for (int i = 0; i < C::IB; ++i)
@@ -1151,9 +1187,16 @@ template <int HD, bool DROP, int NW, int NST>
 __global__ __launch_bounds__(64 * NW, 1) void attn_dkv_stream_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                                      const float* __restrict__ kbias, const float* __restrict__ lse,
                                                                      const float* __restrict__ Dv, bf16_t* __restrict__ dqkv, int B,
-                                                                     int T, int H, float scale, uint32_t drop_thr, uint32_t drop_key,
-                                                                     float drop_scale) {
+                                                                     int T_launch, int H, float scale, uint32_t drop_thr, uint32_t drop_key,
+                                                                     float drop_scale, const int* __restrict__ seq_off) {
   extern __shared__ __attribute__((aligned(1024))) char dyn_smem[];
+  const int tid = threadIdx.x;
+  const int G = (T_launch + 32 * NW - 1) / (32 * NW);
+  int bh, p;
+  xcd_remap((G + 1) / 2, B * H, bh, p);
+  const int b = bh / H, h = bh - b * H;
+  const SeqG g = seq_geom(b, h, H, T_launch, seq_off);
+  const int T = g.T;
   const int Tp = (T + KT - 1) / KT * KT;
   char* ring = dyn_smem;                                                        // NST stages of [Q tile | dO tile]
   float* ldsKb = reinterpret_cast<float*>(dyn_smem + NST * 2 * SC<HD>::TILE);   // [Tp]
@@ -1161,22 +1204,19 @@ __global__ __launch_bounds__(64 * NW, 1) void attn_dkv_stream_kernel(const bf16_
   float* ldsD = ldsLse + Tp;                                                    // [Tp]  D / s
   int* ldsPad = reinterpret_cast<int*>(ldsD + Tp);                              // [Tp / 64]  bit t: 32-row half t holds a padded position
   if (DROP) drop_key += neko_drop_salt();
-  const int tid = threadIdx.x;
-  const int G = (T + 32 * NW - 1) / (32 * NW);
-  int bh, p;
-  xcd_remap((G + 1) / 2, B * H, bh, p);
-  const int b = bh / H, h = bh - b * H;
-  stage_kbias<NW>(kbias + (long)b * T, T, ldsKb, ldsPad, tid, tid & 63, tid >> 6);
+  const int first = p, second = G - 1 - p;
+  const bool do_first = first * 32 * NW < T, do_second = second != first && second * 32 * NW < T;
+  if (!do_first && !do_second) return;
+  stage_kbias<NW>(kbias + g.row0, T, ldsKb, ldsPad, tid, tid & 63, tid >> 6);
   for (int i = tid; i < Tp; i += 64 * NW) {
-    ldsLse[i] = i < T ? lse[((long)b * H + h) * T + i] * LOG2E : 0.f;
-    ldsD[i] = i < T ? Dv[((long)b * H + h) * T + i] : 0.f;
+    ldsLse[i] = i < T ? lse[g.hrow + i] * LOG2E : 0.f;
+    ldsD[i] = i < T ? Dv[g.hrow + i] : 0.f;
   }
   __syncthreads();
-  const int first = p, second = G - 1 - p;
-  dkv_tile<HD, DROP, NW, NST>(ring, ldsKb, ldsPad, ldsLse, ldsD, qkv, dout, dqkv, T, H, scale, drop_thr, drop_key, drop_scale, first, b, h);
-  if (second != first) {
+  if (do_first) dkv_tile<HD, DROP, NW, NST>(ring, ldsKb, ldsPad, ldsLse, ldsD, qkv, dout, dqkv, T, H, scale, drop_thr, drop_key, drop_scale, first, g, h);
+  if (do_second) {
     __syncthreads();
-    dkv_tile<HD, DROP, NW, NST>(ring, ldsKb, ldsPad, ldsLse, ldsD, qkv, dout, dqkv, T, H, scale, drop_thr, drop_key, drop_scale, second, b, h);
+    dkv_tile<HD, DROP, NW, NST>(ring, ldsKb, ldsPad, ldsLse, ldsD, qkv, dout, dqkv, T, H, scale, drop_thr, drop_key, drop_scale, second, g, h);
   }
 }
 
@@ -1196,7 +1236,7 @@ int set_lds_limit(K kernel, LdsLimitDone& done) {
 }
 template <int HD, int NW, int NST>
 int fwd_launch(const bf16_t* qkv, const float* kbias, const int* kstart, bf16_t* out, float* lse, int B, int T, int H,
-               int thr, unsigned key, float dscale, hipStream_t s) {
+               int thr, unsigned key, float dscale, hipStream_t s, const int* seq_off) {
   const float scale = 1.0f / sqrtf((float)HD);
   const int G = (T + 32 * NW - 1) / (32 * NW);
   dim3 grid((unsigned)((long)((G + 1) / 2) * H * B), 1, 1);      // (sequence, head, tile pair) decoded by xcd_remap
@@ -1208,10 +1248,10 @@ int fwd_launch(const bf16_t* qkv, const float* kbias, const int* kstart, bf16_t*
     return NEKO_ERR_LAUNCH;
   if (thr)
     hipLaunchKernelGGL((attn_fwd_stream_kernel<HD, true, NW, NST>), grid, dim3(64 * NW), lds, s, qkv, kbias, kstart, out, lse,
-                       B, T, H, scale, (uint32_t)thr, key, dscale);
+                       B, T, H, scale, (uint32_t)thr, key, dscale, seq_off);
   else
     hipLaunchKernelGGL((attn_fwd_stream_kernel<HD, false, NW, NST>), grid, dim3(64 * NW), lds, s, qkv, kbias, kstart, out, lse,
-                       B, T, H, scale, 0u, key, dscale);
+                       B, T, H, scale, 0u, key, dscale, seq_off);
   NEKO_CHECK_LAUNCH();
   return NEKO_OK;
 }
@@ -1221,7 +1261,8 @@ int fwd_launch(const bf16_t* qkv, const float* kbias, const int* kstart, bf16_t*
 // lane at a 256-B lane stride: 82 us at B = 8, H = 16, T = 1024, more than the forward kernel)
 template <int HD>
 __global__ __launch_bounds__(256) void attn_D_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout, float* __restrict__ D,
-                                                    long npieces, int T, int H, float inv_drop_scale) {
+                                                    long npieces, int T, int H, float inv_drop_scale,
+                                                    const int* __restrict__ seq_off, int nseq) {
   constexpr int LPH = HD / 8;                 // lanes per (row, head)
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   float acc = 0.f;
@@ -1240,15 +1281,26 @@ __global__ __launch_bounds__(256) void attn_D_kernel(const bf16_t* __restrict__ 
     const long rh = i / LPH;                  // row * H + head
     const long row = rh / H;
     const int h = (int)(rh - row * H);
-    const long b = row / T;
-    const int q = (int)(row - b * T);
-    D[(b * H + h) * T + q] = acc * inv_drop_scale;
+    if (seq_off) {                            // packed sequences: the sequence of this row by bisection, D at row0 * H + h * T_b + q
+      int lo = 0, hi = nseq;                  // invariant: seq_off[lo] <= row < seq_off[hi]
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if ((long)seq_off[mid] <= row) lo = mid; else hi = mid;
+      }
+      const long row0 = seq_off[lo];
+      const int Tb = seq_off[lo + 1] - (int)row0;
+      D[row0 * H + (long)h * Tb + (row - row0)] = acc * inv_drop_scale;
+    } else {
+      const long b = row / T;
+      const int q = (int)(row - b * T);
+      D[(b * H + h) * T + q] = acc * inv_drop_scale;
+    }
   }
 }
 
 template <int HD, int NWQ, int NSTQ, int NWK, int NSTK>
 int bwd_launch(const bf16_t* qkv, const bf16_t* dout, const float* kbias, const int* kstart, const float* lse, const float* D,
-               bf16_t* dqkv, int B, int T, int H, int thr, unsigned key, float dscale, hipStream_t s) {
+               bf16_t* dqkv, int B, int T, int H, int thr, unsigned key, float dscale, hipStream_t s, const int* seq_off) {
   const float scale = 1.0f / sqrtf((float)HD);
   const int ntile = (T + KT - 1) / KT;
   {
@@ -1259,11 +1311,11 @@ int bwd_launch(const bf16_t* qkv, const bf16_t* dout, const float* kbias, const 
     if (thr) {
       if (set_lds_limit(&attn_dq_stream_kernel<HD, true, NWQ, NSTQ>, done[1]) != NEKO_OK) return NEKO_ERR_LAUNCH;
       hipLaunchKernelGGL((attn_dq_stream_kernel<HD, true, NWQ, NSTQ>), grid, dim3(64 * NWQ), lds, s, qkv, dout, kbias, kstart, lse, D,
-                         dqkv, B, T, H, scale, (uint32_t)thr, key, dscale);
+                         dqkv, B, T, H, scale, (uint32_t)thr, key, dscale, seq_off);
     } else {
       if (set_lds_limit(&attn_dq_stream_kernel<HD, false, NWQ, NSTQ>, done[0]) != NEKO_OK) return NEKO_ERR_LAUNCH;
       hipLaunchKernelGGL((attn_dq_stream_kernel<HD, false, NWQ, NSTQ>), grid, dim3(64 * NWQ), lds, s, qkv, dout, kbias, kstart, lse, D,
-                         dqkv, B, T, H, scale, 0u, key, dscale);
+                         dqkv, B, T, H, scale, 0u, key, dscale, seq_off);
     }
     NEKO_CHECK_LAUNCH();
   }
@@ -1275,11 +1327,11 @@ int bwd_launch(const bf16_t* qkv, const bf16_t* dout, const float* kbias, const 
     if (thr) {
       if (set_lds_limit(&attn_dkv_stream_kernel<HD, true, NWK, NSTK>, done[1]) != NEKO_OK) return NEKO_ERR_LAUNCH;
       hipLaunchKernelGGL((attn_dkv_stream_kernel<HD, true, NWK, NSTK>), grid, dim3(64 * NWK), lds, s, qkv, dout, kbias, lse, D, dqkv, B,
-                         T, H, scale, (uint32_t)thr, key, dscale);
+                         T, H, scale, (uint32_t)thr, key, dscale, seq_off);
     } else {
       if (set_lds_limit(&attn_dkv_stream_kernel<HD, false, NWK, NSTK>, done[0]) != NEKO_OK) return NEKO_ERR_LAUNCH;
       hipLaunchKernelGGL((attn_dkv_stream_kernel<HD, false, NWK, NSTK>), grid, dim3(64 * NWK), lds, s, qkv, dout, kbias, lse, D, dqkv, B,
-                         T, H, scale, 0u, key, dscale);
+                         T, H, scale, 0u, key, dscale, seq_off);
     }
     NEKO_CHECK_LAUNCH();
   }
@@ -1290,17 +1342,18 @@ int bwd_launch(const bf16_t* qkv, const bf16_t* dout, const float* kbias, const 
 
 bool neko_attn_stream_applicable(int T, int hd) { return (hd == 64 || hd == 128) && T >= 1 && T <= TMAX; }
 
+// seq_off null: the uniform (B, T) batch; otherwise B packed sequences (rows seq_off[b] .. seq_off[b+1]-1) whose longest has T rows
 int neko_attn_fwd_stream_impl(const bf16_t* qkv, const float* kbias, const int* kstart, bf16_t* out, float* lse, int B, int T,
-                              int H, int hd, int drop_thr, unsigned drop_key, float drop_scale, hipStream_t s) {
+                              int H, int hd, int drop_thr, unsigned drop_key, float drop_scale, hipStream_t s, const int* seq_off) {
   // 4 waves x 2 workgroups per CU measured ahead of 8 waves x 1 (hd = 128: 59 vs 63 us at B = 8, 291 vs 312 at B = 32; hd = 64: 70 vs 81)
   static const int nw = [] { const char* e = getenv("NEKO_ATTN_STREAM_WAVES"); return e ? atoi(e) : 4; }();
   if (hd == 128) {
-    if (nw == 4) return fwd_launch<128, 4, 2>(qkv, kbias, kstart, out, lse, B, T, H, drop_thr, drop_key, drop_scale, s);
-    return fwd_launch<128, 8, 3>(qkv, kbias, kstart, out, lse, B, T, H, drop_thr, drop_key, drop_scale, s);
+    if (nw == 4) return fwd_launch<128, 4, 2>(qkv, kbias, kstart, out, lse, B, T, H, drop_thr, drop_key, drop_scale, s, seq_off);
+    return fwd_launch<128, 8, 3>(qkv, kbias, kstart, out, lse, B, T, H, drop_thr, drop_key, drop_scale, s, seq_off);
   }
   if (hd == 64) {
-    if (nw == 4) return fwd_launch<64, 4, 3>(qkv, kbias, kstart, out, lse, B, T, H, drop_thr, drop_key, drop_scale, s);
-    return fwd_launch<64, 8, 3>(qkv, kbias, kstart, out, lse, B, T, H, drop_thr, drop_key, drop_scale, s);
+    if (nw == 4) return fwd_launch<64, 4, 3>(qkv, kbias, kstart, out, lse, B, T, H, drop_thr, drop_key, drop_scale, s, seq_off);
+    return fwd_launch<64, 8, 3>(qkv, kbias, kstart, out, lse, B, T, H, drop_thr, drop_key, drop_scale, s, seq_off);
   }
   return NEKO_ERR_UNSUPPORTED;
 }
@@ -1308,16 +1361,16 @@ int neko_attn_fwd_stream_impl(const bf16_t* qkv, const float* kbias, const int* 
 // D: fp32 workspace [B, H, T]
 int neko_attn_bwd_stream_impl(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const float* kbias, const int* kstart,
                               const float* lse, float* D, bf16_t* dqkv, int B, int T, int H, int hd, int drop_thr,
-                              unsigned drop_key, float drop_scale, hipStream_t s) {
-  const long npieces = (long)B * T * H * hd / 8;
+                              unsigned drop_key, float drop_scale, hipStream_t s, const int* seq_off, long rows) {
+  const long npieces = (seq_off ? rows : (long)B * T) * H * hd / 8;
   const float inv = drop_thr ? 1.0f / drop_scale : 1.0f;
   if (hd == 128)
-    hipLaunchKernelGGL((attn_D_kernel<128>), dim3((unsigned)((npieces + 255) / 256)), dim3(256), 0, s, out, dout, D, npieces, T, H, inv);
+    hipLaunchKernelGGL((attn_D_kernel<128>), dim3((unsigned)((npieces + 255) / 256)), dim3(256), 0, s, out, dout, D, npieces, T, H, inv, seq_off, B);
   else
-    hipLaunchKernelGGL((attn_D_kernel<64>), dim3((unsigned)((npieces + 255) / 256)), dim3(256), 0, s, out, dout, D, npieces, T, H, inv);
+    hipLaunchKernelGGL((attn_D_kernel<64>), dim3((unsigned)((npieces + 255) / 256)), dim3(256), 0, s, out, dout, D, npieces, T, H, inv, seq_off, B);
   NEKO_CHECK_LAUNCH();
-  if (hd == 128) return bwd_launch<128, 4, 2, 4, 3>(qkv, dout, kbias, kstart, lse, D, dqkv, B, T, H, drop_thr, drop_key, drop_scale, s);
-  if (hd == 64) return bwd_launch<64, 4, 3, 4, 3>(qkv, dout, kbias, kstart, lse, D, dqkv, B, T, H, drop_thr, drop_key, drop_scale, s);
+  if (hd == 128) return bwd_launch<128, 4, 2, 4, 3>(qkv, dout, kbias, kstart, lse, D, dqkv, B, T, H, drop_thr, drop_key, drop_scale, s, seq_off);
+  if (hd == 64) return bwd_launch<64, 4, 3, 4, 3>(qkv, dout, kbias, kstart, lse, D, dqkv, B, T, H, drop_thr, drop_key, drop_scale, s, seq_off);
   return NEKO_ERR_UNSUPPORTED;
 }
 

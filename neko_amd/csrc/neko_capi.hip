@@ -75,23 +75,33 @@ int neko_attn_fwd(const uint16_t* qkv, const float* kbias, const int* kstart, ui
   return neko_attn_fwd_impl(qkv, kbias, kstart, out, lse, B, T, H, hd, drop_thr, drop_key, drop_scale, drop_mask, S(stream));
 }
 long neko_attn_mask_dwords(int B, int T, int H, int hd) { return neko_attn_mask_dwords_impl(B, T, H, hd); }
-// packed sequences of different lengths in ONE launch (head-resident kernels only: hd = 32, every length <= 1024)
-int neko_attn_varlen_supported(int Tmax, int hd) { return neko_attn_res_applicable(Tmax, hd) ? 1 : 0; }
+// packed sequences of different lengths in ONE launch: head-resident kernels (hd = 32, every length <= 1024) or the DMA-ring
+// kernels (hd = 64 / 128, every length <= 4096; ABI v16)
+int neko_attn_varlen_supported(int Tmax, int hd) { return (neko_attn_res_applicable(Tmax, hd) || neko_attn_stream_applicable(Tmax, hd)) ? 1 : 0; }
 int neko_attn_fwd_varlen(const uint16_t* qkv, const float* kbias, const int* kstart, const int* seq_off, const long long* mask_off,
                          uint16_t* out, float* lse, int nseq, int Tmax, int H, int hd, int drop_thr, unsigned drop_key,
                          float drop_scale, uint32_t* drop_mask, void* stream) {
   if (!qkv || !kbias || !seq_off || !out || !lse || nseq <= 0 || Tmax <= 0 || H <= 0) return NEKO_ERR_ARG;
   if (drop_thr < 0 || drop_thr > 255 || (drop_mask && !mask_off)) return NEKO_ERR_ARG;
+  if (neko_attn_stream_applicable(Tmax, hd)) {          // hd = 64 / 128: no stored keep masks (the backward re-hashes the decisions)
+    if (drop_mask) return NEKO_ERR_ARG;
+    return neko_attn_fwd_stream_impl(qkv, kbias, kstart, out, lse, nseq, Tmax, H, hd, drop_thr, drop_key, drop_scale, S(stream), seq_off);
+  }
   if (!neko_attn_res_applicable(Tmax, hd)) return NEKO_ERR_UNSUPPORTED;
   return neko_attn_fwd_res_impl(qkv, kbias, kstart, out, lse, nseq, Tmax, H, drop_thr, drop_key, drop_scale, drop_mask, S(stream),
                                 seq_off, mask_off);
 }
 int neko_attn_bwd_varlen(const uint16_t* qkv, const uint16_t* out, const uint16_t* dout, const float* kbias, const int* kstart,
                          const int* seq_off, const long long* mask_off, const float* lse, float* D, uint16_t* dqkv, int nseq,
-                         int Tmax, int H, int hd, int drop_thr, unsigned drop_key, float drop_scale, const uint32_t* drop_mask,
-                         void* stream) {
+                         long rows, int Tmax, int H, int hd, int drop_thr, unsigned drop_key, float drop_scale,
+                         const uint32_t* drop_mask, void* stream) {
   if (!qkv || !out || !dout || !kbias || !seq_off || !lse || !D || !dqkv || nseq <= 0 || Tmax <= 0 || H <= 0) return NEKO_ERR_ARG;
   if (drop_thr < 0 || drop_thr > 255 || (drop_mask && !mask_off)) return NEKO_ERR_ARG;
+  if (neko_attn_stream_applicable(Tmax, hd)) {
+    if (drop_mask || rows <= 0) return NEKO_ERR_ARG;
+    return neko_attn_bwd_stream_impl(qkv, out, dout, kbias, kstart, lse, D, dqkv, nseq, Tmax, H, hd, drop_thr, drop_key, drop_scale,
+                                     S(stream), seq_off, rows);
+  }
   if (!neko_attn_res_applicable(Tmax, hd)) return NEKO_ERR_UNSUPPORTED;
   return neko_attn_bwd_res_impl(qkv, out, dout, kbias, kstart, lse, D, dqkv, nseq, Tmax, H, drop_thr, drop_key, drop_scale,
                                 drop_mask, S(stream), seq_off, mask_off);

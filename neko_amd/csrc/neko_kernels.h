@@ -63,9 +63,10 @@ bool neko_attn_res_applicable(int T, int hd);
 bool neko_attn_stream_applicable(int T, int hd);
 int neko_attn_bwd_stream_impl(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const float* kbias, const int* kstart,
                               const float* lse, float* D, bf16_t* dqkv, int B, int T, int H, int hd, int drop_thr,
-                              unsigned drop_key, float drop_scale, hipStream_t s);
+                              unsigned drop_key, float drop_scale, hipStream_t s, const int* seq_off = nullptr, long rows = 0);
 int neko_attn_fwd_stream_impl(const bf16_t* qkv, const float* kbias, const int* kstart, bf16_t* out, float* lse, int B, int T,
-                              int H, int hd, int drop_thr, unsigned drop_key, float drop_scale, hipStream_t s);
+                              int H, int hd, int drop_thr, unsigned drop_key, float drop_scale, hipStream_t s,
+                              const int* seq_off = nullptr);
 int neko_attn_fwd_res_impl(const bf16_t* qkv, const float* kbias, const int* kstart, bf16_t* out, float* lse, int B, int T,
                            int H, int drop_thr, unsigned drop_key, float drop_scale, uint32_t* dmask, hipStream_t s,
                            const int* seq_off = nullptr, const long long* mask_off = nullptr);

@@ -278,7 +278,7 @@ def attn_fwd_varlen(qkv, kbias, kstart, geom: VarlenGeom, hd, drop=None, out=Non
         out = torch.empty(qkv.shape[0], H * hd, dtype=BF16, device=qkv.device)
     lse = torch.empty(geom.rows * H, dtype=torch.float32, device=qkv.device)
     mask = None
-    if want_mask and drop is not None and drop.thr > 0:
+    if want_mask and drop is not None and drop.thr > 0 and hd == 32:      # only the head-resident kernels hand keep masks on
         mask = torch.empty(geom.mask_dwords, dtype=torch.int32, device=qkv.device)
     _lib.call("neko_attn_fwd_varlen", _p(qkv), _p(kbias), _p(kstart), _p(geom.seq_off), _p(geom.mask_off), _p(out), _p(lse),
               geom.nseq, geom.Tmax, H, hd, *_drop(drop), _p(mask), _stream())
@@ -313,7 +313,7 @@ def attn_bwd_varlen(qkv, out, dout, kbias, kstart, lse, geom: VarlenGeom, hd, dr
         _chk(mask, torch.int32, "mask"); assert mask.numel() == geom.mask_dwords
     with _DetAttnPath():
         _lib.call("neko_attn_bwd_varlen", _p(qkv), _p(out), _p(dout), _p(kbias), _p(kstart), _p(geom.seq_off), _p(geom.mask_off),
-                  _p(lse), _p(D), _p(dqkv), geom.nseq, geom.Tmax, H, hd, *_drop(drop), _p(mask), _stream())
+                  _p(lse), _p(D), _p(dqkv), geom.nseq, geom.rows, geom.Tmax, H, hd, *_drop(drop), _p(mask), _stream())
     return dqkv
 
 

@@ -815,6 +815,61 @@ def test_attention_varlen_equals_per_sequence_calls(ops):
             ops.attn_set_path(prev)
 
 
+@pytest.mark.parametrize("hd,H", [(128, 2), (64, 3)])
+@pytest.mark.parametrize("drop_p", [0.0, 0.1])
+def test_attention_varlen_wide_heads_equals_per_sequence_calls(ops, hd, H, drop_p):
+    """hd = 64 / 128 (the DMA-ring kernels, ABI v16): one packed launch over sequences of 1024 / 200 / 33 / 2048 / 97 / 1000 positions
+    (two left-padded; 2048 is beyond the head-resident limit) gives the very bits of running every sequence alone -- out, lse and
+    dqkv without dropout; with dropout the hash walks packed row ids, so the packed result is held against the fp32 oracle with
+    the host restatement of that index instead (every sequence, forward and backward)."""
+    d = H * hd
+    lengths = [1024, 200, 33, 2048, 97, 1000] if drop_p == 0.0 else [300, 64, 33, 520]
+    pads = [0, 17, 0, 40, 0, 0][:len(lengths)]
+    rows = sum(lengths)
+    g = torch.Generator(device=DEV).manual_seed(41 + hd)
+    qkv = (torch.randn(rows, 3 * d, device=DEV, generator=g) * 0.6).to(torch.bfloat16)
+    do = torch.randn(rows, d, device=DEV, generator=g).to(torch.bfloat16)
+    kbs, kss, r0 = [], [], 0
+    for T, pad in zip(lengths, pads):
+        m = torch.ones(1, T, device=DEV)
+        m[0, :pad] = 0
+        kb, ks = ops.mask_bias(m)
+        kbs.append(kb.reshape(-1)); kss.append(ks.reshape(-1))
+        do[r0:r0 + pad] = 0
+        r0 += T
+    geom = ops.VarlenGeom(lengths, H, DEV)
+    kb_all, ks_all = torch.cat(kbs), torch.cat(kss)
+    drop = ops.Drop(drop_p, 0xFACE) if drop_p > 0 else None
+    out, lse, mk = ops.attn_fwd_varlen(qkv, kb_all, ks_all, geom, hd, drop=drop, want_mask=True)
+    assert mk is None                                   # these kernels re-hash the keep decisions in the backward
+    dqkv = ops.attn_bwd_varlen(qkv, out, do, kb_all, ks_all, lse, geom, hd, drop=drop)
+    r0 = 0
+    if drop is None:
+        for i, T in enumerate(lengths):
+            q1 = qkv[r0:r0 + T].contiguous()
+            o1, l1 = ops.attn_fwd(q1, kbs[i].view(1, T), kss[i], 1, T, H, hd)
+            g1 = ops.attn_bwd(q1, o1, do[r0:r0 + T].contiguous(), kbs[i].view(1, T), kss[i], l1, 1, T, H, hd)
+            assert torch.equal(out[r0:r0 + T], o1), f"out of sequence {i}"
+            assert torch.equal(lse[r0 * H:(r0 + T) * H].view(H, T), l1.view(H, T)), f"lse of sequence {i}"
+            assert torch.equal(dqkv[r0:r0 + T], g1), f"dqkv of sequence {i}"
+            r0 += T
+        return
+    from test_dropout_gpu import mask_attn_varlen          # (tests/ is on sys.path: pytest's rootdir insertion)
+    dms = mask_attn_varlen(lengths, H, drop)
+    for i, T in enumerate(lengths):
+        x = qkv[r0:r0 + T].float().cpu().view(1, T, 3 * d).clone().requires_grad_(True)
+        q, k, v = x.split(d, dim=2)
+        sh = lambda t: t.view(1, T, H, hd).permute(0, 2, 1, 3)
+        mask = torch.ones(1, T); mask[0, :pads[i]] = 0
+        o_ref = O.attention_core(sh(q), sh(k), sh(v), mask, drop_mask=dms[i]).permute(0, 2, 1, 3).reshape(1, T, d)
+        o_ref.backward(do[r0:r0 + T].float().cpu().view(1, T, d))
+        sc = float(o_ref.detach().abs().max())
+        assert float((out[r0:r0 + T].float().cpu() - o_ref.detach()[0]).abs().max()) < 1e-2 * sc, f"out of sequence {i}"
+        gs = float(x.grad.abs().max())
+        assert float((dqkv[r0:r0 + T].float().cpu() - x.grad[0]).abs().max()) < 2e-2 * gs, f"dqkv of sequence {i}"
+        r0 += T
+
+
 def test_attention_varlen_dropout_masks_are_consistent(ops):
     """Packed launch with attention dropout: the backward that reuses the forward's stored keep masks must produce the very bits of
     the backward that re-hashes them (same index formula on both sides: unique row id x ceil(Tmax / 4) + key / 4), the keep rate

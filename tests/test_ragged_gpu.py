@@ -50,9 +50,14 @@ def grads_of(m):
     return {k: p.grad.detach().float().cpu().clone() for k, p in m.named_parameters() if p.grad is not None}
 
 
+@pytest.mark.parametrize("hd", [32, 64, 128], ids=["hd32-head-resident", "hd64-dma-ring", "hd128-dma-ring"])
 @pytest.mark.parametrize("groups", [1, 2, 3, 8])
-def test_ragged_loss_and_grads_equal_padded_layout_and_oracle(groups):
-    cfg = O.OracleConfig(embed_dim=64, layers=2, heads=2, text_tokens=128, context_len=96)
+def test_ragged_loss_and_grads_equal_padded_layout_and_oracle(groups, hd):
+    """hd = 64 / 128 (configs[4]'s head width): since ABI v16 the packed layout runs ONE launch of the DMA-ring attention kernels
+    too (before, one launch per length bucket)."""
+    from neko_amd import ops
+    assert ops.attn_varlen_supported(96, hd)
+    cfg = O.OracleConfig(embed_dim=2 * hd, layers=2, heads=2, text_tokens=128, context_len=96)
     batch = ragged_batch()
     m = make_policy(cfg, 11)                     # eval mode: deterministic patch positions in both layouts
     _, loss_pad = m(to_dev(batch), compute_loss=True, return_logits=False)
@@ -68,7 +73,9 @@ def test_ragged_loss_and_grads_equal_padded_layout_and_oracle(groups):
         assert sum(b * t for _, b, t in m.last_pack.segments) < 0.9 * len(batch) * 91
     loss_rag.backward()
     g_rag = grads_of(m)
-    assert abs(float(loss_rag) - float(loss_pad)) < 2e-6 * abs(float(loss_pad)), (float(loss_rag), float(loss_pad))
+    # (hd = 64 / 128: the DMA-ring kernels walk 64-key tiles from the first row of a sequence INCLUDING its padding, so the two layouts
+    # add the same probabilities up in other groupings and a few bf16 roundings of the attention output fall differently: 2.0e-6 measured)
+    assert abs(float(loss_rag) - float(loss_pad)) < (2e-6 if hd == 32 else 1e-5) * abs(float(loss_pad)), (float(loss_rag), float(loss_pad))
     assert g_rag.keys() == g_pad.keys()
     for k in g_pad:
         scale = float(g_pad[k].abs().max())
