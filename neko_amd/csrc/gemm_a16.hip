@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256, 1) void gemm_a16_kernel(GemmArgs p) {
   const unsigned nkt = (unsigned)(kend - kbeg) / 32u;
 
   // per-lane DMA source offsets (bytes from the operand's tile origin) and LDS read addresses; layouts: gen_gemm_a16.py
-  constexpr bool KC64 = NEKO_A16_KC_MODE == 64;
+  constexpr bool KC64_OF[2] = {NEKO_A16_KC_MODE_A == 64, NEKO_A16_KC_MODE_B == 64};
   const unsigned lds0 = __builtin_amdgcn_readfirstlane(
       (unsigned)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)smem));
   const int c16 = lane & 15, g4 = lane >> 4;
@@ -75,6 +75,7 @@ __global__ __launch_bounds__(256, 1) void gemm_a16_kernel(GemmArgs p) {
     const long ld = x ? p.ldb : p.lda;
     const int half = x ? wn : wm;                                            // which 128 rows / columns of the tile this wave reads
     const unsigned region = lds0 + (x ? 65536u : 0u);
+    const bool KC64 = KC64_OF[x];
     hh[x] = (unsigned)ks_hh(krd);
 #pragma unroll
     for (int pc = 0; pc < 8; ++pc) {

@@ -238,17 +238,27 @@ SCHED = {"read_span": 40, "dma_first": 4, "dma_step": 6, "snake": True}
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--kc", type=int, default=64, choices=(32, 64))
+    ap.add_argument("--kc", type=int, default=64, choices=(32, 64), help="layout of a k-contiguous A operand")
+    ap.add_argument("--kcb", type=int, default=32, choices=(0, 32, 64),
+                    help="layout of a k-contiguous B operand (0: same as --kc).  Default 32: with both operands in two 64-k slots every DMA piece "
+                         "of a trip falls into its odd tiles and the queue drains completely every second tile; B on the 4-stage 32-k ring spreads "
+                         "them (12 / 4 pieces per tile) -- dgrad fc 65536 x 768 x 3072: 318 -> 301 us, 8192^3 NT -1.3 % (profiles/r04_gemm_a16_ab.txt)")
+    ap.add_argument("--read-span", type=int, default=SCHED["read_span"], help="the next tile's fragment reads are spread over the first N MFMAs")
+    ap.add_argument("--dma-first", type=int, default=SCHED["dma_first"], help="MFMA index behind which the first DMA piece of a tile is issued")
+    ap.add_argument("--dma-step", type=int, default=SCHED["dma_step"], help="MFMAs between two DMA pieces (shrunk when a tile issues many)")
+    ap.add_argument("--no-snake", action="store_true", help="row-major MFMA order instead of the serpentine one")
     ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "neko_amd", "csrc",
                                                   "gemm_a16_loop.inc"))
     args = ap.parse_args()
+    SCHED.update(read_span=args.read_span, dma_first=args.dma_first, dma_step=args.dma_step, snake=not args.no_snake)
     kc = f"kc{args.kc}"
+    kcb = f"kc{args.kcb or args.kc}"
     txt = ["// GENERATED by tools/gen_gemm_a16.py -- do not edit; the generator is the source (design notes in its docstring).",
-           f"#define NEKO_A16_KC_MODE {args.kc}", ""]
+           f"#define NEKO_A16_KC_MODE_A {args.kc}", f"#define NEKO_A16_KC_MODE_B {args.kcb or args.kc}", ""]
     for a_kc in (True, False):
         for b_kc in (True, False):
             name = f"NEKO_A16_LOOP_{'KC' if a_kc else 'KS'}_{'KC' if b_kc else 'KS'}"
-            L, counts, n0 = stream(kc if a_kc else "ks", kc if b_kc else "ks", SCHED)
+            L, counts, n0 = stream(kc if a_kc else "ks", kcb if b_kc else "ks", SCHED)
             txt.append(f"// {name}: vmcnt at the prologue wait {n0}, at the four tiles of a trip {counts}")
             txt.append(f"#define {name} \\")
             txt += [f'  "{ins}\\n\\t" \\' for ins in L[:-1]]
