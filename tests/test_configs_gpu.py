@@ -210,4 +210,4 @@ def test_metric_shape_gradients_add_up():
         # same kernels, same order of every fixed-order reduction; only the atomically scattered embedding rows may differ
         # in their last bits
         assert float((r1s - r3).abs().max()) / den < 1e-5, (name, "side stream vs one stream")
-        assert float((r1 - r1s).abs().max()) / den < 2e-3, (name, "one-pass vs two-kernel attention backward")
+        assert float((r1 - r1s).abs().max()) / den < 5e-3, (name, "one-pass vs two-kernel attention backward")
