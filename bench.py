@@ -406,6 +406,11 @@ def main():
         lp = model.last_pack
         lm_frac = (lp.n_loss / float(B * Tlen)) if (lp is not None and lp.n_loss > 0 and model.lm_head_selected_rows) else 1.0
         fpt = 3 * flops_per_token_fwd(d=D, layers=L, t=Tlen, lm_rows_frac=lm_frac)
+        if lp is not None and lp.segments:
+            # length-grouped (ragged) layout: the stack runs the packed rows only and attention sees every group at its own length --
+            # the executed FLOPs per step, expressed per position of the padded (B, T) batch that `value` counts
+            ex = sum(bk * tk * L * (24 * D * D + 2 * D * (tk + 1)) for (_, bk, tk) in lp.segments) + 2 * D * V * lp.n_loss
+            fpt = 3 * ex / float(B * Tlen)
         # the launch the step itself makes: every loss row of the batch in one logits GEMM, up to lm_head_chunk_rows
         # (same padding rule as engine.lm_head_loss_selected: whole 256-row tiles once the batch is large)
         pad_rows = lambda n: max(64, (n + 63) // 64 * 64) if n < 2048 else (n + 255) // 256 * 256
