@@ -30,7 +30,7 @@ __device__ __forceinline__ void tile_coords(const GemmArgs& p, int& tm, int& tn,
 #ifndef NEKO_GEMM_GROUP_M
 #define NEKO_GEMM_GROUP_M 8        // row panels per rasterisation group (4 / 16 measured in round 3: profiles/r03_step_ab.txt)
 #endif
-  constexpr int GROUP_M = NEKO_GEMM_GROUP_M;
+  const int GROUP_M = p.group_m > 0 ? p.group_m : NEKO_GEMM_GROUP_M;
   const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
   int bid = xcd_remap(blockIdx.x, gridDim.x);
   slice = bid / (nbm * nbn);

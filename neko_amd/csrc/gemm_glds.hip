@@ -729,7 +729,28 @@ int neko_colsum_bands_reduce_impl(const float* ws, int bands, int N, float* out,
 }
 
 // returns 1 if the fast path does not apply (caller falls back), otherwise a neko status code
-int neko_gemm_glds_try(const GemmArgs& a, int a_kstrided, int b_kstrided, hipStream_t s) {
+namespace {
+// Row panels per rasterisation group (tile_coords walks a group's tiles row-panel-fastest).  An XCD runs 32 consecutive tiles at a time:
+// with GROUP_M x nbn <= 32 the tiles that share an A row panel run in the same round and the panel is fetched once.
+// Measured inside the m-mix step (profiles/r04_group_m_ab.txt): 2 panels per group for every class -0.3...0.5 ms per step against 8 (the
+// product until round 4), each class contributing about a third; 1 and 4 are level with 8.  The isolated per-shape timings of the same
+// file do not predict this (wide outputs measure 1-3 % slower alone): inside the step the operands were just written by the
+// previous kernel and what matters is how much of them is still in the 256 MB last-level cache when their tiles come up.
+// NEKO_GEMM_GM_NARROW / _WIDE / _SPLITK override the three classes.
+int group_m_for(const GemmArgs& a) {
+  static const int env_n = [] { const char* e = getenv("NEKO_GEMM_GM_NARROW"); return e ? atoi(e) : 2; }();
+  static const int env_w = [] { const char* e = getenv("NEKO_GEMM_GM_WIDE"); return e ? atoi(e) : 2; }();
+  static const int env_s = [] { const char* e = getenv("NEKO_GEMM_GM_SPLITK"); return e ? atoi(e) : 2; }();
+  const int nbn = (a.N + 255) / 256;
+  if (a.splitk > 1) return env_s;
+  if (nbn <= 4) return env_n;
+  return env_w;
+}
+}  // namespace
+
+int neko_gemm_glds_try(const GemmArgs& a_in, int a_kstrided, int b_kstrided, hipStream_t s) {
+  GemmArgs a = a_in;
+  a.group_m = group_m_for(a);
   t_colsum_bands = 0;
   if (a.K % 64) return 1;
   if (a.splitk > 1 && (a.k_per_split % 64)) return 1;

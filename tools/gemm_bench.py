@@ -20,6 +20,7 @@ SHAPES = [
     ("fwd proj  NN", M, D, D, False, True, "bias,resid,f32"),
     ("fwd fc    NN", M, 4 * D, D, False, True, "bias,gelu,bf16"),
     ("fwd pr    NN", M, D, 4 * D, False, True, "bias,resid,f32"),
+    ("fwd prdrop NN", M, D, 4 * D, False, True, "bias,resid,drop,f32"),
     ("dgrad pr  NT", M, 4 * D, D, False, False, "gelubwd,bf16"),
     ("dgrad fc  NT", M, D, 4 * D, False, False, "f32"),
     ("dgrad o   NT", M, D, D, False, False, "bf16"),
@@ -80,6 +81,9 @@ def main():
             kw["bias"] = torch.randn(n, device=dev)
         if "resid" in ex:
             kw["resid"] = torch.randn(m, n, device=dev)
+        if "drop" in ex:
+            import types
+            kw["drop"] = types.SimpleNamespace(thr=26, key=0x1234567, scale=256.0 / 230.0)
         if "gelu," in ex:
             kw["act"] = 1
             kw["pre_out"] = torch.empty(m, n, dtype=BF, device=dev)

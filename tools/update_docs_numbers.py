@@ -11,6 +11,11 @@ tag = sys.argv[1]
 b = lambda n: json.load(open(os.path.join(root, "profiles", f"{tag}_{n}_bench.json")))
 mm, m32, mt, c2, c3, c4 = b("mmix"), b("mmix_b32"), b("mtext"), b("c2"), b("c3"), b("c4")
 g12, c5p, c5r = b("gato1p2b_mtext_b8"), b("c5mix_pad"), b("c5mix_rag4")
+g32, g64 = b("gato1p2b_mmix_b32"), b("gato1p2b_mmix_b64")
+try:
+    g5r = b("gato1p2b_c5mix_rag4")
+except FileNotFoundError:
+    g5r = None
 rm = {e["kernel"]: e for e in mm["roofline_more"]}
 traffic = mm['roofline']['traffic'] or json.load(open(os.path.join(root, 'profiles', f'{tag}_lmhead_traffic.json')))['traffic_bytes_per_launch']
 shape = mm['roofline'].get('shape_MNK', [4096, 52305, 768])
@@ -19,10 +24,11 @@ design = f"""<!-- bench:begin -->
 | workload (1 x MI355X, dropout 0.1, fwd + bwd + clip + AdamW, synthetic data; `profiles/{tag}_*`) | ms / step | tokens/s | step MFMA fraction |
 |---|---|---|---|
 | **m-mix, 64 x 1024 tokens per step (the bench default)** | {mm['ms_per_step']:.2f} | **{mm['value']/1e6:.3f} M** | {mm['step_mfma_frac']:.3f} |
-| m-mix, 32 x 1024 (the r01 default; r01: 23.81 ms, 1.376 M, 0.202) | {m32['ms_per_step']:.2f} | {m32['value']/1e6:.3f} M | {m32['step_mfma_frac']:.3f} |
+| m-mix, 32 x 1024 (r01: 23.81 ms, 1.376 M, 0.202; r03: 21.83 ms, 0.219) | {m32['ms_per_step']:.2f} | {m32['value']/1e6:.3f} M | {m32['step_mfma_frac']:.3f} |
 | m-text, 64 x 1024 (LM head on every position; r01 at 32: 1.19 M, 0.245) | {mt['ms_per_step']:.2f} | {mt['value']/1e6:.3f} M | {mt['step_mfma_frac']:.3f} |
 | c2 / c3 / c4 (README shapes, 32 sequences) | {c2['ms_per_step']:.2f} / {c3['ms_per_step']:.2f} / {c4['ms_per_step']:.2f} | {c2['value']/1e6:.2f} / {c3['value']/1e6:.2f} / {c4['value']/1e6:.2f} M | {c2['step_mfma_frac']:.3f} / {c3['step_mfma_frac']:.3f} / {c4['step_mfma_frac']:.3f} |
-| configs[4] Gato-1.2B (2048d x 24L x 16H, hd = 128), m-text, 8 x 1024 (r02: 84.5 ms, 0.318) | {g12['ms_per_step']:.2f} | {g12['value']/1e6:.3f} M | {g12['step_mfma_frac']:.3f} |
+| configs[4] Gato-1.2B (2048d x 24L x 16H, hd = 128), m-text, 8 x 1024 (r02: 84.5 ms, 0.318; r03: 77.6 ms, 0.346) | {g12['ms_per_step']:.2f} | {g12['value']/1e6:.3f} M | {g12['step_mfma_frac']:.3f} |
+| configs[4] Gato-1.2B on the FULL mix (m-mix: text + image-patch + control examples), 32 x 1024 / 64 x 1024 | {g32['ms_per_step']:.1f} / {g64['ms_per_step']:.1f} | {g32['value']/1e6:.3f} / {g64['value']/1e6:.3f} M | {g32['step_mfma_frac']:.3f} / {g64['step_mfma_frac']:.3f} |
 | c5-mix (1024 / 494 / 289 / 240-token examples, 8 each): padded layout / 4 length groups, varlen attention | {c5p['ms_per_step']:.2f} / {c5r['ms_per_step']:.2f} | {c5p['real_tokens_per_sec']/1e6:.2f} / {c5r['real_tokens_per_sec']/1e6:.2f} M real tokens/s | {c5p['step_mfma_frac']:.3f} / {c5r['step_mfma_frac']:.3f} |
 
 `roofline` of the bench line (LM-head logits GEMM {shape[0]} x {shape[1]} x {shape[2]}, HIP events): {mm['roofline']['achieved']:.0f} TFLOP/s = {mm['roofline']['frac']:.3f} of 2.5 PFLOP/s, {traffic/1e6:.0f} MB of
@@ -31,6 +37,8 @@ fabric traffic per launch (`profiles/{tag}_lmhead_traffic.json`); `cpu_baseline`
 | kernel | us | TFLOP/s (useful) | of 2.5 PF |
 |---|---|---|---|
 """ + "".join(f"| {k} | {e['ms_per_launch']*1e3:.0f} | {e['achieved']:.0f} | {e['frac']:.3f} |\n" for k, e in rm.items()) + "<!-- bench:end -->"
+if g5r is not None:
+    design = design.replace("\n\n`roofline` of the bench line", f"\n| configs[4] Gato-1.2B, c5-mix in 4 length groups (one varlen hd = 128 attention launch per layer and pass), 32 examples | {g5r['ms_per_step']:.1f} | {g5r['real_tokens_per_sec']/1e6:.3f} M real tokens/s | {g5r['step_mfma_frac']:.3f} |\n\n`roofline` of the bench line", 1)
 
 readme = f"""<!-- bench:begin -->
 | workload (`bench.py --workload …`; `profiles/{tag}_*`, one box) | step | rate | step MFMA fraction |
