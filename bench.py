@@ -255,6 +255,11 @@ def main():
     # cuda:0, gradients reduced through the host) -- exercises the DP hooks, barriers and max-over-ranks timing, not
     # a performance configuration
     backend = os.environ.get("NEKO_BENCH_BACKEND", "nccl")
+    # stdout carries exactly ONE line, rank 0's JSON: whatever else writes to fd 1 during the run (RCCL prints a version banner
+    # through C stdio when the first communicator is created) is sent to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     if os.environ.get("NEKO_BENCH_ONE_DEVICE") == "1":
         local = 0
     torch.cuda.set_device(local)
@@ -484,7 +489,7 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:          # rank 0 at N = 1 only (the other ranks would idle behind it)
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out), flush=True)
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if world > 1 or args.force_dp:
         torch.distributed.destroy_process_group()
 

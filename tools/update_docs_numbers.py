@@ -13,7 +13,7 @@ mm, m32, mt, c2, c3, c4 = b("mmix"), b("mmix_b32"), b("mtext"), b("c2"), b("c3")
 g12, c5p, c5r = b("gato1p2b_mtext_b8"), b("c5mix_pad"), b("c5mix_rag4")
 g32, g64 = b("gato1p2b_mmix_b32"), b("gato1p2b_mmix_b64")
 try:
-    g5r = b("gato1p2b_c5mix_rag4")
+    g5r = b("gato1p2b_c5mix_rag4_b32")
 except FileNotFoundError:
     g5r = None
 rm = {e["kernel"]: e for e in mm["roofline_more"]}
@@ -24,10 +24,10 @@ design = f"""<!-- bench:begin -->
 | workload (1 x MI355X, dropout 0.1, fwd + bwd + clip + AdamW, synthetic data; `profiles/{tag}_*`) | ms / step | tokens/s | step MFMA fraction |
 |---|---|---|---|
 | **m-mix, 64 x 1024 tokens per step (the bench default)** | {mm['ms_per_step']:.2f} | **{mm['value']/1e6:.3f} M** | {mm['step_mfma_frac']:.3f} |
-| m-mix, 32 x 1024 (r01: 23.81 ms, 1.376 M, 0.202; r03: 21.83 ms, 0.219) | {m32['ms_per_step']:.2f} | {m32['value']/1e6:.3f} M | {m32['step_mfma_frac']:.3f} |
+| m-mix, 32 x 1024 (r01: 23.81 ms, 1.376 M, 0.202; r03: 21.14 ms, 0.228) | {m32['ms_per_step']:.2f} | {m32['value']/1e6:.3f} M | {m32['step_mfma_frac']:.3f} |
 | m-text, 64 x 1024 (LM head on every position; r01 at 32: 1.19 M, 0.245) | {mt['ms_per_step']:.2f} | {mt['value']/1e6:.3f} M | {mt['step_mfma_frac']:.3f} |
 | c2 / c3 / c4 (README shapes, 32 sequences) | {c2['ms_per_step']:.2f} / {c3['ms_per_step']:.2f} / {c4['ms_per_step']:.2f} | {c2['value']/1e6:.2f} / {c3['value']/1e6:.2f} / {c4['value']/1e6:.2f} M | {c2['step_mfma_frac']:.3f} / {c3['step_mfma_frac']:.3f} / {c4['step_mfma_frac']:.3f} |
-| configs[4] Gato-1.2B (2048d x 24L x 16H, hd = 128), m-text, 8 x 1024 (r02: 84.5 ms, 0.318; r03: 77.6 ms, 0.346) | {g12['ms_per_step']:.2f} | {g12['value']/1e6:.3f} M | {g12['step_mfma_frac']:.3f} |
+| configs[4] Gato-1.2B (2048d x 24L x 16H, hd = 128), m-text, 8 x 1024 (r02: 84.5 ms, 0.318; r03: 78.64 ms, 0.341) | {g12['ms_per_step']:.2f} | {g12['value']/1e6:.3f} M | {g12['step_mfma_frac']:.3f} |
 | configs[4] Gato-1.2B on the FULL mix (m-mix: text + image-patch + control examples), 32 x 1024 / 64 x 1024 | {g32['ms_per_step']:.1f} / {g64['ms_per_step']:.1f} | {g32['value']/1e6:.3f} / {g64['value']/1e6:.3f} M | {g32['step_mfma_frac']:.3f} / {g64['step_mfma_frac']:.3f} |
 | c5-mix (1024 / 494 / 289 / 240-token examples, 8 each): padded layout / 4 length groups, varlen attention | {c5p['ms_per_step']:.2f} / {c5r['ms_per_step']:.2f} | {c5p['real_tokens_per_sec']/1e6:.2f} / {c5r['real_tokens_per_sec']/1e6:.2f} M real tokens/s | {c5p['step_mfma_frac']:.3f} / {c5r['step_mfma_frac']:.3f} |
 
