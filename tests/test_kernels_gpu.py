@@ -324,6 +324,14 @@ def test_gemm_gelu_factor_epilogues(ops, M, N, K):
     out2 = torch.empty_like(out)
     ops.gemm(bf(dY), bf(W2), M, N, K, act=4, act_in=fac, out_bf16=out2)
     assert torch.equal(out, out2)
+    # act = 4 (stored bf16 factor) against act = 2 (gelu' evaluated in fp32 from the bf16 pre-activation) on the SAME inputs:
+    # the stored factor costs exactly one more bf16 rounding per element (2^-9 relative on top of the output's own rounding)
+    out_a2 = torch.empty_like(out)
+    ops.gemm(bf(dY), bf(W2), M, N, K, act=2, act_in=pre, out_bf16=out_a2)
+    a4, a2 = out.float().cpu(), out_a2.float().cpu()
+    close(out, a2, 2 ** -7, 1e-3, "act = 4 vs act = 2")
+    rel = float((a4 - a2).norm() / a2.norm())
+    assert rel < 2 ** -8, rel          # one more bf16 rounding per element (2^-9 relative, unbiased); profiles/r04_gelu_factor_bound.txt
 
 
 # ----------------------------------------------------------------------------------------------------
