@@ -7,6 +7,10 @@ that work takes at min(matrix pipe at the SUSTAINED clock, 6.3 TB/s), the measur
 Shapes: the bench default (768d x 6L x 24H, 64 x 1024 positions per step, 22784 loss rows after padding, 52480 computed vocabulary
 columns, ~12289 image patches).  Measured times: the rocprofv3 kernel table of the same step (sum of the family's kernels divided by
 the steps in the table; the table's launches of bench.py's own roofline legs are taken out by their grid sizes).
+Vector floor (attention and the patch kernels are VALU work, not matrix work): executed vector instructions x 64 lanes / (1024 SIMDs x 16
+lanes per clock x clock).  Attention: SQ_INSTS_VALU per launch of profiles/r04_attn_counters.txt (forward 1.322e8, one-pass backward
+1.677e8 wave-instructions at B = 64; 10.5 per score in the forward, 4.3 of them the dropout decision); ResidualBlock: the ISA's vector
+instructions per patch and wave (forward 2601, backward 4310; exact-erf GELU on 128 channels x 256 pixels) x 4 waves x 12289 patches.
 Sustained clock: what the counters of this round show under each kind of load (profiles/r04_gemm_counters.txt: 8192^3 on the
 hand-placed loop runs at 1.55 GHz, the K = 768 shapes and attention around 2.0-2.1 GHz); the matrix peak scales with it from
 2.5 PFLOP/s at 2.4 GHz."""
@@ -17,6 +21,9 @@ M, D, L, T, B, H = 65536, 768, 6, 1024, 64, 24
 ROWS_LM, VPAD, V = 22784, 52480, 52305
 PATCHES = 12289
 PEAK, HBM = 2.5e15, 6.3e12
+VALU_LANES_PER_CLK = 1024 * 16        # SIMDs x lanes issued per clock
+ATTN_VALU_WAVE_INSTS = (1.322e8 + 1.677e8) * 6          # per step: forward + backward launch, 6 layers
+PATCH_VALU_WAVE_INSTS = (2601 + 4310) * 4 * 12289.0     # per step
 
 
 def fam_of(name, blocks):
@@ -80,26 +87,30 @@ def main():
     fams = [
         ("block GEMMs (c_attn, c_proj, c_fc, mlp c_proj: fwd, dgrad, wgrad) + patch projection", gemm_flops, gemm_bytes, 1.85),
         ("LM-head GEMMs (logits, dH, dW)", lm_flops, lm_bytes, 1.7),
-        ("attention (hd = 32: fwd + one-pass bwd)", attn_flops, attn_bytes, 2.1),
+        ("attention (hd = 32: fwd + one-pass bwd)", attn_flops, attn_bytes, 2.1, ATTN_VALU_WAVE_INSTS),
         ("LayerNorm fwd / bwd (+ parameter reductions)", 0.0, ln_bytes, 2.1),
         ("cross-entropy (bf16 logits -> dlogits in place)", 0.0, ce_bytes, 2.1),
-        ("image patch kernels (ResidualBlock fwd / bwd, position add)", patch_flops, PATCHES * 768 * (4 + 2 + 4 + 4) * 2.0, 2.1),
+        ("image patch kernels (ResidualBlock fwd / bwd, position add)", patch_flops, PATCHES * 768 * (4 + 2 + 4 + 4) * 2.0, 2.1, PATCH_VALU_WAVE_INSTS),
         ("clip + AdamW", 0.0, adam_bytes, 2.1),
         ("split-K / column-sum reductions", 0.0, 0.0, 2.1),
         ("packing / embedding / row gathers", 0.0, M * D * 4 * 4.0, 2.1),
         ("other (fills, copies, torch glue)", 0.0, 0.0, 2.1),
     ]
-    print(f"| kernel family (m-mix, 64 x 1024 per step; `{path}`) | executed TFLOP | algorithmic GB | sustained GHz | floor ms = max(FLOP / (2.5 PF x GHz / 2.4), B / 6.3 TB/s) | measured ms | measured / floor |")
-    print("|---|---|---|---|---|---|---|")
+    print(f"| kernel family (m-mix, 64 x 1024 per step; `{path}`) | executed TFLOP | algorithmic GB | vector G lane-ops | sustained GHz | floor ms = max(FLOP / (2.5 PF x GHz / 2.4), B / 6.3 TB/s, lane-ops / (16384 x GHz)) | bound | measured ms | measured / floor |")
+    print("|---|---|---|---|---|---|---|---|---|")
     tf = tm = 0.0
-    for name, fl, by, ghz in fams:
-        floor = max(fl / (PEAK * ghz / 2.4), by / HBM) * 1e3
+    for fam in fams:
+        name, fl, by, ghz = fam[:4]
+        vi = fam[4] * 64 if len(fam) > 4 else 0.0
+        parts = {"matrix": fl / (PEAK * ghz / 2.4), "hbm": by / HBM, "vector": vi / (VALU_LANES_PER_CLK * ghz * 1e9)}
+        bound = max(parts, key=parts.get)
+        floor = parts[bound] * 1e3
         m = meas.get(name, 0.0)
         tf += floor
         tm += m
         ratio = f"{m / floor:.2f}" if floor > 0.02 else "-"
-        print(f"| {name} | {fl / 1e12:.2f} | {by / 1e9:.2f} | {ghz:.2f} | {floor:.2f} | {m:.2f} | {ratio} |")
-    print(f"| **sum** | | | | **{tf:.1f}** | **{tm:.1f}** | {tm / tf:.2f} |")
+        print(f"| {name} | {fl / 1e12:.2f} | {by / 1e9:.2f} | {vi / 1e9:.1f} | {ghz:.2f} | {floor:.2f} | {bound if floor > 0.02 else '-'} | {m:.2f} | {ratio} |")
+    print(f"| **sum** | | | | | **{tf:.1f}** | | **{tm:.1f}** | {tm / tf:.2f} |")
 
 
 if __name__ == "__main__":
