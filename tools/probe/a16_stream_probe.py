@@ -32,6 +32,10 @@ def run(name, m, n, k, bks, lda, iters=30):
     print(f"{name:28s} lda={lda:5d}  {us:8.1f} us  {2.0 * m * n * k / us / 1e6:7.1f} TFLOP/s")
 
 
+if len(sys.argv) > 1:          # power / clock sampling: one shape for a long time:  a16_stream_probe.py <lda0: 0|1> <iters>
+    z = int(sys.argv[1])
+    run("dgrad fc16 NT 65536x768x3072", M, 768, 3072, False, 0 if z else 3072, iters=int(sys.argv[2]))
+    sys.exit(0)
 for lda_of in (lambda k: k, lambda k: 0):
     run("dgrad fc16 NT 65536x768x3072", M, 768, 3072, False, lda_of(3072))
     run("fwd pr-like NN 65536x768x3072", M, 768, 3072, True, lda_of(3072))
