@@ -103,7 +103,9 @@ int neko_gemm_dgrad_gelu_colsum(const uint16_t* dY, long lda, const uint16_t* W,
  * bwd: dy f32 [M,d]; g_in (may be null) is the residual-stream gradient added to the result;
  *      dx f32 and/or dx16 bf16 (either may be null); dgamma/dbeta f32 [d] (+= when accumulate);
  *      workspace: neko_layernorm_bwd_blocks(M) * 3 * d floats.  drop_thr != 0: dx16 (only) additionally carries the
- *      dropout mask of the residual-dropout site whose Linear consumes it (element index row*d + col).
+ *      dropout mask of the residual-dropout site whose Linear consumes it (element index row*d + col); with dx16 null the
+ *      mask is applied to dx instead (the embedding dropout in front of the first block, trajectory_gpt2.py:707: its backward
+ *      is the last thing the stack's backward does).
  *      dcolsum16 (may be null; needs dx16): f32 [d] += column sums of the dx16 values as stored = the bias gradient of
  *      the Conv1D that consumes dx16 (trajectory_gpt2.py:253,277), folded into this pass.
  * ------------------------------------------------------------------------------------------- */

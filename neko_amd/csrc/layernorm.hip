@@ -167,7 +167,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
         o.z = rs * (dv[i].z - m1 - xh[i].z * m2);
         o.w = rs * (dv[i].w - m1 - xh[i].w * m2);
         if (g_in) { o.x += gv[i].x; o.y += gv[i].y; o.z += gv[i].z; o.w += gv[i].w; }
-        if (dx) reinterpret_cast<float4*>(dx + (long)row * d)[c] = o;
+        if (dx) {
+          float4 of = o;
+          if (!dx16 && drop_thr) {     // no bf16 copy asked for: the mask belongs to the fp32 result (embedding dropout behind layer 0)
+            float e[4] = {o.x, o.y, o.z, o.w};
+            drop4(e, (uint32_t)row * (uint32_t)d + (uint32_t)c * 4u, drop_key, drop_thr, drop_scale);
+            of = make_float4(e[0], e[1], e[2], e[3]);
+          }
+          reinterpret_cast<float4*>(dx + (long)row * d)[c] = of;
+        }
         if (dx16) {
           // the bf16 copy feeds the dgrad/wgrad of the Linear that sits behind a residual dropout: it carries that
           // site's mask (the fp32 residual-stream gradient above does not)

@@ -404,16 +404,16 @@ def stack_backward(P: StackParams, ctx: StackCtx, dhf: torch.Tensor,
                                                       ops.colsum_bf16(dqkv, M, 3 * d, lp.g_b_qkv)), dqkv)
         g0 = torch.empty(M, d, dtype=F32, device=dev)
         g0_16 = torch.empty(M, d, dtype=BF16, device=dev) if i > 0 else None
+        # layer 0 has no bf16 copy to make: its LayerNorm backward applies the EMBEDDING dropout's mask to the fp32 result instead
+        # (the backward of `x = drop(x)` at the top of stack_forward), which used to be a pass of its own over [M, d]
         ops.layernorm_bwd(d_a1, c.x, lp.ln1_w, c.mean1, c.rstd1, lp.g_ln1_w, lp.g_ln1_b, g_in=g1, dx=g0, dx16=g0_16,
-                          drop=dr.resid_mlp[i - 1] if (dr and i > 0) else None,
+                          drop=(dr.resid_mlp[i - 1] if i > 0 else dr.embd) if dr else None,
                           colsum16=P.layers[i - 1].g_b_pr if i > 0 else None)
         g, g16 = g0, g0_16
         if on_layer_done:
             on_layer_done(i)
     SideStream.join(dev)          # every parameter gradient of the stack is ordered before what follows on this stream
-    if dr is not None and dr.embd is not None:
-        g = ops.dropout_f32(g, dr.embd)                       # backward of the embedding dropout: same mask
-    return g
+    return g                      # (already through the embedding dropout's mask: layer 0's LayerNorm backward above)
 
 
 # ------------------------------------------------------------------------------------------------------

@@ -39,7 +39,20 @@ def _opt(m):
     return opt, sch
 
 
-def test_captured_steps_train_like_eager_steps():
+@pytest.mark.parametrize("det", [True, False])
+def test_captured_steps_train_like_eager_steps(det):
+    """det: the embedding-table gradients by sorted sums and the attention backward as its two kernels (what NEKO_DETERMINISTIC=1
+    selects): eager and captured steps are then the same arithmetic in the same order, and the tight gates hold for EVERY step
+    (ADVICE r03); with atomics the trajectories may separate from step 4 on (see below) and only the first steps are gated tightly."""
+    from neko_amd import ops
+    prev_det, ops.SCATTER_DET = ops.SCATTER_DET, bool(det)
+    try:
+        _captured_vs_eager(det)
+    finally:
+        ops.SCATTER_DET = prev_det
+
+
+def _captured_vs_eager(det):
     from neko_amd.training.captured import CapturedTrainStep
     batches = _batches()
     m0 = _policy(0.0)
@@ -73,10 +86,11 @@ def test_captured_steps_train_like_eager_steps():
     # Two EAGER runs of this very recipe are either bit-identical or, from step 4 on, on a second trajectory (relative loss
     # differences 6e-8, 8e-6, 3.3e-4, 5e-5, 1e-7, 4.9e-4 at steps 4..9; tools/trajectory_noise_probe.py, 8 runs: 4 of each) --
     # so the tight gate covers the steps before any run can separate (incl. the first replay) and the loose one the rest.
-    assert torch.allclose(got[:4], ref[:4], rtol=2e-5, atol=0), (got, ref)
-    assert torch.allclose(got, ref, rtol=2e-3, atol=0), (got, ref)
-    assert torch.allclose(gotn[:4], refn[:4], rtol=2e-4, atol=0), (gotn, refn)
-    assert torch.allclose(gotn, refn, rtol=2e-2, atol=0), (gotn, refn)
+    tight = len(batches) if det else 4
+    assert torch.allclose(got[:tight], ref[:tight], rtol=2e-5, atol=0), (got, ref)
+    assert torch.allclose(got, ref, rtol=5e-3, atol=0), (got, ref)
+    assert torch.allclose(gotn[:tight], refn[:tight], rtol=2e-4, atol=0), (gotn, refn)
+    assert torch.allclose(gotn, refn, rtol=3e-2, atol=0), (gotn, refn)
     for (k, a), (_, b2) in zip(m1.state_dict().items(), m0.state_dict().items()):
         # (small tensors whose gradient is rounding noise random-walk under Adam: only the weight matrices are compared)
         if a.dtype == torch.float32 and a.numel() >= 4096:

@@ -92,6 +92,15 @@ def test_gemm_epilogue_and_ln_bwd_masks():
     ops.layernorm_bwd(dy.to(DEV), xd, w.to(DEV), mean, rstd, dg, db, dx=dx, dx16=dx16, drop=d)
     ref16 = (dx.cpu() * mask_flat(M * dd, d).view(M, dd)).to(torch.bfloat16)
     assert torch.equal(dx16.cpu(), ref16)
+    # without a bf16 copy the mask goes onto the fp32 result (layer 0: the embedding dropout's backward, neko_hip.h)
+    dg2 = torch.zeros(dd, device=DEV); db2 = torch.zeros(dd, device=DEV)
+    dxm = torch.empty(M, dd, device=DEV)
+    gin = torch.randn(M, dd, generator=g)
+    ops.layernorm_bwd(dy.to(DEV), xd, w.to(DEV), mean, rstd, dg2, db2, g_in=gin.to(DEV), dx=dxm, drop=d)
+    dxu = torch.empty(M, dd, device=DEV)
+    ops.layernorm_bwd(dy.to(DEV), xd, w.to(DEV), mean, rstd, torch.zeros(dd, device=DEV), torch.zeros(dd, device=DEV), g_in=gin.to(DEV), dx=dxu)
+    assert torch.equal(dxm.cpu(), ops.dropout_f32(dxu, d).cpu())          # what the separate pass produced
+    assert torch.equal(dg2.cpu(), dg.cpu()) and torch.equal(db2.cpu(), db.cpu())     # parameter gradients are not touched by it
 
 
 def same_backward(a, b, d, what=""):
