@@ -134,8 +134,10 @@ int neko_layernorm_bwd_bf16dy(const uint16_t* dy, const float* x, const float* g
  *   bwd workspace: D f32 [B*H*T], qflags int32 [B*ceil(T/64)]; dqkv bf16 [B*T, 3*H*hd] fully written.
  *   hd in {32, 64, 128}.
  *   Two schedules compute the same sums: head-resident kernels (hd = 32, T <= 1024: one workgroup per (b, h) keeps
- *   the head's K/V or Q/dO in LDS) and streaming kernels (any T, hd).  neko_attn_set_path(0) = automatic (default),
- *   (1) = always streaming; returns the previous mode (any other argument only queries).  Process-wide tuning knob.
+ *   the head's K/V or Q/dO in LDS) and streaming kernels (any T, hd).  neko_attn_set_path(0) = automatic (default: the
+ *   head-resident backward in one pass above 256 positions, as two kernels below), (1) = always streaming, (2) / (3) =
+ *   head-resident with the two-kernel (bit-reproducible) / the one-pass backward at every length; returns the previous
+ *   mode (any other argument only queries).  Process-wide tuning knob.
  *   drop_mask (optional, only touched when drop_thr > 0): neko_attn_mask_dwords(B, T, H, hd) uint32 of device memory
  *   (0 = the schedule in use does not exchange masks: pass null).  The forward stores its keep decisions there (scalar
  *   stores of the compares' lane masks) and the backward of the SAME forward call applies them instead of re-hashing

@@ -773,18 +773,19 @@ int bwd_launch(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const f
 
 }  // namespace
 
-// schedule selection: 0 = automatic (head-resident kernels of attention_res.hip when they apply, their backward in one pass), 2 = the same
-// with the two-kernel backward (bit-reproducible: no LDS float atomics), 1 = always the
-// streaming kernels of this file.  A tuning / test knob, not part of the numerics: both schedules compute the same sums.
-static int g_attn_path = [] {              // NEKO_ATTN_PATH=0/1/2 sets the initial mode (A/B runs of whole steps)
+// schedule selection: 0 = automatic (head-resident kernels of attention_res.hip when they apply; their backward in one pass for
+// T > 256, as two kernels below: attention_res.hip), 2 = head-resident with the two-kernel backward at every length (bit-reproducible:
+// no order-dependent dQ sums), 3 = head-resident with the one-pass backward at every length (tests, A/B runs), 1 = always the
+// streaming kernels of this file.  A tuning / test knob, not part of the numerics: all schedules compute the same sums.
+static int g_attn_path = [] {              // NEKO_ATTN_PATH=0..3 sets the initial mode (A/B runs of whole steps)
   const char* e = getenv("NEKO_ATTN_PATH");
   const int v = e ? atoi(e) : 0;
-  return v >= 0 && v <= 2 ? v : 0;
+  return v >= 0 && v <= 3 ? v : 0;
 }();
 int neko_attn_path_mode() { return g_attn_path; }
 int neko_attn_set_path_impl(int mode) {
   const int prev = g_attn_path;
-  if (mode >= 0 && mode <= 2) g_attn_path = mode;
+  if (mode >= 0 && mode <= 3) g_attn_path = mode;
   return prev;
 }
 

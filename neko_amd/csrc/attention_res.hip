@@ -1275,7 +1275,12 @@ int neko_attn_bwd_res_impl(const bf16_t* qkv, const bf16_t* out, const bf16_t* d
                            float drop_scale, const uint32_t* dmask, hipStream_t s, const int* seq_off,
                            const long long* mask_off) {
   if (!D) return NEKO_ERR_ARG;          // f32 [rows * H]: the dQ kernel leaves sum_hd dO.O / s there for the dK/dV kernel
-  if (neko_attn_path_mode() != 2) {     // one pass over S / dP (attn_bwd_fused_res_kernel); path 2 keeps the two bit-reproducible kernels
+  // One pass over S / dP (attn_bwd_fused_res_kernel) or the two kernels below.  Automatic: one pass above 256 positions.  A short head is
+  // one phase of at most 8 key blocks handed to 8 waves from the queue -- triangle sizes 1..8, half the waves idle at the end -- and
+  // the two kernels are ahead: 42.7 vs 73.6 us at T = 128, 96 vs 118 at 256, 224 vs 206 at 384, 334 vs 285 at 512 (B = 64, 24 heads,
+  // dropout 0.1); README-size steps (T = 240): c2 5.90 -> 5.75 ms, c3 5.95 -> 5.85; T = 494 (c4) stays with one pass (11.29 vs 11.56).
+  const int pm = neko_attn_path_mode();
+  if (pm == 3 || (pm != 2 && T > 256)) {
     const int Tp = (T + 31) & ~31, Rmax = min(Tp, FUSED_Q);
     const size_t lds = (size_t)Rmax * (128 + 128 + 8) + FUSED_W * 2048 + 16 + 64;
     const float scale = 1.0f / sqrtf(32.0f);

@@ -109,7 +109,7 @@ def same_backward(a, b, d, what=""):
     and adds dQ up block by block in the order its waves arrive: equal to fp32 rounding before the bf16 store."""
     from neko_amd import ops
     mode = ops.attn_set_path(-1)                    # -1 is not a mode: the call only reports the current one
-    if mode != 0 or a.shape[1] != 3 * d:
+    if mode not in (0, 3) or a.shape[1] != 3 * d:
         assert torch.equal(a, b), (what, float((a.float() - b.float()).abs().max()))
         return
     assert torch.equal(a[:, d:], b[:, d:]), (what, "dK / dV", float((a[:, d:].float() - b[:, d:].float()).abs().max()))
@@ -117,13 +117,13 @@ def same_backward(a, b, d, what=""):
     assert float((dq_a - dq_b).abs().max()) <= 2 ** -7 * float(dq_b.abs().max()), (what, "dQ")
 
 
-@pytest.mark.parametrize("path", ["auto", "split", "streaming"])
+@pytest.mark.parametrize("path", ["auto", "onepass", "split", "streaming"])
 @pytest.mark.parametrize("B,T,H,hd", [(2, 96, 2, 32), (1, 200, 2, 64), (2, 301, 3, 32), (1, 520, 2, 128), (2, 1024, 1, 128), (1, 777, 2, 64)])
 def test_attention_dropout_fwd_bwd(B, T, H, hd, path):
     from neko_amd import ops
-    if path == "split" and hd != 32:
+    if path in ("split", "onepass") and hd != 32:
         pytest.skip("the split / one-pass choice only exists for the head-resident kernels (hd = 32)")
-    prev = ops.attn_set_path({"auto": 0, "split": 2, "streaming": 1}[path])
+    prev = ops.attn_set_path({"auto": 0, "onepass": 3, "split": 2, "streaming": 1}[path])
     try:
         _attention_dropout_case(ops, B, T, H, hd)
     finally:
@@ -159,7 +159,7 @@ def _attention_dropout_case(ops, B, T, H, hd):
         assert hd != 32 or ops.attn_set_path(-1) == 1
 
 
-@pytest.mark.parametrize("path", [0, 2], ids=["one-pass", "two-kernel"])
+@pytest.mark.parametrize("path", [3, 2], ids=["one-pass", "two-kernel"])
 @pytest.mark.parametrize("B,T,H,pad", [(2, 1024, 3, 0), (3, 1000, 2, 77), (2, 33, 2, 5), (1, 512, 4, 0)])
 def test_attention_backward_with_stored_keep_masks_is_bit_identical(B, T, H, pad, path):
     """The forward's compares (hash byte >= threshold) are stored as 64-bit lane masks by scalar stores and applied by

@@ -400,11 +400,12 @@ def _masks(B, T, kind):
     return m
 
 
-@pytest.fixture(params=["auto", "split", "streaming"])
+@pytest.fixture(params=["auto", "onepass", "split", "streaming"])
 def attn_path(request, ops):
-    """Every attention schedule against the oracle: head-resident for hd = 32 / T <= 1024 with the backward in ONE pass (auto),
-    the same with the two-kernel backward (split: neko_attn_set_path(2), the bit-reproducible form), streaming for everything."""
-    prev = ops.attn_set_path({"auto": 0, "split": 2, "streaming": 1}[request.param])
+    """Every attention schedule against the oracle: head-resident for hd = 32 / T <= 1024 with the library's own choice of backward
+    (auto: one pass above 256 positions), with the backward in ONE pass at every length (onepass: neko_attn_set_path(3)), with the
+    two-kernel backward (split: neko_attn_set_path(2), the bit-reproducible form), streaming for everything."""
+    prev = ops.attn_set_path({"auto": 0, "onepass": 3, "split": 2, "streaming": 1}[request.param])
     yield request.param
     ops.attn_set_path(prev)
 
@@ -416,7 +417,7 @@ def attn_path(request, ops):
 def test_attention_fwd_bwd(ops, attn_path, B, T, H, hd, mask_kind):
     if attn_path == "streaming" and hd == 32 and T >= 1000 and mask_kind in ("right", "holes"):
         pytest.skip("large streaming cases are covered by the 'none' and 'left' masks")
-    if attn_path == "split" and hd != 32:
+    if attn_path in ("split", "onepass") and hd != 32:
         pytest.skip("the split / one-pass choice only exists for the head-resident kernels (hd = 32)")
     if T < 16 and mask_kind != "none":
         pytest.skip("mask pattern needs T >= 16")
