@@ -425,8 +425,15 @@ def main():
         # number is the committed rocprofv3 --pmc measurement of the same call (tools/pmc_lmhead.sh), null if absent
         traffic, traffic_src = None, None
         import glob
-        for tp in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_lmhead_traffic.json")), reverse=True):    # newest round first
+        # only files named exactly r<NN>_lmhead_traffic.json count (the measurement of the SHIPPED kernel, written by tools/pmc_lmhead.sh +
+        # tools/pmc_lmhead_summarise.py for the final code of a round); probe builds keep other names.  Newest round first.
+        import re as _re
+        cands = [tp for tp in glob.glob(os.path.join(ROOT, "profiles", "r*_lmhead_traffic.json"))
+                 if _re.fullmatch(r"r\d+_lmhead_traffic\.json", os.path.basename(tp))]
+        for tp in sorted(cands, key=lambda tp: int(_re.match(r"r(\d+)_", os.path.basename(tp)).group(1)), reverse=True):
             tj = json.load(open(tp))
+            if tj.get("build", "default") != "default":
+                continue
             if tj.get("shape_MNK") == dom["shape"]:
                 traffic = tj["traffic_bytes_per_launch"]
                 traffic_src = f"profiles/{os.path.basename(tp)} (committed rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE pass of this call, calibrated; not re-measured in this run)"

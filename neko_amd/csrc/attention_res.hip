@@ -16,6 +16,7 @@
 //     (the K^T / V^T / Q^T / dO^T operands), so no transposed copy is built.
 //   * workgroup ids are paired so that heads 2j and 2j+1 of one batch row (the two halves of every 128-byte line of
 //     the [B*T, 3d] qkv matrix) run on the same XCD.
+#include <atomic>
 #include "neko_kernels.h"
 
 extern int neko_attn_path_mode();
@@ -1232,6 +1233,21 @@ int allow_lds(K kernel, size_t bytes) {
              ? NEKO_OK
              : NEKO_ERR_LAUNCH;
 }
+// The > 64 KiB dynamic-LDS limit is a per-DEVICE attribute of a kernel (a process-wide `static const int once` left every
+// device but the first without it): one bit per device ordinal, set after fn() -- the allow_lds calls of one kernel family -- succeeded
+// on the current device.  Setting it twice from two threads is harmless.
+typedef std::atomic<unsigned long long> LdsLimitDone;
+template <class Fn>
+int lds_limit_once_per_device(LdsLimitDone& done, Fn&& fn) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return NEKO_ERR_LAUNCH;
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (done.load(std::memory_order_acquire) & bit) return NEKO_OK;
+  const int rc = fn();
+  if (rc != NEKO_OK) return rc;
+  done.fetch_or(bit, std::memory_order_release);
+  return NEKO_OK;
+}
 
 }  // namespace
 
@@ -1252,8 +1268,11 @@ int neko_attn_fwd_res_impl(const bf16_t* qkv, const float* kbias, const int* kst
   const size_t lds = (size_t)Tp * 128 + (size_t)Tp * 4 + 16;
   const float scale = 1.0f / sqrtf(32.0f);
   const int T4 = (T + 3) >> 2;
-  static const int once = allow_lds(attn_fwd_res_kernel<true, true>, 160 * 1024) | allow_lds(attn_fwd_res_kernel<true, false>, 160 * 1024) |
-                          allow_lds(attn_fwd_res_kernel<false, false>, 160 * 1024);
+  static LdsLimitDone done_fwd;
+  const int once = lds_limit_once_per_device(done_fwd, [] {
+    return allow_lds(attn_fwd_res_kernel<true, true>, 160 * 1024) | allow_lds(attn_fwd_res_kernel<true, false>, 160 * 1024) |
+           allow_lds(attn_fwd_res_kernel<false, false>, 160 * 1024);
+  });
   if (once != NEKO_OK) return once;
   if (drop_thr && dmask)
     hipLaunchKernelGGL((attn_fwd_res_kernel<true, true>), dim3(B * H), dim3(64 * nw), lds, s, qkv, kbias, kstart, out, lse, B, T,
@@ -1285,8 +1304,11 @@ int neko_attn_bwd_res_impl(const bf16_t* qkv, const bf16_t* out, const bf16_t* d
     const size_t lds = (size_t)Rmax * (128 + 128 + 8) + FUSED_W * 2048 + 16 + 64;
     const float scale = 1.0f / sqrtf(32.0f);
     const int T4 = (T + 3) >> 2;
-    static const int once_f = allow_lds(attn_bwd_fused_res_kernel<true, true>, 160 * 1024) | allow_lds(attn_bwd_fused_res_kernel<true, false>, 160 * 1024) |
-                              allow_lds(attn_bwd_fused_res_kernel<false, false>, 160 * 1024);
+    static LdsLimitDone done_fused;
+    const int once_f = lds_limit_once_per_device(done_fused, [] {
+      return allow_lds(attn_bwd_fused_res_kernel<true, true>, 160 * 1024) | allow_lds(attn_bwd_fused_res_kernel<true, false>, 160 * 1024) |
+             allow_lds(attn_bwd_fused_res_kernel<false, false>, 160 * 1024);
+    });
     if (once_f != NEKO_OK) return once_f;
 #define NEKO_BWD_FUSED(DROPV, MASKV, THR, MP)                                                                                       \
     hipLaunchKernelGGL((attn_bwd_fused_res_kernel<DROPV, MASKV>), dim3(B * H), dim3(FUSED_W * 64), lds, s, qkv, out, dout, kbias, kstart, lse, \
@@ -1302,9 +1324,12 @@ int neko_attn_bwd_res_impl(const bf16_t* qkv, const bf16_t* out, const bf16_t* d
   const size_t lds_q = (size_t)Tp * 128 + (size_t)Tp * 4 + 16, lds_kv = (size_t)Tp * 128 + (size_t)Tp * 8 + 16;
   const float scale = 1.0f / sqrtf(32.0f);
   const int T4 = (T + 3) >> 2;
-  static const int once = allow_lds(attn_dq_res_kernel<true, true>, 160 * 1024) | allow_lds(attn_dq_res_kernel<true, false>, 160 * 1024) |
-                          allow_lds(attn_dq_res_kernel<false, false>, 160 * 1024) | allow_lds(attn_dkv_res_kernel<true, true>, 160 * 1024) |
-                          allow_lds(attn_dkv_res_kernel<true, false>, 160 * 1024) | allow_lds(attn_dkv_res_kernel<false, false>, 160 * 1024);
+  static LdsLimitDone done_bwd;
+  const int once = lds_limit_once_per_device(done_bwd, [] {
+    return allow_lds(attn_dq_res_kernel<true, true>, 160 * 1024) | allow_lds(attn_dq_res_kernel<true, false>, 160 * 1024) |
+           allow_lds(attn_dq_res_kernel<false, false>, 160 * 1024) | allow_lds(attn_dkv_res_kernel<true, true>, 160 * 1024) |
+           allow_lds(attn_dkv_res_kernel<true, false>, 160 * 1024) | allow_lds(attn_dkv_res_kernel<false, false>, 160 * 1024);
+  });
   if (once != NEKO_OK) return once;
 #define NEKO_BWD_RES(DROPV, MASKV, THR, MP)                                                                                       \
   do {                                                                                                                            \

@@ -39,7 +39,18 @@ extern "C" int neko_gemm_diag_trace(void* buf) {
 #define NEKO_TRACE(slot) do { } while (0)
 #endif
 
+// Per-CU output-phase lock (round 5): two co-resident workgroups of a CU may not be in their output phase (epilogue arithmetic +
+// stores) at the same time, so one's output phase falls under the other's main loop instead of both idling the matrix pipe together.
+// Indexed by the hardware CU id (XCC id, shader engine, shader array, CU); only timing depends on it, never results.
+__device__ unsigned g_neko_cu_lock[4096 * 16];
+
 namespace {
+
+__device__ __forceinline__ unsigned* cu_lock_ptr() {
+  const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);        // HW_REG_HW_ID: cu_id [11:8], sh_id [12], se_id [15:13]
+  const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);       // HW_REG_XCC_ID [3:0]
+  return &g_neko_cu_lock[((((hw >> 8) & 0xffu) | ((xcc & 0xfu) << 8)) & 4095u) * 16u];
+}
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void glb_cvoid;
@@ -591,8 +602,21 @@ __global__ __launch_bounds__(C::NT, C::WAVES_PER_SIMD) void gemm_glds_kernel(Gem
   NEKO_TRACE(3);
   return;
 #endif
-  if (try_epilogue_fast<C>(p, ParkAcc32<C>{acc}, smem, m0, n0, wm, wn, wave, lane, slice)) return;
-  epilogue<C>(p, acc, smem, m0, n0, wm, wn, wave, lane, slice);
+  unsigned* lock = nullptr;
+  if (p.epi_lock) {
+    lock = cu_lock_ptr();
+    if (tid == 0) {
+      while (atomicCAS(lock, 0u, 1u) != 0u) __builtin_amdgcn_s_sleep(16);
+    }
+    __syncthreads();
+  }
+  if (!try_epilogue_fast<C>(p, ParkAcc32<C>{acc}, smem, m0, n0, wm, wn, wave, lane, slice))
+    epilogue<C>(p, acc, smem, m0, n0, wm, wn, wave, lane, slice);
+  if (p.epi_lock) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) atomicExch(lock, 0u);
+  }
 }
 
 // 128x128: 4 waves x (64x64), 3 blocks/CU (3-stage) or 2 (4-stage)      -- short K / ragged or small outputs
@@ -754,6 +778,8 @@ int group_m_for(const GemmArgs& a) {
 int neko_gemm_glds_try(const GemmArgs& a_in, int a_kstrided, int b_kstrided, hipStream_t s) {
   GemmArgs a = a_in;
   a.group_m = group_m_for(a);
+  static const int env_lock = [] { const char* e = getenv("NEKO_GEMM_EPILOCK"); return e ? atoi(e) : 0; }();
+  a.epi_lock = env_lock;
   t_colsum_bands = 0;
   if (a.K % 64) return 1;
   if (a.splitk > 1 && (a.k_per_split % 64)) return 1;

@@ -31,6 +31,7 @@ struct GemmArgs {
   float* colsum_ws;       // optional: per-(32*TM)-row-band column sums of the result (before bf16 rounding), f32 [bands, N];
                           // written only when the launch can fold them (gemm_glds.hip), see neko_gemm_glds_colsum_bands()
   int group_m;            // row panels per rasterisation group (tile_coords); 0 = the compiled default.  Set by neko_gemm_glds_try
+  int epi_lock;           // 1: the output phase runs under the CU's lock (gemm_glds.hip, co-resident workgroups).  Set by neko_gemm_glds_try
 };
 
 int neko_gemm_bf16_impl(GemmArgs a, int a_kstrided, int b_kstrided, int safe_transpose, hipStream_t s);

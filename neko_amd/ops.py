@@ -246,6 +246,7 @@ class VarlenGeom:
             nb = (t + 31) // 32
             moff.append(moff[-1] + self.H * nb * nb * 32)
         self.rows, self.mask_dwords = off[-1], moff[-1]
+        self.pinned_by_capture = False
         pin = torch.device(device).type == "cuda"
         self._host_off = torch.tensor(off, dtype=torch.int32)
         self._host_moff = torch.tensor(moff[:-1], dtype=torch.int64)
@@ -260,8 +261,15 @@ class VarlenGeom:
         g = cls._cache.get(key)
         if g is None:
             if len(cls._cache) >= cls._CACHE_MAX:
-                cls._cache.pop(next(iter(cls._cache)))
+                # evict the oldest geometry that no captured graph points at (a HIP graph bakes seq_off / mask_off and,
+                # when the geometry was built inside the capture, the pinned sources of their uploads into its nodes)
+                for k, old in cls._cache.items():
+                    if not old.pinned_by_capture:
+                        del cls._cache[k]
+                        break
             g = cls._cache[key] = cls(lengths, H, device)
+        if not g.pinned_by_capture and torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            g.pinned_by_capture = True           # used (or built) while a step is being captured: lives as long as the process
         return g
 
 
@@ -477,7 +485,9 @@ def set_drop_salt(salt: Optional[torch.Tensor]) -> None:
     _salt_holder[0] = salt
 
 
-def patch_resblock_fwd(images, w1, b1, gw, gb, w2, b2, mid, groups, want_x=True):
+def patch_resblock_fwd(images, w1, b1, gw, gb, w2, b2, mid, groups, want_x=True, want_padded=False):
+    """-> (y16 [P, 768] bf16, x_patches [P, 768] fp32 | None), plus with `want_padded` the zero-padded storage y16 is the row prefix of
+    ([Ppad, 768], Ppad a multiple of 128): the weight gradient of the projection contracts over ITS rows."""
     assert images.is_cuda and images.dim() == 4 and images.shape[1] == 3
     assert images.dtype in (torch.float32, torch.uint8)
     images = images.contiguous()
@@ -495,6 +505,8 @@ def patch_resblock_fwd(images, w1, b1, gw, gb, w2, b2, mid, groups, want_x=True)
     xp = torch.empty(P, 768, dtype=torch.float32, device=images.device) if want_x else None
     _lib.call("neko_patch_resblock_fwd", _p(images), int(images.dtype == torch.uint8), n, H, W, _p(w1), _p(b1),
               _p(gw), _p(gb), _p(w2), _p(b2), mid, groups, _p(y16), _p(xp), _stream())
+    if want_padded:
+        return y16, xp, y16_all
     return y16, xp
 
 

@@ -72,10 +72,10 @@ class _ImageEmbedFn(torch.autograd.Function):
         f.ensure_shadow()
         pe = pre + "patch_embedding."
         w = lambda n: f.view(n)
-        y16, xp = ops.patch_resblock_fwd(images, w(pe + "conv1.weight"), w(pe + "conv1.bias"), w(pe + "gn2.weight"),
-                                         w(pe + "gn2.bias"), w(pe + "conv2.weight"), w(pe + "conv2.bias"),
-                                         mod.patch_embedding.mid_channels, mod.patch_embedding.num_groups,
-                                         want_x=need)
+        y16, xp, y16_all = ops.patch_resblock_fwd(images, w(pe + "conv1.weight"), w(pe + "conv1.bias"), w(pe + "gn2.weight"),
+                                                  w(pe + "gn2.bias"), w(pe + "conv2.weight"), w(pe + "conv2.bias"),
+                                                  mod.patch_embedding.mid_channels, mod.patch_embedding.num_groups,
+                                                  want_x=need, want_padded=True)
         P = y16.shape[0]
         d = mod.embed_dim
         out = torch.empty(P, d, dtype=torch.float32, device=y16.device)
@@ -84,7 +84,7 @@ class _ImageEmbedFn(torch.autograd.Function):
         if mod.use_pos_encoding:
             ops.patch_pos_add(out, hpos, wpos, f.view(pre + "patch_pos_encoding.height_pos_embedding.weight"),
                               f.view(pre + "patch_pos_encoding.width_pos_embedding.weight"))
-        ctx.mod, ctx.y16, ctx.xp, ctx.hpos, ctx.wpos = mod, y16, xp, hpos, wpos
+        ctx.mod, ctx.y16_all, ctx.xp, ctx.hpos, ctx.wpos = mod, y16_all, xp, hpos, wpos
         return out
 
     @staticmethod
@@ -99,8 +99,9 @@ class _ImageEmbedFn(torch.autograd.Function):
             ops.patch_pos_add_bwd(g, ctx.hpos, ctx.wpos, f.gview(pre + "patch_pos_encoding.height_pos_embedding.weight"),
                                   f.gview(pre + "patch_pos_encoding.width_pos_embedding.weight"))
         # rows P .. Ppad of both operands of the weight gradient are zero (ops.patch_resblock_fwd pads y16's storage the same way)
-        y16_all = ctx.y16._base if ctx.y16._base is not None else ctx.y16      # the zero-padded storage y16 is a row prefix of
+        y16_all = ctx.y16_all                       # the zero-padded storage the forward's y16 is a row prefix of
         Ppad = y16_all.shape[0]
+        assert y16_all.shape == (Ppad, 768) and Ppad % 128 == 0 and Ppad >= P
         g16_all = torch.empty(Ppad, d, dtype=torch.bfloat16, device=g.device)
         if Ppad > P:
             g16_all[P:].zero_()

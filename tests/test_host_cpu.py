@@ -461,3 +461,17 @@ def test_host_stager_rings_are_keyed_by_capacity_and_capped(monkeypatch):
     big = torch.zeros(200000, dtype=torch.float32)    # 1 MiB class: the idle small rings are dropped to make room
     assert torch.equal(st.upload(big, "cpu"), big)
     assert st._bytes <= (1 << 20) + 262144 * 4
+
+
+def test_varlen_geometry_cache_never_evicts_what_a_captured_graph_points_at(monkeypatch):
+    """a HIP graph bakes a geometry's seq_off / mask_off pointers; eviction must skip geometries used under capture."""
+    from neko_amd import ops
+    monkeypatch.setattr(ops.VarlenGeom, "_cache", {})
+    monkeypatch.setattr(ops.VarlenGeom, "_CACHE_MAX", 4)
+    g0 = ops.VarlenGeom.get([5, 7], 2, "cpu")
+    g0.pinned_by_capture = True                      # what get() sets while torch.cuda.is_current_stream_capturing()
+    for n in range(3, 12):
+        ops.VarlenGeom.get([n, n + 1], 2, "cpu")
+    assert len(ops.VarlenGeom._cache) <= 4
+    assert ops.VarlenGeom.get([5, 7], 2, "cpu") is g0
+    assert g0.seq_off.tolist() == [0, 5, 12] and g0.rows == 12

@@ -80,7 +80,7 @@ def test_gemm_pipelined_loop_short_and_long_k(ops, layout, K):
     M, N = 2048, 2304
     A = rb(torch.randn(M, K, generator=g)); Bm = rb(torch.randn(K, N, generator=g) * 0.2)
     ref = A @ Bm
-    a_ks, b_ks = layout == "tn", layout in ("nn", "tn")
+    a_ks, b_ks = layout in ("tn", "tt"), layout in ("nn", "tn")       # "tt": A k-strided, B k-contiguous (the fourth generated stream)
     A_dev = bf(A.t()) if a_ks else bf(A)
     B_dev = bf(Bm) if b_ks else bf(Bm.t())
     out = torch.full((M, N), float("nan"), device=DEV)
@@ -99,7 +99,7 @@ def a16(ops):
     ops.gemm_set_mainloop(prev)
 
 
-@pytest.mark.parametrize("layout", ["nt", "nn", "tn"])
+@pytest.mark.parametrize("layout", ["nt", "nn", "tn", "tt"])
 @pytest.mark.parametrize("M,N,K", [(256, 256, 128), (512, 768, 384), (1024, 512, 3072), (256, 1024, 8192)])
 def test_gemm_a16_main_loop_layouts(a16, layout, M, N, K):
     """gemm_a16.hip (4 waves x 128 x 128 on 16x16x32 MFMAs, accumulators in AGPRs, hand-placed instruction stream): one loop
