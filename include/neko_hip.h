@@ -36,7 +36,7 @@ extern "C" {
 #define NEKO_ERR_UNSUPPORTED (-2)
 #define NEKO_ERR_LAUNCH (-3)
 
-#define NEKO_ABI_VERSION 16
+#define NEKO_ABI_VERSION 17
 
 int neko_abi_version(void);
 /* human-readable text for a return code (static storage) */
@@ -116,6 +116,14 @@ int neko_layernorm_bwd(const float* dy, const float* x, const float* gamma, cons
                        const float* g_in, float* dx, uint16_t* dx16, float* dgamma, float* dbeta, int accumulate,
                        float* workspace, int M, int d, int drop_thr, unsigned drop_key, float drop_scale,
                        float* dcolsum16, void* stream);
+/* same with the gradient given for SOME rows only (ABI v17): dy_rows f32 [n, d] compact, dy_row_map int32 [M] = index of row r's
+ * gradient in dy_rows, or -1 where it is zero.  The LM head returns gradient rows for the loss positions only (the reference's
+ * boolean-mask gather, gato/policy/gato_policy.py:183-185, differentiated); ln_f's backward reads them in place instead of a
+ * zero-filled [M, d] expansion. */
+int neko_layernorm_bwd_rows(const float* dy_rows, const int* dy_row_map, const float* x, const float* gamma, const float* mean,
+                            const float* rstd, const float* g_in, float* dx, uint16_t* dx16, float* dgamma, float* dbeta,
+                            int accumulate, float* workspace, int M, int d, int drop_thr, unsigned drop_key, float drop_scale,
+                            float* dcolsum16, void* stream);
 /* same with dy as bf16 [M,d] (the dgrad GEMM's bf16 output, as autocast leaves it in the reference: the gradient of a
  * bf16 addmm input is bf16, trajectory_gpt2.py:274-277): half the bytes written by the GEMM and read here */
 int neko_layernorm_bwd_bf16dy(const uint16_t* dy, const float* x, const float* gamma, const float* mean,
@@ -293,6 +301,16 @@ int neko_patch_resblock_bwd(const float* x_patches, const float* dy, int P, cons
                             const float* gn_w, const float* gn_b, const float* w2, const float* b2,
                             int mid_channels, int num_groups, float* dw1, float* db1, float* dgn_w, float* dgn_b,
                             float* dw2, float* db2, float* workspace, void* stream);
+/* ABI v17: the forward also leaves the GroupNorm statistics of every patch (gn_stats f32 [P, 64]: mean[32] | rstd[32] per group) and
+ * the backward takes them instead of recomputing them (same values: the recomputation repeats the forward's arithmetic) */
+int neko_patch_resblock_fwd_stats(const void* images, int images_are_u8, int n, int H, int W, const float* w1,
+                                  const float* b1, const float* gn_w, const float* gn_b, const float* w2,
+                                  const float* b2, int mid_channels, int num_groups, uint16_t* y16, float* x_patches,
+                                  float* gn_stats, void* stream);
+int neko_patch_resblock_bwd_stats(const float* x_patches, const float* gn_stats, const float* dy, int P, const float* w1,
+                                  const float* b1, const float* gn_w, const float* gn_b, const float* w2, const float* b2,
+                                  int mid_channels, int num_groups, float* dw1, float* db1, float* dgn_w, float* dgn_b,
+                                  float* dw2, float* db2, float* workspace, void* stream);
 /* workspace floats the backward needs for P patches (per-block partial gradient rows, reduced in fixed order) */
 int neko_patch_resblock_bwd_ws_floats(int P);
 int neko_patch_pos_add(float* out, const int* hpos, const int* wpos, const float* row_emb, const float* col_emb,

@@ -25,6 +25,7 @@ SIGNATURES = {
     "neko_layernorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp],
     "neko_layernorm_bwd_blocks": [_i],
     "neko_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, C.c_uint, _f, _vp, _vp],
+    "neko_layernorm_bwd_rows": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, C.c_uint, _f, _vp, _vp],
     "neko_layernorm_bwd_bf16dy": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, C.c_uint, _f, _vp, _vp],
     "neko_mask_bias": [_vp, _vp, _vp, _i, _i, _vp],
     "neko_attn_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, C.c_uint, _f, _vp, _vp],
@@ -56,6 +57,9 @@ SIGNATURES = {
     "neko_patch_resblock_fwd": [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp],
     "neko_patch_resblock_bwd": [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
                                 _vp, _vp],
+    "neko_patch_resblock_fwd_stats": [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp],
+    "neko_patch_resblock_bwd_stats": [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
+                                      _vp, _vp],
     "neko_patch_resblock_bwd_ws_floats": [_i],
     "neko_patch_pos_add": [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "neko_patch_pos_add_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp],

@@ -23,6 +23,7 @@ using CA16 = Cfg<2, 2, 4, 4, 4>;      // 2 x 2 waves, 128 x 128 per wave, 4-stag
 typedef float f32x32 __attribute__((ext_vector_type(32)));
 
 struct ParkAgpr16 {
+  static constexpr int PREFETCH = 0;
   f32x32 (&acc)[8];
   template <int I>
   __device__ __forceinline__ void park(float* slab, int lane) const {
@@ -150,15 +151,18 @@ int launch_a16(const GemmArgs& a, hipStream_t s) {
 
 }  // namespace
 
+// -1: per-shape choice, 0: neither hand-placed loop, 1: gemm_a16.hip wherever it applies (never gemm_b16.hip), 2: gemm_b16.hip wherever
+// it applies (then the per-shape choice)
 int neko_gemm_set_mainloop_impl(int mode) {
   const int prev = g_mainloop_mode;
-  g_mainloop_mode = mode < 0 ? -1 : (mode ? 1 : 0);
+  g_mainloop_mode = mode < 0 ? -1 : (mode > 2 ? 1 : mode);
   return prev;
 }
+int neko_gemm_mainloop_mode() { return g_mainloop_mode; }
 
 // 1 = not applicable (the caller runs gemm_glds.hip's loop), otherwise a status code
 int neko_gemm_a16_try(const GemmArgs& a, int a_kstrided, int b_kstrided, hipStream_t s) {
-  const int mode = g_mainloop_mode >= 0 ? g_mainloop_mode : env_mode();
+  const int mode = g_mainloop_mode == 2 ? env_mode() : (g_mainloop_mode >= 0 ? g_mainloop_mode : env_mode());
   if (mode == 0) return 1;
   if ((a.M & 255) || (a.N & 255)) return 1;
   const int klen = a.splitk > 1 ? a.k_per_split : a.K;

@@ -91,6 +91,7 @@ __device__ __forceinline__ void static_for(Fn&& fn) {
 // its columns 8q + 4(l>>5) + 0..3 in acc[4q .. 4q+3] -- four consecutive columns per register quad, one ds_write_b128.
 template <class C>
 struct ParkAcc32 {
+  static constexpr int PREFETCH = 0;       // 0: a whole 32-row pass of epilogue inputs in flight
   f32x16 (&acc)[C::TM][C::TN];
   template <int I>
   __device__ __forceinline__ void park(float* slab, int lane) const {
@@ -139,7 +140,13 @@ __device__ __forceinline__ void epilogue_fast(const GemmArgs& p, const Park& par
     // every global INPUT of this pass (GELU' argument, residual, accumulate target) is fetched up front: inside the step
     // loop each load would sit behind the previous step's stores (possible aliasing) and cost a full HBM round trip,
     // 32 of them per tile (the dgrad through the MLP projection spent half its time there)
-    constexpr int NST = 32 / RPI;
+    // (a park policy may bound the prefetch depth -- Park::PREFETCH steps at a time -- when the wave has 128 instead of 256 VGPRs:
+    // gemm_b16.hip's 16 steps x float4 of residual would spill)
+    constexpr int NST_ALL = 32 / RPI;
+    constexpr int NST = (Park::PREFETCH > 0 && Park::PREFETCH < NST_ALL) ? Park::PREFETCH : NST_ALL;
+    static_assert(NST_ALL % NST == 0, "prefetch depth must divide the steps of a pass");
+#pragma unroll
+    for (int ch = 0; ch < NST_ALL / NST; ++ch) {
     uint2 pre_act[(F & F_GELUBWD) ? NST : 1];
     float4 pre_res[(F & F_RESID) ? NST : 1];
     float4 pre_acc[(F & F_ACCUM) ? NST : 1];
@@ -152,7 +159,7 @@ __device__ __forceinline__ void epilogue_fast(const GemmArgs& p, const Park& par
     // same-wave LDS write -> read: ordered by the LDS queue, no barrier (a slab is private to its wave)
 #pragma unroll
     for (int st = 0; st < NST; ++st) {
-      const float4 a4 = *reinterpret_cast<const float4*>(rbase + st * RPI * SWP);
+      const float4 a4 = *reinterpret_cast<const float4*>(rbase + (ch * NST + st) * RPI * SWP);
       float v[4] = {a4.x, a4.y, a4.z, a4.w};
       if (F & F_ALPHA) {
 #pragma unroll
@@ -222,9 +229,10 @@ __device__ __forceinline__ void epilogue_fast(const GemmArgs& p, const Park& par
       if (F & F_PRE) ppre += spre;
       if (F & F_DROP) didx += sdrop;
     }
-    // the inputs were indexed from the pass base: advance them by the whole pass (32 rows)
+    // the inputs were indexed from the chunk base: advance them by the chunk (NST * RPI rows; the whole pass when NST == NST_ALL)
     if (F & F_GELUBWD) pact += (long)NST * sact;
     if (F & F_RESID) pres += (long)NST * sres;
+    }   // prefetch chunks
   });
   if (F & F_COLSUM) {
     // lanes that share a column chunk differ in lane / CPR: fold them in a fixed order, then one row of the band table per

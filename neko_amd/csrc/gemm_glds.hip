@@ -768,9 +768,11 @@ int group_m_for(const GemmArgs& a) {
   static const int env_n = [] { const char* e = getenv("NEKO_GEMM_GM_NARROW"); return e ? atoi(e) : 2; }();
   static const int env_w = [] { const char* e = getenv("NEKO_GEMM_GM_WIDE"); return e ? atoi(e) : 2; }();
   static const int env_s = [] { const char* e = getenv("NEKO_GEMM_GM_SPLITK"); return e ? atoi(e) : 2; }();
+  static const int env_h = [] { const char* e = getenv("NEKO_GEMM_GM_HUGE"); return e ? atoi(e) : 2; }();
   const int nbn = (a.N + 255) / 256;
   if (a.splitk > 1) return env_s;
   if (nbn <= 4) return env_n;
+  if (nbn > 64) return env_h;          // LM-head logits (205 column panels): its own class since round 5
   return env_w;
 }
 }  // namespace
@@ -793,6 +795,14 @@ int neko_gemm_glds_try(const GemmArgs& a_in, int a_kstrided, int b_kstrided, hip
   if (a.bias && (reinterpret_cast<uintptr_t>(a.bias) & 15)) return 1;
   if (a.act_in && ((reinterpret_cast<uintptr_t>(a.act_in) & 7) || (a.ldact & 3))) return 1;
   if (a.pre_out && ((reinterpret_cast<uintptr_t>(a.pre_out) & 7) || (a.ldpre & 3))) return 1;
+  {                         // two workgroups per CU, hand-placed 64 x 128 wave tiles (gemm_b16.hip), where it applies
+    int bands = 0;
+    const int rc = neko_gemm_b16_try(a, a_kstrided, b_kstrided, neko_gemm_mainloop_mode(), &bands, s);
+    if (rc != 1) {
+      t_colsum_bands = bands;
+      return rc;
+    }
+  }
   {                         // hand-placed long-contraction main loop (gemm_a16.hip), where it applies
     const int rc = neko_gemm_a16_try(a, a_kstrided, b_kstrided, s);
     if (rc != 1) return rc;

@@ -76,8 +76,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // DY16: dy arrives as bf16 (the dgrad GEMM's output as the reference's autocast produces it: the gradient of a bf16
 // addmm input is bf16, trajectory_gpt2.py:274-277 under train.py:33-40) -- 2 instead of 4 bytes per element read here
 // and written by the GEMM.
-template <int NV, bool DY16>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy_any, const float* __restrict__ x,
+// MAP: dy holds only SOME rows, dy_map[row] = index of row's gradient in dy or -1 (that row's gradient is zero): the LM head hands
+// back gradient rows of the loss positions only (gato_policy.py:183-185), and expanding them into a zero [M, d] buffer first cost a
+// 201 MB fill, a scatter and 130 MB of zeros read here at 65536 rows.
+template <int NV, bool DY16, bool MAP = false>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy_any, const int* __restrict__ dy_map, const float* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const float* __restrict__ g_in,
                                                      float* __restrict__ dx, bf16_t* __restrict__ dx16,
@@ -108,12 +111,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
   const int stride = gridDim.x * 4;
   float4 nx[NV], nd[NV], ng[NV];
   float nmu = 0.f, nrs = 0.f;
-  auto fetch = [&](int row) {
+  auto fetch = [&](int row, int src) {
     nmu = mean[row];
     nrs = rstd[row];
+    const bool have = !MAP || src >= 0;           // wave-uniform
+    if (MAP && !have) src = 0;
     const float4* xr = reinterpret_cast<const float4*>(x + (long)row * d);
-    const float4* dr = reinterpret_cast<const float4*>(static_cast<const float*>(dy_any) + (long)row * d);
-    const uint2* dr16 = reinterpret_cast<const uint2*>(static_cast<const bf16_t*>(dy_any) + (long)row * d);
+    const float4* dr = reinterpret_cast<const float4*>(static_cast<const float*>(dy_any) + (long)src * d);
+    const uint2* dr16 = reinterpret_cast<const uint2*>(static_cast<const bf16_t*>(dy_any) + (long)src * d);
     const float4* gr = g_in ? reinterpret_cast<const float4*>(g_in + (long)row * d) : nullptr;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -125,19 +130,29 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
         nd[i] = make_float4(__uint_as_float(q.x << 16), __uint_as_float(q.x & 0xffff0000u), __uint_as_float(q.y << 16),
                             __uint_as_float(q.y & 0xffff0000u));
       } else {
-        nd[i] = ok ? dr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        nd[i] = (ok && have) ? dr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
       }
       ng[i] = (ok && gr) ? gr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
   int row = blockIdx.x * 4 + wave;
-  if (row < M) fetch(row);
+  // the map entry of a row is requested one fetch ahead of the row itself, so the row's loads never wait for it
+  auto map_of = [&](int r) { return (MAP && r < M) ? dy_map[r] : r; };
+  int src_next = 0;
+  if (row < M) {
+    fetch(row, map_of(row));
+    src_next = map_of(row + stride);
+  }
   for (; row < M; row += stride) {
     const float mu = nmu, rs = nrs;
     float4 xh[NV], dv[NV], gv[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) { xh[i] = nx[i]; dv[i] = nd[i]; gv[i] = ng[i]; }
-    if (row + stride < M) fetch(row + stride);            // next row in flight during this row's reduction
+    if (row + stride < M) {                               // next row in flight during this row's reduction
+      const int src = src_next;
+      src_next = map_of(row + 2 * stride);
+      fetch(row + stride, src);
+    }
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -263,16 +278,20 @@ int fwd_launch(const float* x, const float* g, const float* b, bf16_t* y16, floa
   return NEKO_OK;
 }
 template <int NV>
-int bwd_launch(const void* dy, int dy16, const float* x, const float* g, const float* mean, const float* rstd,
+int bwd_launch(const void* dy, int dy16, const int* dy_map, const float* x, const float* g, const float* mean, const float* rstd,
                const float* g_in, float* dx, bf16_t* dx16, float* part, int nblk, int M, int d, int thr, unsigned key,
                float scale, int want_colsum, hipStream_t s) {
   const size_t lds_bytes = (size_t)(want_colsum ? 12 : 8) * d * sizeof(float);     // 4 waves x (2 or 3) rows x d
   if (lds_bytes > 160 * 1024) return NEKO_ERR_UNSUPPORTED;                          // one workgroup's LDS limit on gfx950
+  if (dy16 && dy_map) return NEKO_ERR_UNSUPPORTED;
   if (dy16)
-    hipLaunchKernelGGL((ln_bwd_kernel<NV, true>), dim3(nblk), dim3(256), lds_bytes, s, dy, x, g, mean,
+    hipLaunchKernelGGL((ln_bwd_kernel<NV, true>), dim3(nblk), dim3(256), lds_bytes, s, dy, dy_map, x, g, mean,
+                       rstd, g_in, dx, dx16, part, M, d, (uint32_t)thr, key, scale, want_colsum);
+  else if (dy_map)
+    hipLaunchKernelGGL((ln_bwd_kernel<NV, false, true>), dim3(nblk), dim3(256), lds_bytes, s, dy, dy_map, x, g, mean,
                        rstd, g_in, dx, dx16, part, M, d, (uint32_t)thr, key, scale, want_colsum);
   else
-    hipLaunchKernelGGL((ln_bwd_kernel<NV, false>), dim3(nblk), dim3(256), lds_bytes, s, dy, x, g, mean,
+    hipLaunchKernelGGL((ln_bwd_kernel<NV, false>), dim3(nblk), dim3(256), lds_bytes, s, dy, dy_map, x, g, mean,
                        rstd, g_in, dx, dx16, part, M, d, (uint32_t)thr, key, scale, want_colsum);
   NEKO_CHECK_LAUNCH();
   return NEKO_OK;
@@ -315,7 +334,7 @@ int neko_layernorm_bwd_blocks_impl(int M) {
 int neko_layernorm_bwd_impl(const void* dy, int dy16, const float* x, const float* gamma, const float* mean,
                             const float* rstd, const float* g_in, float* dx, bf16_t* dx16, float* dgamma,
                             float* dbeta, int accumulate, float* workspace, int M, int d, int drop_thr,
-                            unsigned drop_key, float drop_scale, float* dcolsum16, hipStream_t s) {
+                            unsigned drop_key, float drop_scale, float* dcolsum16, hipStream_t s, const int* dy_map) {
   if (M <= 0) return NEKO_OK;
   if (!dy || !x || !gamma || !mean || !rstd || !workspace || !dgamma || !dbeta) return NEKO_ERR_ARG;
   if (dcolsum16 && !dx16) return NEKO_ERR_ARG;
@@ -324,12 +343,12 @@ int neko_layernorm_bwd_impl(const void* dy, int dy16, const float* x, const floa
   const int nblk = ln_bwd_blocks(M, dy16);
   const int nv = (d / 4 + 63) / 64;
   int rc;
-  if (nv <= 1) rc = bwd_launch<1>(dy, dy16, x, gamma, mean, rstd, g_in, dx, dx16, workspace, nblk, M, d, drop_thr, drop_key, drop_scale, wc, s);
-  else if (nv <= 2) rc = bwd_launch<2>(dy, dy16, x, gamma, mean, rstd, g_in, dx, dx16, workspace, nblk, M, d, drop_thr, drop_key, drop_scale, wc, s);
-  else if (nv <= 3) rc = bwd_launch<3>(dy, dy16, x, gamma, mean, rstd, g_in, dx, dx16, workspace, nblk, M, d, drop_thr, drop_key, drop_scale, wc, s);
-  else if (nv <= 4) rc = bwd_launch<4>(dy, dy16, x, gamma, mean, rstd, g_in, dx, dx16, workspace, nblk, M, d, drop_thr, drop_key, drop_scale, wc, s);
-  else if (nv <= 8) rc = bwd_launch<8>(dy, dy16, x, gamma, mean, rstd, g_in, dx, dx16, workspace, nblk, M, d, drop_thr, drop_key, drop_scale, wc, s);
-  else rc = bwd_launch<16>(dy, dy16, x, gamma, mean, rstd, g_in, dx, dx16, workspace, nblk, M, d, drop_thr, drop_key, drop_scale, wc, s);
+  if (nv <= 1) rc = bwd_launch<1>(dy, dy16, dy_map, x, gamma, mean, rstd, g_in, dx, dx16, workspace, nblk, M, d, drop_thr, drop_key, drop_scale, wc, s);
+  else if (nv <= 2) rc = bwd_launch<2>(dy, dy16, dy_map, x, gamma, mean, rstd, g_in, dx, dx16, workspace, nblk, M, d, drop_thr, drop_key, drop_scale, wc, s);
+  else if (nv <= 3) rc = bwd_launch<3>(dy, dy16, dy_map, x, gamma, mean, rstd, g_in, dx, dx16, workspace, nblk, M, d, drop_thr, drop_key, drop_scale, wc, s);
+  else if (nv <= 4) rc = bwd_launch<4>(dy, dy16, dy_map, x, gamma, mean, rstd, g_in, dx, dx16, workspace, nblk, M, d, drop_thr, drop_key, drop_scale, wc, s);
+  else if (nv <= 8) rc = bwd_launch<8>(dy, dy16, dy_map, x, gamma, mean, rstd, g_in, dx, dx16, workspace, nblk, M, d, drop_thr, drop_key, drop_scale, wc, s);
+  else rc = bwd_launch<16>(dy, dy16, dy_map, x, gamma, mean, rstd, g_in, dx, dx16, workspace, nblk, M, d, drop_thr, drop_key, drop_scale, wc, s);
   if (rc != NEKO_OK) return rc;
   hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(((wc ? 3 : 2) * d + 63) / 64), dim3(256), 0, s, workspace, nblk, d, dgamma,
                      dbeta, dcolsum16, accumulate);

@@ -58,6 +58,14 @@ int neko_layernorm_bwd(const float* dy, const float* x, const float* gamma, cons
   return neko_layernorm_bwd_impl(dy, 0, x, gamma, mean, rstd, g_in, dx, dx16, dgamma, dbeta, accumulate, workspace, M, d,
                                  drop_thr, drop_key, drop_scale, dcolsum16, S(stream));
 }
+int neko_layernorm_bwd_rows(const float* dy_rows, const int* dy_row_map, const float* x, const float* gamma, const float* mean,
+                            const float* rstd, const float* g_in, float* dx, uint16_t* dx16, float* dgamma, float* dbeta, int accumulate,
+                            float* workspace, int M, int d, int drop_thr, unsigned drop_key, float drop_scale, float* dcolsum16,
+                            void* stream) {
+  if (drop_thr < 0 || drop_thr > 255 || !dy_row_map) return NEKO_ERR_ARG;
+  return neko_layernorm_bwd_impl(dy_rows, 0, x, gamma, mean, rstd, g_in, dx, dx16, dgamma, dbeta, accumulate, workspace, M, d,
+                                 drop_thr, drop_key, drop_scale, dcolsum16, S(stream), dy_row_map);
+}
 int neko_layernorm_bwd_bf16dy(const uint16_t* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                        const float* g_in, float* dx, uint16_t* dx16, float* dgamma, float* dbeta, int accumulate,
                        float* workspace, int M, int d, int drop_thr, unsigned drop_key, float drop_scale, float* dcolsum16,
@@ -202,6 +210,20 @@ int neko_patch_resblock_bwd(const float* x_patches, const float* dy, int P, cons
                             float* workspace, void* stream) {
   return neko_patch_resblock_bwd_impl(x_patches, dy, P, w1, b1, gn_w, gn_b, w2, b2, mid_channels, num_groups, dw1, db1,
                                       dgn_w, dgn_b, dw2, db2, workspace, S(stream));
+}
+int neko_patch_resblock_fwd_stats(const void* images, int images_are_u8, int n, int H, int W, const float* w1,
+                                  const float* b1, const float* gn_w, const float* gn_b, const float* w2, const float* b2,
+                                  int mid_channels, int num_groups, uint16_t* y16, float* x_patches, float* gn_stats, void* stream) {
+  return neko_patch_resblock_fwd_impl(images, images_are_u8, n, H, W, w1, b1, gn_w, gn_b, w2, b2, mid_channels,
+                                      num_groups, y16, x_patches, S(stream), gn_stats);
+}
+int neko_patch_resblock_bwd_stats(const float* x_patches, const float* gn_stats, const float* dy, int P, const float* w1, const float* b1,
+                                  const float* gn_w, const float* gn_b, const float* w2, const float* b2, int mid_channels,
+                                  int num_groups, float* dw1, float* db1, float* dgn_w, float* dgn_b, float* dw2, float* db2,
+                                  float* workspace, void* stream) {
+  if (!gn_stats) return NEKO_ERR_ARG;
+  return neko_patch_resblock_bwd_impl(x_patches, dy, P, w1, b1, gn_w, gn_b, w2, b2, mid_channels, num_groups, dw1, db1,
+                                      dgn_w, dgn_b, dw2, db2, workspace, S(stream), gn_stats);
 }
 int neko_patch_resblock_bwd_ws_floats(int P) {
   return neko_patch_resblock_bwd_blocks_impl(P) * neko_patch_resblock_ws_stride_impl();

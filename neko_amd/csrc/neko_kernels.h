@@ -42,6 +42,9 @@ int neko_splitk_reduce_impl(const float* ws, int S, int M, int N, float* C, long
 int neko_gemm_glds_try(const GemmArgs& a, int a_kstrided, int b_kstrided, hipStream_t s);   // 1 = not applicable
 int neko_gemm_a16_try(const GemmArgs& a, int a_kstrided, int b_kstrided, hipStream_t s);    // 1 = not applicable (gemm_a16.hip)
 int neko_gemm_set_mainloop_impl(int mode);
+int neko_gemm_mainloop_mode();
+// gemm_b16.hip (two workgroups per CU): 1 = not applicable; mainloop_mode = neko_gemm_mainloop_mode()
+int neko_gemm_b16_try(const GemmArgs& a, int a_kstrided, int b_kstrided, int mainloop_mode, int* colsum_bands, hipStream_t s);
 // bands of colsum_ws the last neko_gemm_glds_try() of this thread filled (0: the column sums were not folded into it)
 int neko_gemm_glds_colsum_bands();
 int neko_colsum_bands_reduce_impl(const float* ws, int bands, int N, float* out, hipStream_t s);   // out[N] += sum over bands, fixed order
@@ -51,7 +54,7 @@ int neko_layernorm_bwd_blocks_impl(int M);
 int neko_layernorm_bwd_impl(const void* dy, int dy_is_bf16, const float* x, const float* gamma, const float* mean,
                             const float* rstd, const float* g_in, float* dx, bf16_t* dx16, float* dgamma,
                             float* dbeta, int accumulate, float* workspace, int M, int d, int drop_thr,
-                            unsigned drop_key, float drop_scale, float* dcolsum16, hipStream_t s);
+                            unsigned drop_key, float drop_scale, float* dcolsum16, hipStream_t s, const int* dy_map = nullptr);
 int neko_dropout_f32_impl(const float* x, float* y, long n, int thr, unsigned key, float scale, hipStream_t s);
 int neko_attn_fwd_impl(const bf16_t* qkv, const float* kbias, const int* kstart, bf16_t* out, float* lse, int B, int T,
                        int H, int hd, int drop_thr, unsigned drop_key, float drop_scale, uint32_t* dmask, hipStream_t s);
@@ -114,11 +117,11 @@ int neko_set_drop_salt_attention_stream(const uint32_t* p);
 int neko_patch_resblock_fwd_impl(const void* images, int images_are_u8, int n, int H, int W, const float* w1,
                                  const float* b1, const float* gn_w, const float* gn_b, const float* w2,
                                  const float* b2, int mid_channels, int num_groups, bf16_t* y16, float* x_patches,
-                                 hipStream_t s);
+                                 hipStream_t s, float* gn_stats = nullptr);
 int neko_patch_resblock_bwd_impl(const float* x_patches, const float* dy, int P, const float* w1, const float* b1,
                                  const float* gn_w, const float* gn_b, const float* w2, const float* b2,
                                  int mid_channels, int num_groups, float* dw1, float* db1, float* dgn_w, float* dgn_b,
-                                 float* dw2, float* db2, float* workspace, hipStream_t s);
+                                 float* dw2, float* db2, float* workspace, hipStream_t s, const float* gn_stats = nullptr);
 int neko_patch_resblock_bwd_blocks_impl(int P);
 int neko_patch_resblock_ws_stride_impl();
 int neko_patch_pos_add_impl(float* out, const int* hpos, const int* wpos, const float* row_emb, const float* col_emb,

@@ -114,7 +114,8 @@ __global__ __launch_bounds__(256, 2) void resblock_fwd_kernel(const void* __rest
                                                            const float* __restrict__ w1, const float* __restrict__ b1,
                                                            const float* __restrict__ gw, const float* __restrict__ gb,
                                                            const float* __restrict__ w2, const float* __restrict__ b2,
-                                                           bf16_t* __restrict__ y16, float* __restrict__ xp) {
+                                                           bf16_t* __restrict__ y16, float* __restrict__ xp,
+                                                           float* __restrict__ gn_stats) {
   __shared__ FwdSmem s;
   const int tid = threadIdx.x, py = tid >> 4, px = tid & 15, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, l32 = lane & 31;
@@ -206,6 +207,9 @@ __global__ __launch_bounds__(256, 2) void resblock_fwd_kernel(const void* __rest
           const float4 r4 = *reinterpret_cast<const float4*>(&s.red[pass][8 * t + 2 * qq + h][0]);
           const float tot = ((r4.x + r4.y) + (r4.z + r4.w)) * inv_n;
           const float k = pass == 0 ? tot : rsqrtf(tot + GN_EPS);
+          // the group statistics go to the backward kernel (64 floats per patch: mean | rstd of group 8t + 2qq + h), which then
+          // skips their recomputation: two block barriers and eight cross-lane reductions per channel tile
+          if (gn_stats && wave == 0 && l32 == 0) gn_stats[(long)p * 64 + 32 * pass + 8 * t + 2 * qq + h] = k;
 #pragma unroll
           for (int pt = 0; pt < 2; ++pt)
 #pragma unroll
@@ -294,6 +298,7 @@ struct BwdSmem {
   __attribute__((aligned(16))) bf16_t w1[C * 32];     // [c][k], piece ^= (c>>2)&3 (bias hi/lo in columns 27/28)
   __attribute__((aligned(16))) bf16_t w2c[C * 32];    // [c][q], piece ^= (c>>2)&3
   __attribute__((aligned(16))) float red[2][8][4];    // GroupNorm statistics partials [pass][group of tile][wave]
+  float stat[64];                                     // GroupNorm statistics of the patch handed over by the forward: mean[32] | rstd[32]
   float cs[4][2][32];                                 // per-wave channel sums [wave][kind][channel of tile]
   float cst[2][32];                                   // their totals
   float gw[C], gb[C];
@@ -356,11 +361,14 @@ __device__ __forceinline__ float reduce_scatter32(float (&v)[32], int l32) {
 // Occupancy: 77 KB of LDS and <= 256 VGPRs per lane -> TWO blocks (8 waves, 2 per SIMD) per CU.  The first version kept
 // separate h2 / d_h1 tiles (93 KB: one block, one wave per SIMD per CU) and every barrier, LDS round trip and shuffle
 // chain of the per-patch dependency chain was exposed: 539 us per call at MFMA busy 3.9 % / HBM 0.9 % (r01 counters).
+// STATS: the GroupNorm statistics come from the forward pass (gn_stats, see resblock_fwd_kernel) instead of being recomputed: per
+// channel tile two block barriers, eight 32-lane reductions and two LDS exchanges fewer (22 -> 17 barriers per patch; round 5).
+template <bool STATS>
 __global__ __launch_bounds__(256, 2) void resblock_bwd_kernel(const float* __restrict__ xp, const float* __restrict__ dy,
                                                               int P, const float* __restrict__ w1,
                                                               const float* __restrict__ b1, const float* __restrict__ gw,
                                                               const float* __restrict__ gb, const float* __restrict__ w2,
-                                                              float* __restrict__ part) {
+                                                              float* __restrict__ part, const float* __restrict__ gn_stats) {
   // every block writes one partial row [PART_STRIDE] = dw1 | db1 | dgamma | dbeta | dw2 | db2 (plain stores);
   // resblock_param_reduce_kernel sums the rows in a fixed order (atomics onto 54 shared lines serialised in L2).
   float* const dw1 = part + (long)blockIdx.x * PART_STRIDE + OFF_W1;
@@ -401,13 +409,14 @@ __global__ __launch_bounds__(256, 2) void resblock_bwd_kernel(const float* __res
   float b2acc[3] = {0.f, 0.f, 0.f};
 
   // next patch's pixels are requested one patch ahead (see the forward kernel)
-  float nxv[3] = {0.f, 0.f, 0.f}, ng3[3] = {0.f, 0.f, 0.f};
+  float nxv[3] = {0.f, 0.f, 0.f}, ng3[3] = {0.f, 0.f, 0.f}, nstat = 0.f;
   auto load_px = [&](int q) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       nxv[i] = xp[(long)q * 768 + i * 256 + tid];
       ng3[i] = dy[(long)q * 768 + i * 256 + tid];
     }
+    if (STATS && tid < 64) nstat = gn_stats[(long)q * 64 + tid];
   };
   if ((int)blockIdx.x < P) load_px(blockIdx.x);
 #pragma unroll 1
@@ -420,12 +429,14 @@ __global__ __launch_bounds__(256, 2) void resblock_bwd_kernel(const float* __res
         g3[i] = ng3[i];
         b2acc[i] += g3[i];
       }
-      __syncthreads();      // previous patch is done with the halo tiles, cs/cst and red
+      const float st = nstat;
+      __syncthreads();      // previous patch is done with the halo tiles, cs/cst, red and stat
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
         s.gx[i][py + 1][px + 1] = gelu_f(xv[i]);
         s.dh3[i][py + 1][px + 1] = g3[i];
       }
+      if (STATS && tid < 64) s.stat[tid] = st;
     }
     __syncthreads();
     if (p + (int)gridDim.x < P) load_px(p + gridDim.x);
@@ -461,6 +472,20 @@ __global__ __launch_bounds__(256, 2) void resblock_bwd_kernel(const float* __res
       }
       // ---- GroupNorm statistics of the tile's 8 groups (qq, h): mean removed, then scaled by rstd, in place ----------
       float rstd[4];
+      if constexpr (STATS) {
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+          const float mu = s.stat[8 * t + 2 * qq + h];
+          rstd[qq] = s.stat[32 + 8 * t + 2 * qq + h];
+#pragma unroll
+          for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[pt][4 * qq + e] = (acc[pt][4 * qq + e] - mu) * rstd[qq];
+        }
+        // the statistics barriers used to separate the previous tile's dW1 products (readers of the [pixel][channel] tile) from this
+        // tile's h2 stores into it; tile 0 sits behind the two barriers of the patch start
+        if (t > 0) __syncthreads();
+      } else {
 #pragma unroll
       for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
@@ -490,6 +515,7 @@ __global__ __launch_bounds__(256, 2) void resblock_bwd_kernel(const float* __res
               acc[pt][4 * qq + e] = pass == 0 ? acc[pt][4 * qq + e] - k : acc[pt][4 * qq + e] * k;
         }
       }
+      }   // !STATS
       // ---- h2 = GELU(u), du = d_h2 * GELU'(u), u = xhat*gamma + beta; per-channel sums over this lane's 2 pixels -------
       // one pixel tile at a time, h2 written to the [pixel][channel] tile straight away (registers 4qq..4qq+3 are channels
       // 8qq + 4h + {0..3}): 16 live h2 values instead of 32, and gamma / beta are re-read from LDS where needed instead
@@ -696,7 +722,7 @@ __global__ void patch_pos_add_bwd_kernel(const float* __restrict__ dout, const i
 int neko_patch_resblock_fwd_impl(const void* images, int images_are_u8, int n, int H, int W, const float* w1,
                                  const float* b1, const float* gn_w, const float* gn_b, const float* w2,
                                  const float* b2, int mid_channels, int num_groups, bf16_t* y16, float* x_patches,
-                                 hipStream_t s) {
+                                 hipStream_t s, float* gn_stats) {
   if (n <= 0) return NEKO_OK;
   if (!images || !w1 || !b1 || !gn_w || !gn_b || !w2 || !b2 || !y16) return NEKO_ERR_ARG;
   if (H <= 0 || W <= 0 || (H % PS) || (W % PS)) return NEKO_ERR_ARG;   // "Image dimensions must be divisible by patch size"
@@ -705,10 +731,10 @@ int neko_patch_resblock_fwd_impl(const void* images, int images_are_u8, int n, i
   const int grid = P < 2048 ? P : 2048;
   if (images_are_u8)
     hipLaunchKernelGGL((resblock_fwd_kernel<true>), dim3(grid), dim3(256), 0, s, images, n, H, W, w1, b1, gn_w, gn_b,
-                       w2, b2, y16, x_patches);
+                       w2, b2, y16, x_patches, gn_stats);
   else
     hipLaunchKernelGGL((resblock_fwd_kernel<false>), dim3(grid), dim3(256), 0, s, images, n, H, W, w1, b1, gn_w, gn_b,
-                       w2, b2, y16, x_patches);
+                       w2, b2, y16, x_patches, gn_stats);
   NEKO_CHECK_LAUNCH();
   return NEKO_OK;
 }
@@ -720,7 +746,7 @@ int neko_patch_resblock_ws_stride_impl() { return PART_STRIDE; }
 int neko_patch_resblock_bwd_impl(const float* x_patches, const float* dy, int P, const float* w1, const float* b1,
                                  const float* gn_w, const float* gn_b, const float* w2, const float* b2,
                                  int mid_channels, int num_groups, float* dw1, float* db1, float* dgn_w, float* dgn_b,
-                                 float* dw2, float* db2, float* workspace, hipStream_t s) {
+                                 float* dw2, float* db2, float* workspace, hipStream_t s, const float* gn_stats) {
   (void)b2;
   if (P <= 0) return NEKO_OK;
   if (!x_patches || !dy || !w1 || !b1 || !gn_w || !gn_b || !w2 || !dw1 || !db1 || !dgn_w || !dgn_b || !dw2 || !db2 ||
@@ -728,8 +754,12 @@ int neko_patch_resblock_bwd_impl(const float* x_patches, const float* dy, int P,
     return NEKO_ERR_ARG;
   if (mid_channels != C || num_groups != G) return NEKO_ERR_UNSUPPORTED;
   const int grid = neko_patch_resblock_bwd_blocks_impl(P);
-  hipLaunchKernelGGL(resblock_bwd_kernel, dim3(grid), dim3(256), 0, s, x_patches, dy, P, w1, b1, gn_w, gn_b, w2,
-                     workspace);
+  if (gn_stats)
+    hipLaunchKernelGGL((resblock_bwd_kernel<true>), dim3(grid), dim3(256), 0, s, x_patches, dy, P, w1, b1, gn_w, gn_b, w2,
+                       workspace, gn_stats);
+  else
+    hipLaunchKernelGGL((resblock_bwd_kernel<false>), dim3(grid), dim3(256), 0, s, x_patches, dy, P, w1, b1, gn_w, gn_b, w2,
+                       workspace, gn_stats);
   NEKO_CHECK_LAUNCH();
   hipLaunchKernelGGL(resblock_param_reduce_kernel, dim3((PART_USED + 63) / 64), dim3(256), 0, s, workspace, grid, dw1,
                      db1, dgn_w, dgn_b, dw2, db2);

@@ -342,8 +342,9 @@ def stack_forward(P: StackParams, x: torch.Tensor, mask: torch.Tensor, save: boo
 
 
 def stack_backward(P: StackParams, ctx: StackCtx, dhf: torch.Tensor,
-                   on_layer_done: Optional[Callable[[int], None]] = None) -> torch.Tensor:
-    """dhf [M,d] fp32 = gradient wrt ln_f output.  Accumulates every parameter gradient of the stack
+                   on_layer_done: Optional[Callable[[int], None]] = None, dhf_row_map: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dhf [M,d] fp32 = gradient wrt ln_f output (with dhf_row_map int32 [M]: dhf holds the rows map[r] >= 0 only, the others are
+    zero -- the LM head's selected loss rows, read in place by ln_f's backward).  Accumulates every parameter gradient of the stack
     into the flat gradient views and returns the gradient wrt the input embeddings [M,d] fp32.
     on_layer_done(i) is called after layer i's gradient kernels are enqueued (i = L for ln_f):
     the data-parallel reducer hooks its bucket launches there."""
@@ -362,7 +363,7 @@ def stack_backward(P: StackParams, ctx: StackCtx, dhf: torch.Tensor,
     # (every LayerNorm backward also leaves the column sums of its bf16 output = the bias gradient of the projection that
     # consumes it: b_pr of the layer above for ln_f / ln_1, b_o of the same layer for ln_2)
     ops.layernorm_bwd(dhf, ctx.xf, P.lnf_w, ctx.meanf, ctx.rstdf, P.g_lnf_w, P.g_lnf_b, g_in=None, dx=g, dx16=g16,
-                      drop=dr.resid_mlp[L - 1] if dr else None, colsum16=P.layers[L - 1].g_b_pr)
+                      drop=dr.resid_mlp[L - 1] if dr else None, colsum16=P.layers[L - 1].g_b_pr, row_map=dhf_row_map)
     if on_layer_done:
         on_layer_done(len(P.layers))
     for i in range(len(P.layers) - 1, -1, -1):
@@ -630,13 +631,24 @@ def lm_head_loss_selected(Hp: HeadParams, hf16: torch.Tensor, target: torch.Tens
     return loss, hsel, dlogits
 
 
+#: ln_f's backward reads the LM head's gradient rows of the loss positions in place through a row map (neko_layernorm_bwd_rows)
+#: instead of a zero-filled [M, d] expansion (fill + scatter + 2/3 of the rows read as zeros: ~0.12 ms per m-mix step).
+#: NEKO_LNF_ROWS=0 returns to the expansion.
+LNF_ROWS = os.environ.get("NEKO_LNF_ROWS", "1") != "0"
+
+
 def lm_head_backward_selected(Hp: HeadParams, hsel: torch.Tensor, dlogits: torch.Tensor, grad_out: torch.Tensor,
-                              idx: torch.Tensor, n: int, M: int) -> torch.Tensor:
-    """Backward of lm_head_loss_selected: gradient rows are scattered back into a zero [M,d] buffer."""
+                              idx: torch.Tensor, n: int, M: int):
+    """Backward of lm_head_loss_selected -> (dhf, row_map): either the gradient rows scattered back into a zero [M,d] buffer and
+    None, or the compact rows [npad, d] and the int32 [M] map row -> compact row (-1: zero), see LNF_ROWS."""
     dsel = lm_head_backward(Hp, hsel, dlogits, grad_out)
+    if LNF_ROWS:
+        row_map = torch.full((M,), -1, dtype=torch.int32, device=hsel.device)
+        row_map.index_copy_(0, idx[:n].long(), torch.arange(n, dtype=torch.int32, device=hsel.device))
+        return dsel, row_map
     dhf = torch.zeros(M, hsel.shape[1], dtype=F32, device=hsel.device)
     ops.scatter_rows_f32(dsel, idx, n, dhf)
-    return dhf
+    return dhf, None
 
 
 def lm_head_backward(Hp: HeadParams, hf16: torch.Tensor, dlogits: torch.Tensor, grad_out: torch.Tensor) -> torch.Tensor:

@@ -165,15 +165,22 @@ def layernorm_fwd(x, gamma, beta, y16=None, y32=None, mean=None, rstd=None, eps:
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, g_in=None, dx=None, dx16=None, accumulate=True, drop=None,
-                  colsum16=None):
+                  colsum16=None, row_map=None):
     """dy fp32 or bf16 [M,d] (neko_layernorm_bwd / neko_layernorm_bwd_bf16dy).  colsum16: fp32 [d] that receives (+=) the
-    column sums of dx16 -- the bias gradient of the Linear that consumes dx16."""
+    column sums of dx16 -- the bias gradient of the Linear that consumes dx16.  row_map (int32 [M]): dy is fp32 [n, d] and holds the
+    gradient of row r at dy[row_map[r]], zero where row_map[r] < 0 (neko_layernorm_bwd_rows)."""
     assert dy.is_cuda and dy.dtype in (torch.float32, BF16) and dy.is_contiguous(), "dy must be a contiguous f32 / bf16 device tensor"
     M, d = x.shape[0], x.shape[1]
     nblk = _lib.load().neko_layernorm_bwd_blocks(M)
     ws = torch.empty(nblk * 3 * d, dtype=torch.float32, device=x.device)
     if colsum16 is not None:
         _chk(colsum16, torch.float32, "colsum16"); assert dx16 is not None and colsum16.numel() >= d
+    if row_map is not None:
+        _chk(dy, torch.float32, "dy"); _chk(row_map, torch.int32, "row_map")
+        assert row_map.numel() == M and row_map.is_contiguous() and dy.shape[1] == d
+        _lib.call("neko_layernorm_bwd_rows", _p(dy), _p(row_map), _p(x), _p(gamma), _p(mean), _p(rstd), _p(g_in), _p(dx), _p(dx16),
+                  _p(dgamma), _p(dbeta), int(accumulate), _p(ws), M, d, *_drop(drop), _p(colsum16), _stream())
+        return
     _lib.call("neko_layernorm_bwd_bf16dy" if dy.dtype == BF16 else "neko_layernorm_bwd", _p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(g_in), _p(dx), _p(dx16),
               _p(dgamma), _p(dbeta), int(accumulate), _p(ws), M, d, *_drop(drop), _p(colsum16), _stream())
 
@@ -485,9 +492,15 @@ def set_drop_salt(salt: Optional[torch.Tensor]) -> None:
     _salt_holder[0] = salt
 
 
-def patch_resblock_fwd(images, w1, b1, gw, gb, w2, b2, mid, groups, want_x=True, want_padded=False):
+#: the patch forward hands its GroupNorm statistics to the backward (neko_patch_resblock_fwd_stats / _bwd_stats, ABI v17) instead of
+#: letting it recompute them; NEKO_PATCH_STATS=0 returns to the recomputing backward
+PATCH_STATS = os.environ.get("NEKO_PATCH_STATS", "1") != "0"
+
+
+def patch_resblock_fwd(images, w1, b1, gw, gb, w2, b2, mid, groups, want_x=True, want_padded=False, want_stats=False):
     """-> (y16 [P, 768] bf16, x_patches [P, 768] fp32 | None), plus with `want_padded` the zero-padded storage y16 is the row prefix of
-    ([Ppad, 768], Ppad a multiple of 128): the weight gradient of the projection contracts over ITS rows."""
+    ([Ppad, 768], Ppad a multiple of 128): the weight gradient of the projection contracts over ITS rows; plus with `want_stats` the
+    GroupNorm statistics [P, 64] fp32 (mean | rstd per group) for patch_resblock_bwd, or None when x_patches was not asked for."""
     assert images.is_cuda and images.dim() == 4 and images.shape[1] == 3
     assert images.dtype in (torch.float32, torch.uint8)
     images = images.contiguous()
@@ -503,16 +516,29 @@ def patch_resblock_fwd(images, w1, b1, gw, gb, w2, b2, mid, groups, want_x=True,
         y16_all[P:].zero_()
     y16 = y16_all[:P]
     xp = torch.empty(P, 768, dtype=torch.float32, device=images.device) if want_x else None
-    _lib.call("neko_patch_resblock_fwd", _p(images), int(images.dtype == torch.uint8), n, H, W, _p(w1), _p(b1),
-              _p(gw), _p(gb), _p(w2), _p(b2), mid, groups, _p(y16), _p(xp), _stream())
+    stats = torch.empty(P, 64, dtype=torch.float32, device=images.device) if (want_stats and want_x and PATCH_STATS) else None
+    if stats is not None:
+        _lib.call("neko_patch_resblock_fwd_stats", _p(images), int(images.dtype == torch.uint8), n, H, W, _p(w1), _p(b1),
+                  _p(gw), _p(gb), _p(w2), _p(b2), mid, groups, _p(y16), _p(xp), _p(stats), _stream())
+    else:
+        _lib.call("neko_patch_resblock_fwd", _p(images), int(images.dtype == torch.uint8), n, H, W, _p(w1), _p(b1),
+                  _p(gw), _p(gb), _p(w2), _p(b2), mid, groups, _p(y16), _p(xp), _stream())
+    out = (y16, xp)
     if want_padded:
-        return y16, xp, y16_all
-    return y16, xp
+        out += (y16_all,)
+    if want_stats:
+        out += (stats,)
+    return out
 
 
-def patch_resblock_bwd(xp, dy, w1, b1, gw, gb, w2, b2, mid, groups, dw1, db1, dgw, dgb, dw2, db2):
+def patch_resblock_bwd(xp, dy, w1, b1, gw, gb, w2, b2, mid, groups, dw1, db1, dgw, dgb, dw2, db2, stats=None):
     _chk(dy, torch.float32, "dy")
     ws = torch.empty(_lib.load().neko_patch_resblock_bwd_ws_floats(xp.shape[0]), dtype=torch.float32, device=xp.device)
+    if stats is not None:
+        _chk(stats, torch.float32, "stats"); assert stats.shape == (xp.shape[0], 64) and stats.is_contiguous()
+        _lib.call("neko_patch_resblock_bwd_stats", _p(xp), _p(stats), _p(dy), xp.shape[0], _p(w1), _p(b1), _p(gw), _p(gb), _p(w2), _p(b2),
+                  mid, groups, _p(dw1), _p(db1), _p(dgw), _p(dgb), _p(dw2), _p(db2), _p(ws), _stream())
+        return
     _lib.call("neko_patch_resblock_bwd", _p(xp), _p(dy), xp.shape[0], _p(w1), _p(b1), _p(gw), _p(gb), _p(w2), _p(b2),
               mid, groups, _p(dw1), _p(db1), _p(dgw), _p(dgb), _p(dw2), _p(db2), _p(ws), _stream())
 

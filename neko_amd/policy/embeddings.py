@@ -72,10 +72,10 @@ class _ImageEmbedFn(torch.autograd.Function):
         f.ensure_shadow()
         pe = pre + "patch_embedding."
         w = lambda n: f.view(n)
-        y16, xp, y16_all = ops.patch_resblock_fwd(images, w(pe + "conv1.weight"), w(pe + "conv1.bias"), w(pe + "gn2.weight"),
-                                                  w(pe + "gn2.bias"), w(pe + "conv2.weight"), w(pe + "conv2.bias"),
-                                                  mod.patch_embedding.mid_channels, mod.patch_embedding.num_groups,
-                                                  want_x=need, want_padded=True)
+        y16, xp, y16_all, stats = ops.patch_resblock_fwd(images, w(pe + "conv1.weight"), w(pe + "conv1.bias"), w(pe + "gn2.weight"),
+                                                         w(pe + "gn2.bias"), w(pe + "conv2.weight"), w(pe + "conv2.bias"),
+                                                         mod.patch_embedding.mid_channels, mod.patch_embedding.num_groups,
+                                                         want_x=need, want_padded=True, want_stats=True)
         P = y16.shape[0]
         d = mod.embed_dim
         out = torch.empty(P, d, dtype=torch.float32, device=y16.device)
@@ -84,7 +84,7 @@ class _ImageEmbedFn(torch.autograd.Function):
         if mod.use_pos_encoding:
             ops.patch_pos_add(out, hpos, wpos, f.view(pre + "patch_pos_encoding.height_pos_embedding.weight"),
                               f.view(pre + "patch_pos_encoding.width_pos_embedding.weight"))
-        ctx.mod, ctx.y16_all, ctx.xp, ctx.hpos, ctx.wpos = mod, y16_all, xp, hpos, wpos
+        ctx.mod, ctx.y16_all, ctx.xp, ctx.hpos, ctx.wpos, ctx.gn_stats = mod, y16_all, xp, hpos, wpos, stats
         return out
 
     @staticmethod
@@ -122,7 +122,7 @@ class _ImageEmbedFn(torch.autograd.Function):
                                f.view(pe + "conv2.bias"), mod.patch_embedding.mid_channels,
                                mod.patch_embedding.num_groups, f.gview(pe + "conv1.weight"), f.gview(pe + "conv1.bias"),
                                f.gview(pe + "gn2.weight"), f.gview(pe + "gn2.bias"), f.gview(pe + "conv2.weight"),
-                               f.gview(pe + "conv2.bias"))
+                               f.gview(pe + "conv2.bias"), stats=ctx.gn_stats)
         f.attach_grads(mod.used_param_names(pre))
         if mod._on_grads_ready is not None:
             mod._on_grads_ready()

@@ -291,9 +291,10 @@ class _PolicyCoreFn(torch.autograd.Function):
         f.prepare_backward(names)
         dp = policy._dp
         engine.SideStream.rows_hint = B * T        # rows of this step: decides whether weight gradients fork onto the side stream
+        row_map = None
         if ctx.sel_idx is not None:
-            dhf = engine.lm_head_backward_selected(policy._head_params(), ctx.hf16, ctx.dlogits, g_loss, ctx.sel_idx,
-                                                   ctx.sel_n, B * T)
+            dhf, row_map = engine.lm_head_backward_selected(policy._head_params(), ctx.hf16, ctx.dlogits, g_loss, ctx.sel_idx,
+                                                            ctx.sel_n, B * T)
         else:
             dhf = engine.lm_head_backward(policy._head_params(), ctx.hf16, ctx.dlogits, g_loss)
         if dp is not None:
@@ -303,7 +304,7 @@ class _PolicyCoreFn(torch.autograd.Function):
             if dp is not None:
                 dp.group_ready("lnf" if i == len(policy.transformer.h) else f"layer{i}")
 
-        gx = engine.stack_backward(policy.transformer._stack_params(), ctx.sctx, dhf, on_layer_done=layer_done)
+        gx = engine.stack_backward(policy.transformer._stack_params(), ctx.sctx, dhf, on_layer_done=layer_done, dhf_row_map=row_map)
         engine.SideStream.join(gx.device)       # (stack_backward joins too: explicit for the LM-head dW launched before it)
         f.attach_grads(names)
         ctx.sctx = ctx.hf16 = ctx.dlogits = None

@@ -183,6 +183,134 @@ def test_gemm_a16_epilogues(a16, epi):
         assert torch.equal(outs[0], outs[1])
 
 
+@pytest.fixture
+def b16(ops):
+    """every launch the two-workgroups-per-CU main loop (gemm_b16.hip) can serve goes to it"""
+    prev = ops.gemm_set_mainloop(2)
+    yield ops
+    ops.gemm_set_mainloop(prev)
+
+
+@pytest.mark.parametrize("layout", ["nt", "nn"])
+@pytest.mark.parametrize("M,N,K", [(128, 256, 384), (640, 768, 768), (256, 512, 3072), (1152, 1024, 2304)])
+def test_gemm_b16_main_loop_layouts(b16, layout, M, N, K):
+    """gemm_b16.hip (128 x 256 per workgroup, 4 waves x 64 x 128 on 16x16x32 MFMAs, 128 accumulators in AGPRs, two workgroups per CU,
+    hand-placed 12-k-tile loop body): one loop trip, 2, 8 and 6 trips, B k-contiguous (dgrad) and k-strided (forward), bf16 and fp32
+    outputs where a kernel exists, against an fp32 product of the same bf16 operands and against the default loop."""
+    g = torch.Generator().manual_seed(M + 3 * N + 7 * K)
+    A = rb(torch.randn(M, K, generator=g)); Bm = rb(torch.randn(K, N, generator=g) * 0.25)
+    A = rb(A * (1.0 + 0.01 * torch.arange(M).float().unsqueeze(1) % 0.37))      # rows individually recognisable
+    ref = A @ Bm
+    b_ks = layout == "nn"
+    A_dev = bf(A)
+    B_dev = bf(Bm) if b_ks else bf(Bm.t())
+    out16 = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    b16.gemm(A_dev, B_dev, M, N, K, b_kstrided=b_ks, out_bf16=out16)
+    close(out16, ref, 2 ** -7, 2e-4 * math.sqrt(K), f"b16 bf16 {layout} {M}x{N}x{K}")
+    prev = b16.gemm_set_mainloop(0)
+    try:
+        other = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+        b16.gemm(A_dev, B_dev, M, N, K, b_kstrided=b_ks, out_bf16=other)
+    finally:
+        b16.gemm_set_mainloop(prev)
+    # both are fp32 sums of the same products rounded once to bf16: equal up to the rare rounding flip
+    assert float((out16.float() - other.float()).abs().max()) <= 2 ** -7 * float(ref.abs().max())
+    assert float((out16 != other).float().mean()) < 2e-2
+    if not b_ks:                                      # the fp32-out kernel exists for the dgrad layout
+        out = torch.full((M, N), float("nan"), device=DEV)
+        b16.gemm(A_dev, B_dev, M, N, K, b_kstrided=False, out_f32=out)
+        close(out, ref, 2e-4, 2e-4 * math.sqrt(K), f"b16 f32 {layout} {M}x{N}x{K}")
+
+
+@pytest.mark.parametrize("epi", ["bias_bf16", "bias_resid", "bias_resid_drop", "bias_gelu_pre", "bias_gelu_factor", "gelubwd", "gelubwd_factor_colsum"])
+def test_gemm_b16_epilogues(b16, epi):
+    """Every compiled epilogue behind gemm_b16.hip (one kernel per feature set; the accumulators leave the AGPRs 32 rows at a time with
+    at most 8 of a pass's 16 steps of epilogue inputs in flight) against the same call on the default loops -- bit-identical where the
+    epilogue arithmetic is elementwise on identical fp32 sums is not guaranteed (different summation order), so: fp32 tolerance against
+    the reference product, and run-to-run bit identity."""
+    M, N, K = 640, 768, 768
+    g = torch.Generator().manual_seed(123)
+    A = rb(torch.randn(M, K, generator=g)); Bm = rb(torch.randn(K, N, generator=g) * 0.1)
+    ref = A @ Bm
+    A_dev = bf(A)
+    fwd = dict(b_kstrided=True)
+    B_fwd, B_dg = bf(Bm), bf(Bm.t())
+    bias = torch.randn(N, generator=g); resid = torch.randn(M, N, generator=g)
+
+    def twice(fn):
+        a, b = fn(), fn()
+        for x, y in zip(a, b):
+            assert torch.equal(x, y), f"{epi}: not run-to-run identical"
+        return a
+
+    if epi == "bias_bf16":
+        def run():
+            out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+            b16.gemm(A_dev, B_fwd, M, N, K, bias=bias.to(DEV), out_bf16=out, **fwd)
+            return (out,)
+        (out,) = twice(run)
+        close(out, ref + bias, 2 ** -7, 2e-4 * math.sqrt(K), epi)
+    elif epi in ("bias_resid", "bias_resid_drop"):
+        from neko_amd.ops import Drop
+        drop = Drop(0.1, 0x1234567) if epi.endswith("drop") else None
+        def run():
+            out = torch.full((M, N), float("nan"), device=DEV)
+            b16.gemm(A_dev, B_fwd, M, N, K, bias=bias.to(DEV), resid=resid.to(DEV), out_f32=out, drop=drop, **fwd)
+            return (out,)
+        (out,) = twice(run)
+        if drop is None:
+            close(out, ref + bias + resid, 2e-4, 2e-4 * math.sqrt(K), epi)
+        else:       # the same site key on the default loop drops the same elements: compare with it
+            prev = b16.gemm_set_mainloop(0)
+            try:
+                other = torch.full((M, N), float("nan"), device=DEV)
+                b16.gemm(A_dev, B_fwd, M, N, K, bias=bias.to(DEV), resid=resid.to(DEV), out_f32=other, drop=drop, **fwd)
+            finally:
+                b16.gemm_set_mainloop(prev)
+            close(out, other.cpu(), 2e-4, 4e-4 * math.sqrt(K), epi)
+            kept = ((out.cpu() - resid).abs() > 0).float().mean()
+            assert 0.86 < float(kept) < 0.94, float(kept)
+    elif epi in ("bias_gelu_pre", "bias_gelu_factor"):
+        act = 1 if epi == "bias_gelu_pre" else 3
+        def run():
+            out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+            second = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+            b16.gemm(A_dev, B_fwd, M, N, K, bias=bias.to(DEV), act=act, pre_out=second, out_bf16=out, **fwd)
+            return out, second
+        out, second = twice(run)
+        x = (ref + bias).to(torch.bfloat16).float()
+        xd = x.double()
+        err = (out.float().cpu() - torch.nn.functional.gelu(x)).abs()
+        assert float((err > 2 ** -7 * x.abs() + 2e-2).float().mean()) < 1e-3, "gelu values"
+        if act == 1:
+            assert float((second.float().cpu() != x).float().mean()) < 2e-2, "stored pre-activation"
+        else:
+            gp = 0.5 * (1 + torch.erf(xd / math.sqrt(2))) + xd * torch.exp(-0.5 * xd * xd) / math.sqrt(2 * math.pi)
+            errf = (second.float().cpu() - gp.float()).abs()
+            assert float((errf > 2 ** -7 + 2e-2).float().mean()) < 1e-3, "gelu' factor"
+    elif epi == "gelubwd":
+        pre = rb(torch.randn(M, N, generator=g) * 1.5)
+        def run():
+            out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+            b16.gemm(A_dev, B_dg, M, N, K, act=2, act_in=bf(pre), out_bf16=out)
+            return (out,)
+        (out,) = twice(run)
+        gprime = 0.5 * (1 + torch.erf(pre / math.sqrt(2))) + pre * torch.exp(-0.5 * pre * pre) / math.sqrt(2 * math.pi)
+        close(out, ref * gprime, 2 ** -7, 2e-4 * math.sqrt(K), epi)
+    else:
+        fac = rb(torch.rand(M, N, generator=g) * 1.2 - 0.1)
+        base = torch.randn(N, generator=g)
+        def run():
+            out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+            cs = base.clone().to(DEV)
+            b16.gemm_dgrad_gelu_colsum(A_dev, B_dg, M, N, K, bf(fac), out, cs, act_in_is_factor=True)
+            return out, cs
+        out, cs = twice(run)
+        close(out, ref * fac, 2 ** -7, 2e-4 * math.sqrt(K), epi)
+        want = base + (ref * fac).sum(0)
+        assert float((cs.cpu() - want).norm() / want.norm()) < 2e-3
+
+
 def test_gemm_many_tiles_fast_epilogues(ops):
     """A shape with several hundred 256x256 / 128x128 tiles (more than one round of the chip) through the specialised
     epilogues: forward-like (bias + bf16 / GELU + pre-activation / bias + residual f32) and dgrad-like (both operands
@@ -366,6 +494,36 @@ def test_layernorm_fwd_bwd(ops, M, d, dy_bf16):
     close(dx16, xr.grad + gin, 2 ** -8, 1e-4, "ln dx16")
     close(dg, wr.grad + 1, 1e-4, 1e-3, "ln dgamma")
     close(db, br.grad + 1, 1e-4, 1e-3, "ln dbeta")
+
+
+@pytest.mark.parametrize("M,d,frac", [(37, 64, 0.4), (1000, 768, 0.35), (4099, 768, 0.0), (515, 2048, 1.0)])
+def test_layernorm_bwd_row_map_equals_the_expanded_gradient(ops, M, d, frac):
+    """neko_layernorm_bwd_rows (ABI v17): dy given for the mapped rows only (the LM head's loss positions) == the same call on the
+    zero-filled [M, d] expansion, bit for bit (same kernel arithmetic, zeros read from registers instead of memory); includes no
+    mapped row at all and every row mapped, in a permuted order."""
+    g = torch.Generator().manual_seed(M + d)
+    x = (torch.randn(M, d, generator=g) * 2 + 0.3).to(DEV)
+    w, b = torch.randn(d, generator=g).to(DEV), torch.randn(d, generator=g).to(DEV)
+    gin = torch.randn(M, d, generator=g).to(DEV)
+    sel = torch.nonzero(torch.rand(M, generator=g) < frac).flatten() if 0.0 < frac < 1.0 else (torch.arange(M) if frac >= 1.0 else torch.zeros(0, dtype=torch.long))
+    n = int(sel.numel())
+    perm = torch.randperm(n, generator=g)
+    rows = torch.randn(max(n, 1) + 3, d, generator=g)                 # compact rows (a few unused ones behind them)
+    row_map = torch.full((M,), -1, dtype=torch.int32)
+    row_map[sel] = perm.to(torch.int32)
+    dense = torch.zeros(M, d)
+    if n:
+        dense[sel] = rows[perm]
+    mean = torch.empty(M, device=DEV); rstd = torch.empty(M, device=DEV)
+    ops.layernorm_fwd(x, w, b, y32=torch.empty(M, d, device=DEV), mean=mean, rstd=rstd)
+    outs = []
+    for kw in (dict(dy=dense.to(DEV)), dict(dy=rows.to(DEV), row_map=row_map.to(DEV))):
+        dg = torch.ones(d, device=DEV); db = torch.ones(d, device=DEV); cs = torch.zeros(d, device=DEV)
+        dx = torch.empty(M, d, device=DEV); dx16 = torch.empty(M, d, dtype=torch.bfloat16, device=DEV)
+        ops.layernorm_bwd(kw["dy"], x, w, mean, rstd, dg, db, g_in=gin, dx=dx, dx16=dx16, colsum16=cs, row_map=kw.get("row_map"))
+        outs.append((dx, dx16, dg, db, cs))
+    for a, c, what in zip(outs[0], outs[1], ("dx", "dx16", "dgamma", "dbeta", "colsum16")):
+        assert torch.equal(a, c), f"row-map LayerNorm backward differs from the expanded call in {what}"
 
 
 def test_wgrad_splitk_accumulates(ops):
@@ -659,6 +817,18 @@ def test_patch_resblock_fwd_bwd(ops, u8):
         ref = leaf[nme].grad
         # bf16 MFMA operands (h2, d_h1, dy, GELU(x) rounded to bf16), fp32 accumulation over up to 18 x 256 pixels
         close(grads[nme], ref, 1e-2, 1e-2 * float(ref.abs().max()) + 1e-5, f"resblock d{nme}")
+    # ABI v17: the forward hands its GroupNorm statistics over and the backward takes them instead of recomputing them -- the same
+    # numbers (the recomputation repeats the forward's arithmetic), so every gradient is bit-identical to the recomputing kernel's
+    y16s, xps, stats = ops.patch_resblock_fwd(img_in, *[dev[n] for n in names], 128, 32, want_stats=True)
+    assert torch.equal(y16s, y16) and torch.equal(xps, xpd) and stats is not None and stats.shape == (xp.shape[0], 64)
+    h1 = torch.nn.functional.conv2d(torch.nn.functional.gelu(xp), sd[pe + "conv1.weight"], sd[pe + "conv1.bias"], padding=1)
+    grp = h1.reshape(h1.shape[0], 32, -1)
+    close(stats[:, :32], grp.mean(-1), 2e-2, 2e-2, "group means")         # bf16 convolution operands on the device side
+    close(stats[:, 32:], (grp.var(-1, unbiased=False) + 1e-5).rsqrt(), 2e-2, 2e-2, "group rstd")
+    grads_s = {n: torch.zeros_like(dev[n]) for n in names}
+    ops.patch_resblock_bwd(xpd, dy.to(DEV), *[dev[n] for n in names], 128, 32, *[grads_s[n] for n in names], stats=stats)
+    for nme in names:
+        assert torch.equal(grads_s[nme], grads[nme]), f"stats-fed backward differs from the recomputing one in d{nme}"
 
 
 def test_patch_pos_add(ops):

@@ -2,6 +2,7 @@
 """Writes neko_amd/csrc/gemm_a16_loop.inc: the hand-placed main loop of gemm_a16.hip, one instruction stream per operand-layout pair.
 
     python tools/gen_gemm_a16.py [--kc 32|64]           # regenerate (the .inc is committed; build.py does not run this)
+    python tools/gen_gemm_a16.py --geom b16             # the 128 x 256 / two-workgroups-per-CU variant (gemm_b16_loop.inc), see GEOMS
 
 Why a generator: the loop is written instruction by instruction (registers, waits and the position of every LDS read and DMA piece
 between the MFMAs are chosen here, not by hipcc), and the four layout variants x 4 unrolled k-tiles differ only in operand-read
@@ -36,16 +37,37 @@ import argparse
 import os
 import sys
 
-REGION = {"a": 0, "b": 65536}
-
-# fixed registers (all listed as clobbers in gemm_a16.hip)
+# fixed registers (all listed as clobbers in gemm_a16.hip / gemm_b16.hip)
 S_G = {"a": 84, "b": 86}        # 64-bit DMA source bases
 S_NEXT = {"a": 88, "b": 89}     # index of the next stage / slot to request
 S_LIM = {"a": 90, "b": 91}      # number of stages / slots
 S_CNT, S_M0, S_T = 92, 93, 94
 S_LAST = 95
-V_KS = {"a": 96, "b": 104}      # 8 address registers each (k-strided operand, one per 16-wide block)
-V_FRAG = 128                    # two fragment sets of 64
+
+
+class Geom:
+    """One workgroup geometry.  a16: 256 x 256 per workgroup, 128 x 128 per wave (8 x 8 blocks, 256 accumulators, 512 registers, one
+    workgroup per CU, 128 KB of LDS: 64 KB per operand, 4-stage 32-k rings / two 64-k slots).  b16 (round 5): 128 x 256 per workgroup,
+    64 x 128 per wave (4 x 8 blocks, 128 accumulators, <= 256 registers, 80 KB of LDS) so that TWO workgroups share a CU and one's
+    output phase (epilogue arithmetic + stores) runs under the other's main loop: A (k-contiguous only) in two 64-k slots of 128 rows =
+    32 KB at 0, B in a 3-stage 32-k ring = 48 KB at 32 KB (a slot that was read during tile t - 1 is refilled with tile t + 3 during
+    tile t, so three stages carry the same three tiles of lookahead as a16's four).  The slot period (4 tiles) and the ring period (3)
+    give a loop body of 12 k-tiles: the contraction range must be a multiple of 384."""
+
+    def __init__(self, name, fa, fb, ring, region, slot64, npiece64, v_ks, v_frag, boff, trip):
+        self.name, self.fa, self.fb, self.ring, self.region, self.slot64, self.npiece64 = name, fa, fb, ring, region, slot64, npiece64
+        self.v_ks, self.v_frag, self.boff, self.trip = v_ks, v_frag, boff, trip
+        self.set = 4 * (fa + fb)                 # registers of one fragment set
+        self.nm = fa * fb                        # MFMAs per k-tile
+        self.vlo = min(list(v_ks.values()) + [v_frag])
+        self.vhi = v_frag + 2 * self.set         # clobbered VGPRs: [vlo, vhi)
+
+
+GEOMS = {
+    "a16": Geom("A16", 8, 8, 4, {"a": 0, "b": 65536}, {"a": 32768, "b": 32768}, {"a": 8, "b": 8}, {"a": 96, "b": 104}, 128, 32, 4),
+    "b16": Geom("B16", 4, 8, 3, {"a": 0, "b": 32768}, {"a": 16384}, {"a": 4}, {"b": 24}, 32, 16, 12),
+}
+G = GEOMS["a16"]
 
 
 class Op:
@@ -53,25 +75,27 @@ class Op:
 
     def __init__(self, which, mode):
         self.w, self.mode = which, mode
-        self.npiece = 8 if mode == "kc64" else 4              # per wave per request unit (stage or slot)
+        self.npiece = G.npiece64[which] if mode == "kc64" else 4     # per wave per request unit (stage or slot)
+        self.nfrag = G.fa if which == "a" else G.fb
+        assert mode != "ks" or which in G.v_ks, f"geometry {G.name}: operand {which} cannot be k-strided"
 
     def frag(self, setp, t):
-        return V_FRAG + 64 * setp + (0 if self.w == "a" else 32) + 4 * t
+        return G.v_frag + G.set * setp + (0 if self.w == "a" else G.boff) + 4 * t
 
-    def reads(self, tile_u, setp):
-        """LDS reads of the 8 fragments of tile tile_u (mod 4) into fragment set setp"""
+    def reads(self, tile, setp):
+        """LDS reads of the fragments of k-tile `tile` (absolute index) into fragment set setp"""
         out = []
-        for t in range(8):
+        for t in range(self.nfrag):
             r = self.frag(setp, t)
             if self.mode == "kc64":
-                slot, half = (tile_u >> 1) & 1, tile_u & 1
-                out.append(f"ds_read_b128 v[{r}:{r + 3}], %[r{self.w}{half}] offset:{slot * 32768 + t * 2048}")
+                slot, half = (tile >> 1) & 1, tile & 1
+                out.append(f"ds_read_b128 v[{r}:{r + 3}], %[r{self.w}{half}] offset:{slot * G.slot64[self.w] + t * 2048}")
             elif self.mode == "kc32":
-                out.append(f"ds_read_b128 v[{r}:{r + 3}], %[r{self.w}0] offset:{tile_u * 16384 + t * 1024}")
+                out.append(f"ds_read_b128 v[{r}:{r + 3}], %[r{self.w}0] offset:{(tile % G.ring) * 16384 + t * 1024}")
             else:
-                base = V_KS[self.w] + t
-                out.append(f"ds_read_b64_tr_b16 v[{r}:{r + 1}], v{base} offset:{tile_u * 16384}")
-                out.append(f"ds_read_b64_tr_b16 v[{r + 2}:{r + 3}], v{base} offset:{tile_u * 16384 + 2048}")
+                base = G.v_ks[self.w] + t
+                out.append(f"ds_read_b64_tr_b16 v[{r}:{r + 1}], v{base} offset:{(tile % G.ring) * 16384}")
+                out.append(f"ds_read_b64_tr_b16 v[{r + 2}:{r + 3}], v{base} offset:{(tile % G.ring) * 16384 + 2048}")
         return out
 
     def unit_of_tile(self, t):
@@ -83,9 +107,9 @@ class Op:
         out = []
         for pc in range(self.npiece):
             if self.mode == "kc64":
-                dst = REGION[self.w] + (unit % 2) * 32768 + pc * 1024
+                dst = G.region[self.w] + (unit % 2) * G.slot64[self.w] + pc * 1024
             else:
-                dst = REGION[self.w] + (unit % 4) * 16384 + pc * 1024
+                dst = G.region[self.w] + (unit % G.ring) * 16384 + pc * 1024
             sg = S_G[self.w]
             out.append((f"s_add_u32 m0, %[ldsw{self.w}], {dst}", f"global_load_lds_dwordx4 %[vo{self.w}{pc}], s[{sg}:{sg + 1}]"))
         return out
@@ -107,7 +131,7 @@ class Op:
 
 
 def mfma(A, B, ti, tj, setp):
-    acc = 4 * (8 * ti + tj)
+    acc = 4 * (G.fb * ti + tj)
     a, b = A.frag(setp, ti), B.frag(setp, tj)
     return f"v_mfma_f32_16x16x32_bf16 a[{acc}:{acc + 3}], v[{b}:{b + 3}], v[{a}:{a + 3}], a[{acc}:{acc + 3}]"
 
@@ -129,11 +153,11 @@ class Issue:
 
 def tile_body(A, B, t, sched, issue):
     """k-tile t (absolute, steady state): MFMAs on set t&1, reads of tile t+1 into the other set, DMA requests, wait count"""
-    u, setp = t % 4, t & 1
+    setp = t & 1
     need = {("a", A.unit_of_tile(t + 1)), ("b", B.unit_of_tile(t + 1))}
     n = issue.wait_count(need)
     lines = [f"s_waitcnt vmcnt({n})", "s_waitcnt lgkmcnt(0)", "s_barrier"]
-    reads = B.reads((u + 1) % 4, setp ^ 1) + A.reads((u + 1) % 4, setp ^ 1)
+    reads = B.reads(t + 1, setp ^ 1) + A.reads(t + 1, setp ^ 1)
     pieces, adv_after = [], {}
     for op in (A, B):
         for unit in op.units_requested_in_tile(t):
@@ -141,21 +165,22 @@ def tile_body(A, B, t, sched, issue):
             for p in ps:
                 pieces.append((p, (op.w, unit)))
             adv_after[len(pieces) - 1] = op.advance()
-    fill = {m: [] for m in range(64)}
+    NM = G.nm
+    fill = {m: [] for m in range(NM)}
     span = sched["read_span"]
     for i, r in enumerate(reads):
         fill[(i * span) // len(reads)].append(r)
     if pieces:
         first = sched["dma_first"]
-        step = min(sched["dma_step"], max(2, (60 - first) // len(pieces)))
+        step = min(sched["dma_step"], max(2, (NM - 4 - first) // len(pieces)))
         for i, ((setm0, req), tag) in enumerate(pieces):
             m = first + i * step
             fill[m].append(setm0)
             fill[m + 1].append(("DMA", req, tag))
             if i in adv_after:
                 for k, ins in enumerate(adv_after[i]):
-                    fill[min(63, m + 2 + k // 3)].append(ins)
-    order = [(ti, tj) for ti in range(8) for tj in (range(8) if ti % 2 == 0 or not sched["snake"] else range(7, -1, -1))]
+                    fill[min(NM - 1, m + 2 + k // 3)].append(ins)
+    order = [(ti, tj) for ti in range(G.fa) for tj in (range(G.fb) if ti % 2 == 0 or not sched["snake"] else range(G.fb - 1, -1, -1))]
     for m, (ti, tj) in enumerate(order):
         lines.append(mfma(A, B, ti, tj, setp))
         for f in fill[m]:
@@ -175,14 +200,14 @@ def stream(a_mode, b_mode, sched):
         sg = S_G[op.w]
         L += [f"s_mov_b32 s{sg}, %[g{op.w}lo]", f"s_mov_b32 s{sg + 1}, %[g{op.w}hi]", f"s_mov_b32 s{S_NEXT[op.w]}, 0",
               f"s_lshr_b32 s{S_LIM[op.w]}, %[nkt], 1" if op.mode == "kc64" else f"s_mov_b32 s{S_LIM[op.w]}, %[nkt]"]
-    L += [f"s_lshr_b32 s{S_CNT}, %[nkt], 2"]
+    L += [f"s_lshr_b32 s{S_CNT}, %[nkt], 2"] if G.trip == 4 else [f"s_mov_b32 s{S_CNT}, %[ntrips]"]
     for op in (A, B):
         if op.mode == "ks":                      # per-block LDS addresses: base + ((t ^ hh) << 5)
-            vb = V_KS[op.w]
-            for t in range(8):
+            vb = G.v_ks[op.w]
+            for t in range(op.nfrag):
                 L += [f"v_xor_b32 v{vb + t}, {t}, %[h{op.w}]", f"v_lshl_add_u32 v{vb + t}, v{vb + t}, 5, %[r{op.w}0]"]
     # prologue requests (tile 0's data first), accumulators zeroed underneath
-    zero = [f"v_accvgpr_write_b32 a{i}, 0" for i in range(256)]
+    zero = [f"v_accvgpr_write_b32 a{i}, 0" for i in range(4 * G.nm)]
     zi = 0
     # in the order the steady state would have issued them during tiles -3, -2, -1 (the loop body's wait counts assume it)
     units = [(op, u) for t in (-3, -2, -1) for op in (A, B) for u in op.units_requested_in_tile(t) if u >= 0]
@@ -201,8 +226,8 @@ def stream(a_mode, b_mode, sched):
     trips = []
     for trip in range(3):
         body, counts = [], []
-        for u in range(4):
-            lines, n = tile_body(A, B, 4 * trip + u, sched, issue)
+        for u in range(G.trip):
+            lines, n = tile_body(A, B, G.trip * trip + u, sched, issue)
             body += lines
             counts.append(n)
         trips.append((body, counts))
@@ -228,16 +253,44 @@ def check_scc(L):
 
 def clobbers():
     c = ['"memory"', '"vcc"', '"scc"']
-    c += [f'"v{i}"' for i in range(V_KS["a"], 256)]
+    c += [f'"v{i}"' for i in range(G.vlo, G.vhi)]
     c += [f'"s{i}"' for i in range(S_G["a"], S_LAST + 1)]
     return ", ".join(c)
 
 
 SCHED = {"read_span": 40, "dma_first": 4, "dma_step": 6, "snake": True}
+SCHED_B16 = {"read_span": 24, "dma_first": 2, "dma_step": 3, "snake": True}
+
+
+def main_b16(args):
+    """gemm_b16_loop.inc: A k-contiguous (two 64-k slots), B k-strided (forward) or k-contiguous (dgrad, 32-k ring)"""
+    global G
+    G = GEOMS["b16"]
+    sched = dict(SCHED_B16)
+    if args.read_span != SCHED["read_span"]: sched["read_span"] = args.read_span
+    if args.dma_first != SCHED["dma_first"]: sched["dma_first"] = args.dma_first
+    if args.dma_step != SCHED["dma_step"]: sched["dma_step"] = args.dma_step
+    sched["snake"] = not args.no_snake
+    out = args.out.replace("gemm_a16_loop.inc", "gemm_b16_loop.inc")
+    txt = ["// GENERATED by tools/gen_gemm_a16.py --geom b16 -- do not edit; the generator is the source (design notes in its docstring and in Geom).",
+           f"// schedule: {sched}", ""]
+    for b_kc in (True, False):
+        name = f"NEKO_B16_LOOP_KC_{'KC' if b_kc else 'KS'}"
+        L, counts, n0 = stream("kc64", "kc32" if b_kc else "ks", sched)
+        txt.append(f"// {name}: vmcnt at the prologue wait {n0}, at the {G.trip} tiles of a trip {counts}")
+        txt.append(f"#define {name} \\")
+        txt += [f'  "{ins}\\n\\t" \\' for ins in L[:-1]]
+        txt.append(f'  "{L[-1]}"')
+        txt.append("")
+    txt.append(f"#define NEKO_B16_CLOBBERS {clobbers()}")
+    txt.append("")
+    open(out, "w").write("\n".join(txt))
+    print(out, sum(len(t) for t in txt), "bytes")
 
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--geom", default="a16", choices=tuple(GEOMS), help="workgroup geometry (see Geom)")
     ap.add_argument("--kc", type=int, default=64, choices=(32, 64), help="layout of a k-contiguous A operand")
     ap.add_argument("--kcb", type=int, default=32, choices=(0, 32, 64),
                     help="layout of a k-contiguous B operand (0: same as --kc).  Default 32: with both operands in two 64-k slots every DMA piece "
@@ -250,6 +303,8 @@ def main():
     ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "neko_amd", "csrc",
                                                   "gemm_a16_loop.inc"))
     args = ap.parse_args()
+    if args.geom == "b16":
+        return main_b16(args)
     SCHED.update(read_span=args.read_span, dma_first=args.dma_first, dma_step=args.dma_step, snake=not args.no_snake)
     kc = f"kc{args.kc}"
     kcb = f"kc{args.kcb or args.kc}"
