@@ -322,6 +322,21 @@ long neko_patch_pos_add_bwd_det_ws_bytes(int P, int d);
 int neko_patch_pos_add_bwd_det(const float* dout, const int* hpos, const int* wpos, float* d_row_emb, float* d_col_emb,
                                int P, int d, int nrows, void* workspace, long ws_bytes, void* stream);
 
+/* ABI v17: the contended table gradients from HOST-sorted (key, row) pairs -- no device sort, no atomics, bit-reproducible.  The host
+ * builds the packing descriptors and draws the patch positions (gato/policy/gato_policy.py:195-432, gato/policy/embeddings.py:63-110), so
+ * it knows these keys and sorts them (stable, ascending; entries without a destination carry the key 0xFFFFF and come last).
+ *   neko_pack_embed_bwd_sorted: like neko_pack_embed_bwd, but d_pos / d_sep are fixed-order segment sums over (keys_sorted, idx_sorted)
+ *       [ntok entries]: key = local position of token idx, or pos_rows for a separator token; d_embed keeps fp32 atomics.
+ *   neko_patch_pos_add_bwd_sorted: like neko_patch_pos_add_bwd from (hkeys, hidx) / (wkeys, widx) [P entries each]. */
+long neko_pack_embed_bwd_sorted_ws_bytes(int ntok, int d);
+int neko_pack_embed_bwd_sorted(const int* desc, const long long* tokens, const float* dx, float* d_embed, float* d_pos, float* d_sep,
+                               float* d_img, int ntok, int d, int pos_rows, const int* keys_sorted, const int* idx_sorted, void* workspace,
+                               long ws_bytes, void* stream);
+long neko_patch_pos_add_bwd_sorted_ws_bytes(int P, int d);
+int neko_patch_pos_add_bwd_sorted(const float* dout, const int* hkeys_sorted, const int* hidx_sorted, const int* wkeys_sorted,
+                                  const int* widx_sorted, float* d_row_emb, float* d_col_emb, int P, int d, int nrows, void* workspace,
+                                  long ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

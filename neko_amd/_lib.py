@@ -61,6 +61,10 @@ SIGNATURES = {
     "neko_patch_resblock_bwd_stats": [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
                                       _vp, _vp],
     "neko_patch_resblock_bwd_ws_floats": [_i],
+    "neko_pack_embed_bwd_sorted_ws_bytes": [_i, _i],
+    "neko_pack_embed_bwd_sorted": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _l, _vp],
+    "neko_patch_pos_add_bwd_sorted_ws_bytes": [_i, _i],
+    "neko_patch_pos_add_bwd_sorted": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _l, _vp],
     "neko_patch_pos_add": [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "neko_patch_pos_add_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "neko_abi_version": [],
@@ -94,6 +98,8 @@ def load() -> C.CDLL:
     lib.neko_gemm_colsum_ws_floats.restype = C.c_long
     lib.neko_pack_embed_bwd_det_ws_bytes.restype = C.c_long
     lib.neko_patch_pos_add_bwd_det_ws_bytes.restype = C.c_long
+    lib.neko_pack_embed_bwd_sorted_ws_bytes.restype = C.c_long
+    lib.neko_patch_pos_add_bwd_sorted_ws_bytes.restype = C.c_long
     lib.neko_status_string.argtypes = [_i]
     lib.neko_status_string.restype = C.c_char_p
     _lib = lib

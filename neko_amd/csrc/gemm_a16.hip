@@ -11,7 +11,10 @@
 // 4 per loop trip) and whose epilogue is one of the compiled feature sets; everything else stays with gemm_glds.hip.
 #include <cstdlib>
 #include "gemm_epi.h"
-#include "gemm_a16_loop.inc"
+#ifndef NEKO_A16_LOOP_INC
+#define NEKO_A16_LOOP_INC "gemm_a16_loop.inc"      // (tools/probe/gemm_loop_ablation.sh builds timing-only variants of the stream)
+#endif
+#include NEKO_A16_LOOP_INC
 
 namespace {
 

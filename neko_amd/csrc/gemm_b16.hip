@@ -14,7 +14,10 @@
 // of the compiled epilogue feature sets; everything else stays with gemm_a16.hip / gemm_glds.hip.
 #include <cstdlib>
 #include "gemm_epi.h"
-#include "gemm_b16_loop.inc"
+#ifndef NEKO_B16_LOOP_INC
+#define NEKO_B16_LOOP_INC "gemm_b16_loop.inc"      // (tools/probe/gemm_loop_ablation.sh builds timing-only variants of the stream)
+#endif
+#include NEKO_B16_LOOP_INC
 
 namespace {
 

@@ -225,6 +225,21 @@ int neko_patch_resblock_bwd_stats(const float* x_patches, const float* gn_stats,
   return neko_patch_resblock_bwd_impl(x_patches, dy, P, w1, b1, gn_w, gn_b, w2, b2, mid_channels, num_groups, dw1, db1,
                                       dgn_w, dgn_b, dw2, db2, workspace, S(stream), gn_stats);
 }
+long neko_pack_embed_bwd_sorted_ws_bytes(int ntok, int d) { return neko_pack_embed_bwd_sorted_ws_bytes_impl(ntok, d); }
+int neko_pack_embed_bwd_sorted(const int* desc, const long long* tokens, const float* dx, float* d_embed, float* d_pos, float* d_sep,
+                               float* d_img, int ntok, int d, int pos_rows, const int* keys_sorted, const int* idx_sorted, void* workspace,
+                               long ws_bytes, void* stream) {
+  return neko_pack_embed_bwd_sorted_impl(desc, tokens, dx, d_embed, d_pos, d_sep, d_img, ntok, d, pos_rows,
+                                         reinterpret_cast<const unsigned*>(keys_sorted), idx_sorted, workspace, ws_bytes, S(stream));
+}
+long neko_patch_pos_add_bwd_sorted_ws_bytes(int P, int d) { return neko_patch_pos_add_bwd_sorted_ws_bytes_impl(P, d); }
+int neko_patch_pos_add_bwd_sorted(const float* dout, const int* hkeys_sorted, const int* hidx_sorted, const int* wkeys_sorted,
+                                  const int* widx_sorted, float* d_row_emb, float* d_col_emb, int P, int d, int nrows, void* workspace,
+                                  long ws_bytes, void* stream) {
+  return neko_patch_pos_add_bwd_sorted_impl(dout, reinterpret_cast<const unsigned*>(hkeys_sorted), hidx_sorted,
+                                            reinterpret_cast<const unsigned*>(wkeys_sorted), widx_sorted, d_row_emb, d_col_emb, P, d, nrows,
+                                            workspace, ws_bytes, S(stream));
+}
 int neko_patch_resblock_bwd_ws_floats(int P) {
   return neko_patch_resblock_bwd_blocks_impl(P) * neko_patch_resblock_ws_stride_impl();
 }

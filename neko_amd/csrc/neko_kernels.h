@@ -131,6 +131,16 @@ int neko_patch_pos_add_impl(float* out, const int* hpos, const int* wpos, const 
 size_t neko_segsum_ws_bytes_impl(int n, int d);
 int neko_segsum_rows_impl(const float* src, long ld_src, const unsigned* keys, int n, int d, float* out, long ld_out, int nrows,
                           float* extra, void* ws, size_t ws_bytes, hipStream_t s);
+size_t neko_segsum_sorted_ws_bytes_impl(int n, int d);
+int neko_segsum_rows_sorted_impl(const float* src, long ld_src, const unsigned* keys_sorted, const int* idx_sorted, int n, int d, float* out,
+                                 long ld_out, int nrows, float* extra, void* ws, size_t ws_bytes, hipStream_t s);
+long neko_pack_embed_bwd_sorted_ws_bytes_impl(int ntok, int d);
+int neko_pack_embed_bwd_sorted_impl(const int* desc, const long long* tokens, const float* dx, float* d_embed, float* d_pos, float* d_sep,
+                                    float* d_img, int ntok, int d, int pos_rows, const unsigned* keys_sorted, const int* idx_sorted,
+                                    void* ws, long ws_bytes, hipStream_t s);
+long neko_patch_pos_add_bwd_sorted_ws_bytes_impl(int P, int d);
+int neko_patch_pos_add_bwd_sorted_impl(const float* dout, const unsigned* hkeys, const int* hidx, const unsigned* wkeys, const int* widx,
+                                       float* d_row_emb, float* d_col_emb, int P, int d, int nrows, void* ws, long ws_bytes, hipStream_t s);
 long neko_pack_embed_bwd_det_ws_bytes_impl(int ntok, int d);
 int neko_pack_embed_bwd_det_impl(const int* desc, const long long* tokens, const float* dx, float* d_embed, float* d_pos, float* d_sep,
                                  float* d_img, int ntok, int d, int vocab_rows, int pos_rows, void* ws, long ws_bytes, hipStream_t s);

@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void pack_embed_bwd_kernel(PackBwdArgs a) {
   float* dst = nullptr;
   if ((kind >= K_TOKEN && kind <= K_DISC) || kind == K_DEVID) dst = a.d_embed + a.tokens[tok] * (long)a.d;
   else if (kind == K_SEP) dst = a.d_sep;
-  float* dpos = (pos >= 0) ? a.d_pos + (long)pos * a.d : nullptr;
+  float* dpos = (pos >= 0 && a.d_pos) ? a.d_pos + (long)pos * a.d : nullptr;      // null table: its sums are formed elsewhere
   float* dimg = (kind == K_IMAGE && a.d_img) ? a.d_img + (long)src * a.d : nullptr;
   if (dimg) {
     for (int c = lane * 4; c < a.d; c += 256) *reinterpret_cast<float4*>(dimg + c) = *reinterpret_cast<const float4*>(g + c);
@@ -191,6 +191,23 @@ int neko_pack_embed_bwd_impl(const int* desc, const long long* tokens, const flo
   hipLaunchKernelGGL(pack_embed_bwd_kernel, dim3((ntok + 3) / 4), dim3(256), 0, s, a);
   NEKO_CHECK_LAUNCH();
   return NEKO_OK;
+}
+
+// Round 5: the position-table and separator gradients -- the two heavily contended destinations (a local position row takes ~900 adds
+// per column in an m-mix step, the separator ~1500) -- as fixed-order segment sums over HOST-sorted (key, token) pairs: key = local
+// position, or pos_rows for a separator token (segsum's extra row); the embedding-table rows keep their atomics (their ids are only
+// known on the device for continuous values).  keys_sorted / idx_sorted hold ntok entries, NEKO_SEGSUM_KEY_NONE-padded at the end.
+long neko_pack_embed_bwd_sorted_ws_bytes_impl(int ntok, int d) { return ntok > 0 ? (long)neko_segsum_sorted_ws_bytes_impl(ntok, d) : 0; }
+int neko_pack_embed_bwd_sorted_impl(const int* desc, const long long* tokens, const float* dx, float* d_embed, float* d_pos, float* d_sep,
+                                    float* d_img, int ntok, int d, int pos_rows, const unsigned* keys_sorted, const int* idx_sorted,
+                                    void* ws, long ws_bytes, hipStream_t s) {
+  if (ntok <= 0) return NEKO_OK;
+  if (!desc || !tokens || !dx || !d_embed || !d_pos || !d_sep || !keys_sorted || !idx_sorted || !ws || (d & 3) || pos_rows <= 0) return NEKO_ERR_ARG;
+  if ((unsigned)pos_rows >= NEKO_SEGSUM_KEY_NONE) return NEKO_ERR_UNSUPPORTED;
+  PackBwdArgs a{reinterpret_cast<const int4*>(desc), tokens, dx, d_embed, nullptr, nullptr, d_img, ntok, d};
+  hipLaunchKernelGGL(pack_embed_bwd_kernel, dim3((ntok + 3) / 4), dim3(256), 0, s, a);
+  NEKO_CHECK_LAUNCH();
+  return neko_segsum_rows_sorted_impl(dx, d, keys_sorted, idx_sorted, ntok, d, d_pos, d, pos_rows, d_sep, ws, (size_t)ws_bytes, s);
 }
 
 long neko_pack_embed_bwd_det_ws_bytes_impl(int ntok, int d) {

@@ -785,6 +785,18 @@ int neko_patch_pos_add_bwd_impl(const float* dout, const int* hpos, const int* w
   return NEKO_OK;
 }
 
+// ... and from HOST-sorted (position, patch) pairs (round 5: the host draws the patch positions, embeddings.py:63-110, so it sorts them too)
+long neko_patch_pos_add_bwd_sorted_ws_bytes_impl(int P, int d) { return P > 0 ? (long)neko_segsum_sorted_ws_bytes_impl(P, d) : 0; }
+int neko_patch_pos_add_bwd_sorted_impl(const float* dout, const unsigned* hkeys, const int* hidx, const unsigned* wkeys, const int* widx,
+                                       float* d_row_emb, float* d_col_emb, int P, int d, int nrows, void* ws, long ws_bytes, hipStream_t s) {
+  if (P <= 0) return NEKO_OK;
+  if (!dout || !hkeys || !hidx || !wkeys || !widx || !d_row_emb || !d_col_emb || !ws || nrows <= 0) return NEKO_ERR_ARG;
+  if ((unsigned)nrows >= NEKO_SEGSUM_KEY_NONE) return NEKO_ERR_UNSUPPORTED;
+  int rc = neko_segsum_rows_sorted_impl(dout, d, hkeys, hidx, P, d, d_row_emb, d, nrows, nullptr, ws, (size_t)ws_bytes, s);
+  if (rc != NEKO_OK) return rc;
+  return neko_segsum_rows_sorted_impl(dout, d, wkeys, widx, P, d, d_col_emb, d, nrows, nullptr, ws, (size_t)ws_bytes, s);
+}
+
 long neko_patch_pos_add_bwd_det_ws_bytes_impl(int P, int d) { return P > 0 ? (long)neko_segsum_ws_bytes_impl(P, d) : 0; }
 // the same two gradients without atomics (segsum.hip): every table row is the sum of its patches' rows in patch order
 int neko_patch_pos_add_bwd_det_impl(const float* dout, const int* hpos, const int* wpos, float* d_row_emb, float* d_col_emb, int P,

@@ -152,6 +152,32 @@ size_t neko_segsum_ws_bytes_impl(int n, int d) {
   return align256((size_t)n * 4) * 3 + align256(nch * sizeof(ChunkMeta)) + align256(nch * 2 * (size_t)d * 4) + align256(sort_temp_bytes(n));
 }
 
+// The same sums for entries that arrive ALREADY SORTED by key (round 5: the host builds the packing descriptors and draws the patch
+// positions, so it can sort those keys itself -- numpy's stable sort of 65536 16-bit keys is under a millisecond -- and the device-side
+// radix sort with its half-dozen launches drops out): keys_sorted ascending with KEY_NONE entries last, idx_sorted the source rows,
+// ties in source order.  Bit-identical to neko_segsum_rows_impl on the unsorted pairs.
+size_t neko_segsum_sorted_ws_bytes_impl(int n, int d) {
+  if (n <= 0) return 0;
+  const size_t nch = (size_t)(n + SEG_CH - 1) / SEG_CH;
+  return align256(nch * sizeof(ChunkMeta)) + align256(nch * 2 * (size_t)d * 4);
+}
+int neko_segsum_rows_sorted_impl(const float* src, long ld_src, const unsigned* keys_sorted, const int* idx_sorted, int n, int d, float* out,
+                                 long ld_out, int nrows, float* extra, void* ws, size_t ws_bytes, hipStream_t s) {
+  if (n <= 0) return NEKO_OK;
+  if (!src || !keys_sorted || !idx_sorted || !out || !ws || (d & 3) || (ld_src & 3) || (ld_out & 3)) return NEKO_ERR_ARG;
+  if (ws_bytes < neko_segsum_sorted_ws_bytes_impl(n, d)) return NEKO_ERR_ARG;
+  const int nch = (n + SEG_CH - 1) / SEG_CH;
+  char* w = static_cast<char*>(ws);
+  ChunkMeta* meta = reinterpret_cast<ChunkMeta*>(w);                w += align256((size_t)nch * sizeof(ChunkMeta));
+  float* part = reinterpret_cast<float*>(w);
+  hipLaunchKernelGGL(segsum_chunk_kernel, dim3(nch), dim3(64), 0, s, src, ld_src, keys_sorted, idx_sorted, n, d, out, ld_out, nrows, extra,
+                     meta, part);
+  NEKO_CHECK_LAUNCH();
+  hipLaunchKernelGGL(segsum_chain_kernel, dim3(nch, 2), dim3(64), 0, s, meta, part, nch, d, out, ld_out, nrows, extra);
+  NEKO_CHECK_LAUNCH();
+  return NEKO_OK;
+}
+
 // out[keys[i], :] += src[i, :] in index order; keys[i] == nrows goes to `extra` (may be null if no such key), KEY_NONE entries are skipped.
 // d % 4 == 0, rows 16-B aligned.  `keys` is not modified.
 int neko_segsum_rows_impl(const float* src, long ld_src, const unsigned* keys, int n, int d, float* out, long ld_out, int nrows,

@@ -407,8 +407,34 @@ def pack_embed_fwd(desc, cont_vals, disc_vals, img_emb, embed, pos_embed, sep, n
 SCATTER_DET = os.environ.get("NEKO_DETERMINISTIC", "0") == "1"
 
 
-def pack_embed_bwd(desc, tokens, dx, d_embed, d_pos, d_sep, d_img, ntok, d):
+#: The position-table / separator gradients of the packing backward and the patch-position table gradients as fixed-order segment sums
+#: over HOST-sorted (key, row) pairs (neko_pack_embed_bwd_sorted / neko_patch_pos_add_bwd_sorted, ABI v17) instead of fp32 atomics on a
+#: few dozen heavily contended rows; NEKO_SORTED_SCATTER=0 returns to the atomics.
+SORTED_SCATTER = os.environ.get("NEKO_SORTED_SCATTER", "1") != "0"
+SEGSUM_KEY_NONE = 0xFFFFF
+
+
+def sorted_pairs(keys):
+    """numpy int array of destination rows (negative: none) -> (keys_sorted, idx_sorted) int32, stable ascending, entries without a
+    destination last with the key SEGSUM_KEY_NONE -- the input format of the *_sorted backward entry points."""
+    import numpy as np
+    k = np.where(keys < 0, SEGSUM_KEY_NONE, keys).astype(np.int32)
+    order = np.argsort(k.astype(np.int16) if k.max(initial=0) < 32767 else k, kind="stable").astype(np.int32)
+    return k[order], order
+
+
+def pack_embed_bwd(desc, tokens, dx, d_embed, d_pos, d_sep, d_img, ntok, d, sorted_tail=False):
+    """sorted_tail: `desc` holds, behind its ntok x 4 descriptors, ntok sorted keys and ntok row indices (sorted_pairs of the local
+    position, or d_pos.shape[0] for a separator token): position / separator gradients then come from fixed-order segment sums."""
     _chk(dx, torch.float32, "dx")
+    if sorted_tail and SORTED_SCATTER and not SCATTER_DET and d_pos.shape[0] < SEGSUM_KEY_NONE:
+        assert desc.numel() >= 6 * ntok and desc.dtype == torch.int32 and desc.is_contiguous()
+        n = int(_lib.load().neko_pack_embed_bwd_sorted_ws_bytes(ntok, d))
+        ws = torch.empty(n, dtype=torch.uint8, device=dx.device)
+        flat = desc.view(-1)
+        _lib.call("neko_pack_embed_bwd_sorted", _p(desc), _p(tokens), _p(dx), _p(d_embed), _p(d_pos), _p(d_sep), _p(d_img), ntok, d,
+                  int(d_pos.shape[0]), _p(flat[4 * ntok:]), _p(flat[5 * ntok:]), _p(ws), n, _stream())
+        return
     if SCATTER_DET and d_embed.shape[0] < 0xFFFFF and d_pos.shape[0] < 0xFFFFF:
         n = int(_lib.load().neko_pack_embed_bwd_det_ws_bytes(ntok, d))
         ws = torch.empty(n, dtype=torch.uint8, device=dx.device)
@@ -548,8 +574,16 @@ def patch_pos_add(out, hpos, wpos, row_emb, col_emb):
     _lib.call("neko_patch_pos_add", _p(out), _p(hpos), _p(wpos), _p(row_emb), _p(col_emb), P, d, _stream())
 
 
-def patch_pos_add_bwd(dout, hpos, wpos, d_row, d_col):
+def patch_pos_add_bwd(dout, hpos, wpos, d_row, d_col, sorted_rows=None):
+    """sorted_rows: int32 [4, P] = (sorted hpos, their patch indices, sorted wpos, their patch indices) from sorted_pairs, or None"""
     P, d = dout.shape
+    if sorted_rows is not None and SORTED_SCATTER and not SCATTER_DET and P > 0 and d_row.shape[0] < SEGSUM_KEY_NONE:
+        assert sorted_rows.dtype == torch.int32 and sorted_rows.shape == (4, P) and sorted_rows.is_contiguous()
+        n = int(_lib.load().neko_patch_pos_add_bwd_sorted_ws_bytes(P, d))
+        ws = torch.empty(n, dtype=torch.uint8, device=dout.device)
+        _lib.call("neko_patch_pos_add_bwd_sorted", _p(dout), _p(sorted_rows[0]), _p(sorted_rows[1]), _p(sorted_rows[2]), _p(sorted_rows[3]),
+                  _p(d_row), _p(d_col), P, d, int(d_row.shape[0]), _p(ws), n, _stream())
+        return
     if SCATTER_DET and P > 0:
         n = int(_lib.load().neko_patch_pos_add_bwd_det_ws_bytes(P, d))
         ws = torch.empty(n, dtype=torch.uint8, device=dout.device)

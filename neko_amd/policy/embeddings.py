@@ -65,7 +65,7 @@ class PatchPosEncoding(nn.Module):
 
 class _ImageEmbedFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, mod: "ImageEmbedding", images, hpos, wpos, *params):
+    def forward(ctx, mod: "ImageEmbedding", images, hpos, wpos, sorted_rows, *params):
         f = mod._flat
         pre = mod._prefix
         need = any(ctx.needs_input_grad)
@@ -84,7 +84,7 @@ class _ImageEmbedFn(torch.autograd.Function):
         if mod.use_pos_encoding:
             ops.patch_pos_add(out, hpos, wpos, f.view(pre + "patch_pos_encoding.height_pos_embedding.weight"),
                               f.view(pre + "patch_pos_encoding.width_pos_embedding.weight"))
-        ctx.mod, ctx.y16_all, ctx.xp, ctx.hpos, ctx.wpos, ctx.gn_stats = mod, y16_all, xp, hpos, wpos, stats
+        ctx.mod, ctx.y16_all, ctx.xp, ctx.hpos, ctx.wpos, ctx.gn_stats, ctx.sorted_rows = mod, y16_all, xp, hpos, wpos, stats, sorted_rows
         return out
 
     @staticmethod
@@ -97,7 +97,7 @@ class _ImageEmbedFn(torch.autograd.Function):
         P, d = g.shape
         if mod.use_pos_encoding:
             ops.patch_pos_add_bwd(g, ctx.hpos, ctx.wpos, f.gview(pre + "patch_pos_encoding.height_pos_embedding.weight"),
-                                  f.gview(pre + "patch_pos_encoding.width_pos_embedding.weight"))
+                                  f.gview(pre + "patch_pos_encoding.width_pos_embedding.weight"), sorted_rows=ctx.sorted_rows)
         # rows P .. Ppad of both operands of the weight gradient are zero (ops.patch_resblock_fwd pads y16's storage the same way)
         y16_all = ctx.y16_all                       # the zero-padded storage the forward's y16 is a row prefix of
         Ppad = y16_all.shape[0]
@@ -177,7 +177,7 @@ class ImageEmbedding(nn.Module):
         hpos = hp.to(torch.int32).view(1, nh, 1).expand(n, nh, nw).reshape(-1).contiguous().to(dev, non_blocking=True)
         wpos = wp.to(torch.int32).view(1, 1, nw).expand(n, nh, nw).reshape(-1).contiguous().to(dev, non_blocking=True)
         params = [self._flat.param_of[nm] for nm in self.used_param_names(self._prefix)]
-        out = _ImageEmbedFn.apply(self, x, hpos, wpos, *params)
+        out = _ImageEmbedFn.apply(self, x, hpos, wpos, None, *params)
         return out.view(n, nh * nw, self.embed_dim)
 
     def _upload(self, t: torch.Tensor, dev) -> torch.Tensor:
@@ -220,8 +220,14 @@ class ImageEmbedding(nn.Module):
                 X = self._upload(on_cpu[0] if len(on_cpu) == 1 else torch.cat(on_cpu, dim=0), dev)
             else:
                 X = on_dev[0] if len(on_dev) == 1 else torch.cat(on_dev, dim=0)
-            pos = np.stack([np.concatenate([prepared[i][1] for i in idxs]), np.concatenate([prepared[i][2] for i in idxs])])
-            pos = self._upload(torch.from_numpy(np.ascontiguousarray(pos)), dev)
+            hp_all, wp_all = np.concatenate([prepared[i][1] for i in idxs]), np.concatenate([prepared[i][2] for i in idxs])
+            rows = [hp_all, wp_all]
+            if torch.is_grad_enabled() and ops.SORTED_SCATTER:
+                # rows 2..5: the position indices sorted on the host with the patches they belong to -- the backward's table
+                # gradients are then fixed-order segment sums instead of atomics (ops.patch_pos_add_bwd)
+                rows += [*ops.sorted_pairs(hp_all), *ops.sorted_pairs(wp_all)]
+            pos = np.stack(rows)
+            pos = self._upload(torch.from_numpy(np.ascontiguousarray(pos.astype(np.int32))), dev)
             out.append((X, pos, list(idxs), [prepared[i][3] for i in idxs]))
         return out
 
@@ -231,7 +237,7 @@ class ImageEmbedding(nn.Module):
         params = [self._flat.param_of[nm] for nm in self.used_param_names(self._prefix)]
         outs = [None] * n_examples
         for X, pos, idxs, counts in groups:
-            out = _ImageEmbedFn.apply(self, X, pos[0], pos[1], *params)
+            out = _ImageEmbedFn.apply(self, X, pos[0], pos[1], (pos[2:6] if pos.shape[0] >= 6 else None), *params)
             for i, o in zip(idxs, torch.split(out, counts, dim=0)):
                 outs[i] = o
         return outs

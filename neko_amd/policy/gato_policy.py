@@ -556,7 +556,17 @@ class GatoPolicy(nn.Module):
                                "embed_token never receive gradients (GradReducer.declare_unused_rows)")
         pr = _Prepared()
         pr.B, pr.T = pb.B, pb.T
-        pr.desc = self.image_embedding._upload(torch.from_numpy(pb.desc), dev)
+        # behind the descriptors: the (local position | separator) destinations of the packing backward, sorted on the host
+        # (ops.sorted_pairs; _PackEmbedV2.backward hands them to neko_pack_embed_bwd_sorted) -- one flat int32 tensor of 6 ints per row
+        M = pb.desc.shape[0]
+        if torch.is_grad_enabled() and ops.SORTED_SCATTER:
+            kind, pos = pb.desc[:, 0], pb.desc[:, 2]
+            pos_rows = self.pos_embed_observation.weight.shape[0]
+            key = np.where(kind == K_SEP, pos_rows, np.where((pos >= 0) & (kind != K_PAD) & (pos < pos_rows), pos, -1))
+            ks, ix = ops.sorted_pairs(key)
+        else:
+            ks, ix = np.full(M, ops.SEGSUM_KEY_NONE, np.int32), np.zeros(M, np.int32)
+        pr.desc = self.image_embedding._upload(torch.from_numpy(np.concatenate([pb.desc.reshape(-1), ks, ix])), dev)
         pr.cont = self._gather_values(pb.cont, torch.float32, dev)
         pr.disc = self._gather_values(pb.disc, torch.int32, dev)
         pr.img_order = list(pb.img_order)
@@ -798,7 +808,8 @@ class _PackEmbedV2(torch.autograd.Function):
         if ctx.img_rows > 0 and ctx.needs_input_grad[4]:
             d_img = torch.zeros(ctx.img_rows, d, dtype=torch.float32, device=gx.device)
         ops.pack_embed_bwd(ctx.desc, ctx.tokens, gx.view(-1, d), f.gview("embed_token.weight"),
-                           f.gview("pos_embed_observation.weight"), f.gview("separator_token"), d_img, ctx.ntok, d)
+                           f.gview("pos_embed_observation.weight"), f.gview("separator_token"), d_img, ctx.ntok, d,
+                           sorted_tail=ctx.desc.numel() >= 6 * ctx.ntok)
         f.attach_grads(names)
         if policy._dp is not None:
             policy._dp.group_ready("frontend")

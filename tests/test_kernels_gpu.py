@@ -882,6 +882,89 @@ def test_patch_pos_add_bwd_sorted_sums_are_exact_in_order_and_reproducible(ops, 
     close(dr, ref_r.float(), 1e-5, 3 * tol, "atomic row"); close(dc, ref_c.float(), 1e-5, 3 * tol, "atomic col")
 
 
+@pytest.mark.parametrize("P,d,nrows", [(12289, 768, 128), (500, 72, 37), (1, 768, 128), (4099, 2048, 128)])
+def test_patch_pos_add_bwd_host_sorted_equals_device_sorted(ops, P, d, nrows):
+    """ABI v17: the patch-position table gradients from HOST-sorted (position, patch) pairs (ops.sorted_pairs: numpy stable sort) are the
+    same fixed-order sums as the device-sorted ones of ABI v15 -- bit for bit, onto an existing gradient -- and match an fp64 reference."""
+    g = torch.Generator().manual_seed(P + 3 * d)
+    out = torch.randn(P, d, generator=g)
+    hp = torch.randint(0, nrows, (P,), generator=g, dtype=torch.int32)
+    wp = torch.randint(0, nrows, (P,), generator=g, dtype=torch.int32)
+    if P > 1000:
+        hp[: P // 2] = 1
+    base_r, base_c = torch.randn(nrows, d, generator=g), torch.randn(nrows, d, generator=g)
+    import numpy as np
+    rows = torch.from_numpy(np.stack([*ops.sorted_pairs(hp.numpy()), *ops.sorted_pairs(wp.numpy())]).astype(np.int32)).to(DEV)
+    prev_s, prev_d = ops.SORTED_SCATTER, ops.SCATTER_DET
+    try:
+        ops.SORTED_SCATTER, ops.SCATTER_DET = True, False
+        dr, dc = base_r.clone().to(DEV), base_c.clone().to(DEV)
+        ops.patch_pos_add_bwd(out.to(DEV), hp.to(DEV), wp.to(DEV), dr, dc, sorted_rows=rows)
+        ops.SCATTER_DET = True
+        er, ec = base_r.clone().to(DEV), base_c.clone().to(DEV)
+        ops.patch_pos_add_bwd(out.to(DEV), hp.to(DEV), wp.to(DEV), er, ec)
+    finally:
+        ops.SORTED_SCATTER, ops.SCATTER_DET = prev_s, prev_d
+    assert torch.equal(dr, er) and torch.equal(dc, ec)
+    ref_r = base_r.double().index_add_(0, hp.long(), out.double())
+    tol = 4e-6 * (P / 2 + 8) ** 0.5
+    close(dr, ref_r.float(), 1e-5, tol, "host-sorted pos bwd row")
+
+
+@pytest.mark.parametrize("ntok,d", [(4096, 768), (777, 64)])
+def test_pack_embed_bwd_host_sorted_position_and_separator_sums(ops, ntok, d):
+    """ABI v17 (neko_pack_embed_bwd_sorted): local-position and separator gradients of the packing backward as fixed-order segment sums
+    over host-sorted (key, token) pairs behind the descriptors; the embedding rows keep their atomics, image rows are copied.  Against
+    the deterministic ABI v15 path: d_pos / d_img bit-identical, d_sep and d_embed to summation-order noise; twice for bit reproducibility."""
+    import numpy as np
+    g = torch.Generator().manual_seed(ntok + d)
+    V, pos_rows, n_img = 3000, 64, ntok // 4
+    kind = torch.randint(0, 7, (ntok,), generator=g)                 # K_PAD .. K_IMAGE
+    kind[kind == 4] = 2
+    desc = torch.zeros(ntok, 4, dtype=torch.int32)
+    desc[:, 0] = kind.to(torch.int32)
+    desc[:, 2] = torch.randint(-1, pos_rows, (ntok,), generator=g).to(torch.int32)
+    desc[kind == 5, 2] = -1                                          # separators carry no local position (build_layout)
+    desc[kind == 0, 2] = -1
+    img = (kind == 6).nonzero().flatten()
+    desc[img, 1] = torch.arange(img.numel(), dtype=torch.int32) % max(n_img, 1)
+    img_rows = int(min(img.numel(), n_img))
+    if img.numel() > n_img:                                          # every image row is written once: keep the sources unique
+        desc[img[n_img:], 0] = 0
+        desc[img[n_img:], 2] = -1
+    tokens = torch.randint(0, V, (ntok,), generator=g)
+    tokens[: ntok // 3] = torch.randint(0, 8, (ntok // 3,), generator=g)      # contended embedding rows
+    dx = torch.randn(ntok, d, generator=g)
+    dn = desc.numpy()
+    key = np.where(dn[:, 0] == 5, pos_rows, np.where((dn[:, 2] >= 0) & (dn[:, 0] != 0), dn[:, 2], -1))
+    ks, ix = ops.sorted_pairs(key)
+    ext = torch.from_numpy(np.concatenate([dn.reshape(-1), ks, ix]).astype(np.int32)).to(DEV)
+
+    def run(sorted_tail, det):
+        prev_s, prev_d = ops.SORTED_SCATTER, ops.SCATTER_DET
+        try:
+            ops.SORTED_SCATTER, ops.SCATTER_DET = True, det
+            de = torch.ones(V, d, device=DEV); dp = torch.ones(pos_rows, d, device=DEV); ds = torch.ones(d, device=DEV)
+            di = torch.zeros(max(img_rows, 1), d, device=DEV)
+            ops.pack_embed_bwd(ext if sorted_tail else desc.to(DEV), tokens.to(DEV), dx.to(DEV), de, dp, ds, di, ntok, d, sorted_tail=sorted_tail)
+            return de, dp, ds, di
+        finally:
+            ops.SORTED_SCATTER, ops.SCATTER_DET = prev_s, prev_d
+    a, b, ref = run(True, False), run(True, False), run(False, True)
+    assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    assert torch.equal(a[1], ref[1]), "d_pos: host-sorted sums differ from the device-sorted ones"
+    # the separator run starts at another offset of the sorted array than in the ABI v15 call (there it follows the embedding rows), so
+    # its 32-entry chunks group the same addends differently: fixed order and reproducible, not bit-equal to that path
+    nsep = int((desc[:, 0] == 5).sum())
+    close(a[2], ref[2].cpu(), 1e-5, 4e-6 * (nsep + 8) ** 0.5, "d_sep")
+    close(a[2], (1.0 + dx[desc[:, 0] == 5].double().sum(0)).float(), 1e-5, 4e-6 * (nsep + 8) ** 0.5, "d_sep reference")
+    assert torch.equal(a[3], ref[3]), "d_img"
+    close(a[0], ref[0].cpu(), 1e-5, 4e-6 * (ntok / 3 / 8 + 8) ** 0.5, "d_embed (atomics) vs fixed-order sums")
+    emb_kind = torch.isin(kind, torch.tensor([1, 2, 3]))
+    want = torch.ones(V, d).double().index_add_(0, tokens[emb_kind & (desc[:, 0] != 0)], dx[emb_kind & (desc[:, 0] != 0)].double())
+    close(ref[0], want.float(), 1e-5, 4e-6 * (ntok / 3 / 8 + 8) ** 0.5, "d_embed reference")
+
+
 @pytest.mark.parametrize("drop_p", [0.0, 0.1])
 def test_attention_schedules_agree_at_metric_shape(ops, drop_p):
     """Head-resident and streaming kernels on the bench shape (32 x 1024 x 24 heads of 32, left padding on a third of the

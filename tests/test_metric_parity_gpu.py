@@ -39,7 +39,20 @@ def _dev_batch(batch):
 
 
 def _compare(cfg: O.OracleConfig, batch, seed: int, row_stride: int, loss_tol=1e-3, logit_tol=2e-2, gn_tol=2e-2,
-             total_tol=5e-3):
+             total_tol=5e-3, det=False):
+    """det: the embedding / patch-position table gradients through the fixed-order segment sums (what NEKO_DETERMINISTIC=1 selects)
+    instead of fp32 atomics -- at 24 layers the atomically summed patch-position parameters measured 0.9-1.4e-2 of their norm from run
+    to run (70 % of the 2e-2 gate); with the sorted sums the number is the same every run."""
+    from neko_amd import ops as _ops
+    prev_det = _ops.SCATTER_DET
+    _ops.SCATTER_DET = bool(det) or prev_det
+    try:
+        return _compare_impl(cfg, batch, seed, row_stride, loss_tol, logit_tol, gn_tol, total_tol)
+    finally:
+        _ops.SCATTER_DET = prev_det
+
+
+def _compare_impl(cfg, batch, seed, row_stride, loss_tol, logit_tol, gn_tol, total_tol):
     from neko_amd.policy.gato_policy import GatoPolicy
     torch.set_num_threads(max(1, min(64, torch.get_num_threads())))
     sd = O.init_state_dict(cfg, seed)
@@ -131,7 +144,7 @@ def test_c5_full_depth_24_layers_2048d_hd128_vs_oracle():
               "discrete_actions": torch.randint(0, 4, (2, 1), generator=g).to(torch.int32)}]
     # measured: loss 4e-5, logits 7e-3, worst per-parameter gradient norm 7e-3, total norm 4e-3 (24 layers of bf16-operand
     # rounding accumulate in the total: its gate is 1e-2 here, the others are the standard ones)
-    _compare(cfg, batch, seed=14, row_stride=5, total_tol=1e-2)
+    _compare(cfg, batch, seed=14, row_stride=5, total_tol=1e-2, det=True)
 
 
 def _control(n_obs, n_act, n_ts, g):
@@ -167,7 +180,7 @@ def test_c5_full_size_2048d_24L_T1024_V52305_vs_oracle():
     gradient norm 1e-2 (24 layers of bf16-operand rounding accumulate in it, as in the T = 201 case above)."""
     from neko_amd.tasks import synthetic as S
     cfg = O.OracleConfig(embed_dim=2048, layers=24, heads=16)
-    _compare(cfg, S.metric_mix_batch(1, 8, "cpu"), seed=17, row_stride=61, total_tol=1e-2)
+    _compare(cfg, S.metric_mix_batch(1, 8, "cpu"), seed=17, row_stride=61, total_tol=1e-2, det=True)
 
 
 def test_training_trace_100_steps_on_the_metric_model_vs_oracle():
@@ -223,3 +236,55 @@ def test_training_trace_100_steps_on_the_metric_model_vs_oracle():
     assert max(rel) < 1e-3, (max(rel), rel.index(max(rel)))
     assert max(reln[:5]) < 5e-3, reln[:5]
     assert sorted(reln)[len(reln) // 2] < 1.5e-2 and max(reln) < 1.2e-1, (sorted(reln)[len(reln) // 2], max(reln))
+
+
+def test_training_trace_20_steps_on_T1024_multimodal_batches_vs_oracle():
+    """the training trace of the metric's own model on the metric's own batches -- 768d x 6L x 24H, V = 52305,
+    `metric_mix_batch` (caption-like 256 patches + 767 ids + SEP, halfcheetah 42 x 24 left-padded, Atari 26 x 38 left-padded: T = 1024,
+    three sequences per step, five distinct batches) -- 20 optimisation steps with the reference recipe against `O.train_step` on the host.
+    Patch positions are the deterministic (eval-mode) ones on both sides (training mode draws them on the host RNG, embeddings.py:63-110),
+    dropout 0.  Gates: loss 1e-3 relative at every step (north_star), pre-clip gradient norm 5e-3 on the first five steps."""
+    from neko_amd.policy.gato_policy import GatoPolicy
+    from neko_amd.tasks import synthetic as S
+    from neko_amd.training.optim import NekoAdamW
+    from neko_amd.training.schedulers import get_linear_warmup_cosine_decay_scheduler
+    torch.set_num_threads(max(1, min(64, torch.get_num_threads())))
+    cfg = O.OracleConfig(embed_dim=768, layers=6, heads=24)
+    steps, warm, lr, init_lr, min_lr = 20, 5, 1e-4, 1e-6, 1e-5
+    sd = O.init_state_dict(cfg, 33)
+    m = GatoPolicy(DEV, 768, 6, 24, 0.0, resid_mid_channels=128, context_len=cfg.context_len, text_tokenizer=cfg.text_tokens)
+    m.transformer.drop.p = 0.0
+    m.load_state_dict(sd, strict=True)
+    m.eval()                       # deterministic patch positions; nothing else differs at dropout 0
+    opt = NekoAdamW(m, lr=lr, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.1)
+    sch = get_linear_warmup_cosine_decay_scheduler(opt, warm, steps, base_lr=lr, init_lr=init_lr, min_lr=min_lr)
+    NB = 5
+    batches = [S.metric_mix_batch(3, 100 + 7 * i, "cpu") for i in range(NB)]
+    dev_batches = [_dev_batch(b) for b in batches]
+    losses, norms, lrs = [], [], []
+    for step in range(steps):
+        lrs.append(float(sch.get_last_lr()[0]))
+        _, loss = m.forward(inputs=dev_batches[step % NB], compute_loss=True, return_logits=False)
+        loss.backward()
+        norms.append(opt.clip_grad_norm_(1.0))
+        opt.step()
+        sch.step()
+        opt.zero_grad()
+        losses.append(loss.detach())
+    losses = torch.stack(losses).cpu().tolist()
+    norms = torch.stack(norms).reshape(-1).cpu().tolist()
+    st = O.AdamWState(lr=lr)
+    ref_l, ref_n = [], []
+    for step in range(steps):
+        lr_t = lr * O.lr_ratio(step, warm, steps, lr, init_lr, min_lr)
+        assert abs(lr_t - lrs[step]) <= 1e-12 + 1e-9 * lr_t, (step, lr_t, lrs[step])
+        l, n = O.train_step(sd, cfg, st, batches[step % NB], lr_t, grad_norm_clip=1.0)
+        ref_l.append(l)
+        ref_n.append(n)
+    rel = [abs(a - b) / abs(b) for a, b in zip(losses, ref_l)]
+    reln = [abs(a - b) / abs(b) for a, b in zip(norms, ref_n)]
+    print(f"[trace T=1024 m-mix, 768d x 6L V=52305] loss {losses[0]:.4f} -> {losses[-1]:.4f} (oracle {ref_l[0]:.4f} -> {ref_l[-1]:.4f}); "
+          f"max rel loss dev {max(rel):.2e} at step {rel.index(max(rel))}; grad norm dev first five {max(reln[:5]):.2e}, max {max(reln):.2e}")
+    assert max(rel) < 1e-3, (max(rel), rel.index(max(rel)))
+    assert max(reln[:5]) < 5e-3, reln[:5]
+    assert max(reln) < 5e-2, max(reln)

@@ -237,7 +237,30 @@ def stream(a_mode, b_mode, sched):
     # surplus DMA landed, surplus fragment reads returned (their VGPRs go back to the compiler), accumulators readable
     L += ["s_waitcnt vmcnt(0)", "s_waitcnt lgkmcnt(0)", "s_nop 15", "s_nop 15", "s_barrier", f"s_mov_b32 m0, s{S_M0}"]
     check_scc(L)
-    return L, trips[1][1], n0
+    return ablate(L), trips[1][1], n0
+
+
+ABLATE = ""
+
+
+def ablate(L):
+    """timing-only variants of a finished stream (see --ablate)"""
+    if not ABLATE:
+        return L
+    out = []
+    in_loop = False
+    for ins in L:
+        if ins.startswith("LOOP_"):
+            in_loop = True
+        if ABLATE == "mfma" and ins.startswith("v_mfma"):
+            out.append("s_nop 0")
+        elif ABLATE == "dma" and in_loop and ins.startswith("global_load_lds"):
+            continue
+        elif ABLATE == "reads" and in_loop and ins.startswith("ds_read"):
+            continue
+        else:
+            out.append(ins)
+    return out
 
 
 def check_scc(L):
@@ -271,7 +294,7 @@ def main_b16(args):
     if args.dma_first != SCHED["dma_first"]: sched["dma_first"] = args.dma_first
     if args.dma_step != SCHED["dma_step"]: sched["dma_step"] = args.dma_step
     sched["snake"] = not args.no_snake
-    out = args.out.replace("gemm_a16_loop.inc", "gemm_b16_loop.inc")
+    out = args.out.replace("gemm_a16_loop.inc", "gemm_b16_loop.inc")          # (an explicit --out is taken as given)
     txt = ["// GENERATED by tools/gen_gemm_a16.py --geom b16 -- do not edit; the generator is the source (design notes in its docstring and in Geom).",
            f"// schedule: {sched}", ""]
     for b_kc in (True, False):
@@ -291,6 +314,10 @@ def main_b16(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--geom", default="a16", choices=tuple(GEOMS), help="workgroup geometry (see Geom)")
+    ap.add_argument("--ablate", default="", choices=("", "mfma", "dma", "reads"),
+                    help="timing-only streams (WRONG results) for tools/probe/gemm_loop_ablation.sh: 'mfma' replaces every MFMA by s_nop 0 "
+                         "(what the DMA + LDS-read traffic alone costs), 'dma' drops the in-loop DMA requests (matrix pipe + LDS reads alone), "
+                         "'reads' drops the fragment reads")
     ap.add_argument("--kc", type=int, default=64, choices=(32, 64), help="layout of a k-contiguous A operand")
     ap.add_argument("--kcb", type=int, default=32, choices=(0, 32, 64),
                     help="layout of a k-contiguous B operand (0: same as --kc).  Default 32: with both operands in two 64-k slots every DMA piece "
@@ -303,6 +330,8 @@ def main():
     ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "neko_amd", "csrc",
                                                   "gemm_a16_loop.inc"))
     args = ap.parse_args()
+    global ABLATE
+    ABLATE = args.ablate
     if args.geom == "b16":
         return main_b16(args)
     SCHED.update(read_span=args.read_span, dma_first=args.dma_first, dma_step=args.dma_step, snake=not args.no_snake)

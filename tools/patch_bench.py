@@ -23,4 +23,8 @@ def t(fn, name):
     e1.record(); torch.cuda.synchronize()
     print(f"{name}: {e0.elapsed_time(e1)*1e3/iters:.1f} us for {xp.shape[0]} patches")
 t(lambda: ops.patch_resblock_fwd(imgs, *[dev[n] for n in names], 128, 32), "resblock fwd")
-t(lambda: ops.patch_resblock_bwd(xp, dy, *[dev[n] for n in names], 128, 32, *[grads[n] for n in names]), "resblock bwd")
+t(lambda: ops.patch_resblock_bwd(xp, dy, *[dev[n] for n in names], 128, 32, *[grads[n] for n in names]), "resblock bwd (recomputes the GroupNorm statistics)")
+_, _, stats = ops.patch_resblock_fwd(imgs, *[dev[n] for n in names], 128, 32, want_stats=True)
+if stats is not None:
+    t(lambda: ops.patch_resblock_fwd(imgs, *[dev[n] for n in names], 128, 32, want_stats=True), "resblock fwd + statistics out")
+    t(lambda: ops.patch_resblock_bwd(xp, dy, *[dev[n] for n in names], 128, 32, *[grads[n] for n in names], stats=stats), "resblock bwd (statistics from the forward)")

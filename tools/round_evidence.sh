@@ -17,6 +17,10 @@ python3 bench.py --model gato-1.2b --workload m-mix --batch 64 --steps 4 --warmu
 # data-parallel path in a world of one (RCCL executes every collective): regression anchor for exposed_comm_ms_per_step, both payloads
 python3 bench.py --force-dp --no-cpu-baseline --steps 20 --warmup 5 > gpurun_out/${tag}_mmix_forcedp_fp32_bench.json 2>> gpurun_out/${tag}_bench.err
 NEKO_DP_PAYLOAD=bf16 python3 bench.py --force-dp --no-cpu-baseline --steps 20 --warmup 5 > gpurun_out/${tag}_mmix_forcedp_bf16_bench.json 2>> gpurun_out/${tag}_bench.err
+# ... and on configs[2] (c3: the configuration BASELINE names for data-parallel training; control-only, so the 50257 text rows of embed_token
+# are declared unused and leave the reduction), both payloads
+python3 bench.py --workload c3 --force-dp --no-cpu-baseline --steps 40 --warmup 10 > gpurun_out/${tag}_c3_forcedp_fp32_bench.json 2>> gpurun_out/${tag}_bench.err
+NEKO_DP_PAYLOAD=bf16 python3 bench.py --workload c3 --force-dp --no-cpu-baseline --steps 40 --warmup 10 > gpurun_out/${tag}_c3_forcedp_bf16_bench.json 2>> gpurun_out/${tag}_bench.err
 python3 bench.py --workload c5-mix --batch 32 --no-cpu-baseline > gpurun_out/${tag}_c5mix_pad_bench.json 2>> gpurun_out/${tag}_bench.err
 python3 bench.py --workload c5-mix --batch 32 --ragged-groups 4 --no-cpu-baseline > gpurun_out/${tag}_c5mix_rag4_bench.json 2>> gpurun_out/${tag}_bench.err
 NEKO_ATTN_VARLEN=0 python3 bench.py --workload c5-mix --batch 32 --ragged-groups 4 --no-cpu-baseline > gpurun_out/${tag}_c5mix_rag4_buckets_bench.json 2>> gpurun_out/${tag}_bench.err
