@@ -200,14 +200,16 @@ int neko_gemm_b16_try(const GemmArgs& a_in, int a_kstrided, int b_kstrided, int 
     // K <= 1536 (forward qkv, dgrad attention out), 16 LM-head logits (N > 16384)
     static const int rule = [] { const char* e = getenv("NEKO_GEMM_B16_RULE"); return e ? atoi(e) : 1; }();
     const long tiles = (long)(a.M / 128) * (a.N / 256);
-    if (tiles < 512) return 1;
+    // less than one round of workgroups (README batch sizes: 7680 rows x 768 columns = 180 tiles): every class -- the launch is a single
+    // partial round whatever the tile, and this loop runs it faster than gemm_glds.hip's 256 x 128 configuration (c2 5.92 -> 5.87 ms,
+    // c3 5.82 -> 5.76 per step, c4 level: profiles/r05_gemm_b16_ab.txt)
     int cls;
     if (f & F_RESID) cls = 1;
     else if (f & F_GELU) cls = 2;
     else if (f & F_GELUBWD) cls = 4;
     else if (a.N > 16384) cls = 16;
     else cls = a.K <= 1536 ? 8 : 0;
-    if (!(rule & cls)) return 1;
+    if (tiles >= 512 && !(rule & cls)) return 1;
   }
   a.epi_lock = 0;
   const int rc = dispatch_b16(a, !b_kstrided, f, s);
