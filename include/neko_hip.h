@@ -74,13 +74,17 @@ int neko_gemm_bf16(const uint16_t* A, long lda, int a_kstrided, const uint16_t* 
                    int accumulate, uint16_t* Cb, long ldcb, int splitk, int k_per_split, float* splitk_ws,
                    int drop_thr, unsigned drop_key, float drop_scale, int safe_transpose, void* stream);
 
-/* neko_gemm_bf16 has two main loops behind one contract.  The default one (neko_amd/csrc/gemm_glds.hip) serves every shape; the
+/* neko_gemm_bf16 has three main loops behind one contract.  The default one (neko_amd/csrc/gemm_glds.hip) serves every shape; the
  * long-contraction loop (neko_amd/csrc/gemm_a16.hip: 4 waves x 128 x 128 per wave on v_mfma_f32_16x16x32_bf16 with the accumulators
  * in AGPRs, instruction stream placed by hand) takes launches whose tiles are all interior 256 x 256 ones and whose contraction
- * range is a multiple of 128, where it measured faster (long K).  neko_gemm_set_mainloop(1) sends every launch it can serve to
- * the second loop, (0) none, (-1) returns to the built-in per-shape choice (also: environment NEKO_GEMM_A16=0/1); returns the
- * previous mode.  The choice never changes which products are summed into an output element; the two loops add them in a
- * different order (fp32).  (ABI v16; replaces v14's neko_gemm_set_persistent, whose kernel moved to tools/probe/) */
+ * range is a multiple of 128, where it measured faster (long K); the two-workgroups-per-CU loop (neko_amd/csrc/gemm_b16.hip, ABI v17:
+ * 128 x 256 per workgroup, 64 x 128 per wave, 128 accumulators, 80 KB of LDS, so that one workgroup's output phase runs under its
+ * CU-mate's main loop) takes launches with A k-contiguous, M % 128 == N % 256 == K % 384 == 0 whose output phase is long (the fp32
+ * residual epilogues) or that are smaller than one round of workgroups.  neko_gemm_set_mainloop(1) sends every launch it can serve
+ * to gemm_a16 (none to gemm_b16), (2) every launch it can serve to gemm_b16, (0) none to either, (-1) returns to the built-in
+ * per-shape choice (also: environment NEKO_GEMM_A16 / NEKO_GEMM_B16 = 0/1); returns the previous mode.  The choice never changes
+ * which products are summed into an output element; the loops add them in a different order (fp32).  (ABI v16; replaces v14's
+ * neko_gemm_set_persistent, whose kernel moved to tools/probe/) */
 int neko_gemm_set_mainloop(int mode);
 
 /* Backward of the MLP's first Linear + GELU in one launch (trajectory_gpt2.py:266,274: h = act(c_fc(x)); autograd's
@@ -143,7 +147,7 @@ int neko_layernorm_bwd_bf16dy(const uint16_t* dy, const float* x, const float* g
  *   hd in {32, 64, 128}.
  *   Two schedules compute the same sums: head-resident kernels (hd = 32, T <= 1024: one workgroup per (b, h) keeps
  *   the head's K/V or Q/dO in LDS) and streaming kernels (any T, hd).  neko_attn_set_path(0) = automatic (default: the
- *   head-resident backward in one pass above 256 positions, as two kernels below), (1) = always streaming, (2) / (3) =
+ *   head-resident backward in one pass for 256 < T <= 512, as two kernels otherwise -- round 5), (1) = always streaming, (2) / (3) =
  *   head-resident with the two-kernel (bit-reproducible) / the one-pass backward at every length; returns the previous
  *   mode (any other argument only queries).  Process-wide tuning knob.
  *   drop_mask (optional, only touched when drop_thr > 0): neko_attn_mask_dwords(B, T, H, hd) uint32 of device memory

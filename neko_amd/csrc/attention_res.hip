@@ -1298,8 +1298,12 @@ int neko_attn_bwd_res_impl(const bf16_t* qkv, const bf16_t* out, const bf16_t* d
   // one phase of at most 8 key blocks handed to 8 waves from the queue -- triangle sizes 1..8, half the waves idle at the end -- and
   // the two kernels are ahead: 42.7 vs 73.6 us at T = 128, 96 vs 118 at 256, 224 vs 206 at 384, 334 vs 285 at 512 (B = 64, 24 heads,
   // dropout 0.1); README-size steps (T = 240): c2 5.90 -> 5.75 ms, c3 5.95 -> 5.85; T = 494 (c4) stays with one pass (11.29 vs 11.56).
+  // Round 5: above 512 positions (two staging phases, eight waves, 64 registers of carried partial sums) the two kernels are ahead inside
+  // the step -- m-mix 64 x 1024: 36.41 -> 36.10 ms over three alternating rounds on one box, profiles/r05_attn_path_ab.txt (round 4
+  // measured them level) -- while the single-phase lengths keep the one-pass kernel (c4, T = 494: 11.1 vs 11.15-11.75 ms).  The metric's
+  // sequence length therefore runs the bit-reproducible form again.
   const int pm = neko_attn_path_mode();
-  if (pm == 3 || (pm != 2 && T > 256)) {
+  if (pm == 3 || (pm != 2 && T > 256 && T <= FUSED_Q)) {
     const int Tp = (T + 31) & ~31, Rmax = min(Tp, FUSED_Q);
     const size_t lds = (size_t)Rmax * (128 + 128 + 8) + FUSED_W * 2048 + 16 + 64;
     const float scale = 1.0f / sqrtf(32.0f);

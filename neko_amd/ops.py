@@ -203,8 +203,8 @@ def gemm_set_mainloop(mode: int) -> int:
 
 
 def attn_set_path(mode: int) -> int:
-    """0 = automatic (head-resident kernels when hd = 32 and T <= 1024; their backward in one pass above 256 positions, as two kernels
-    below), 1 = always the streaming kernels, 2 / 3 = head-resident with the two-kernel (bit-reproducible) / one-pass backward at
+    """0 = automatic (head-resident kernels when hd = 32 and T <= 1024; their backward in one pass for 256 < T <= 512, as two kernels
+    otherwise), 1 = always the streaming kernels, 2 / 3 = head-resident with the two-kernel (bit-reproducible) / one-pass backward at
     every length; returns the previous mode (neko_attn_set_path)."""
     return int(_lib.load().neko_attn_set_path(int(mode)))
 

@@ -127,7 +127,7 @@ class Op:
         """absolute unit indices requested during tile t of the steady state"""
         if self.mode == "kc64":
             return [(t + 3) >> 1] if t % 2 == 1 else []
-        return [t + 3]
+        return [t + RING_LEAD]
 
 
 def mfma(A, B, ti, tj, setp):
@@ -210,7 +210,7 @@ def stream(a_mode, b_mode, sched):
     zero = [f"v_accvgpr_write_b32 a{i}, 0" for i in range(4 * G.nm)]
     zi = 0
     # in the order the steady state would have issued them during tiles -3, -2, -1 (the loop body's wait counts assume it)
-    units = [(op, u) for t in (-3, -2, -1) for op in (A, B) for u in op.units_requested_in_tile(t) if u >= 0]
+    units = [(op, u) for t in range(-max(3, RING_LEAD), 0) for op in (A, B) for u in op.units_requested_in_tile(t) if u >= 0]
     for op, u in units:
         for setm0, req in op.pieces(u):
             L += [setm0, zero[zi], req] + zero[zi + 1:zi + 4]
@@ -241,6 +241,7 @@ def stream(a_mode, b_mode, sched):
 
 
 ABLATE = ""
+RING_LEAD = 3        # a ring stage is requested this many k-tiles ahead (--ring-lead 4: the 4-stage rings of a16 allow one more, see main)
 
 
 def ablate(L):
@@ -258,6 +259,8 @@ def ablate(L):
             continue
         elif ABLATE == "reads" and in_loop and ins.startswith("ds_read"):
             continue
+        elif ABLATE == "barrier" and in_loop and ins == "s_barrier" and not out[-1].startswith("s_nop"):
+            continue                       # (the barrier behind the loop's closing s_nops stays: the epilogue reuses the ring)
         else:
             out.append(ins)
     return out
@@ -314,10 +317,10 @@ def main_b16(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--geom", default="a16", choices=tuple(GEOMS), help="workgroup geometry (see Geom)")
-    ap.add_argument("--ablate", default="", choices=("", "mfma", "dma", "reads"),
+    ap.add_argument("--ablate", default="", choices=("", "mfma", "dma", "reads", "barrier"),
                     help="timing-only streams (WRONG results) for tools/probe/gemm_loop_ablation.sh: 'mfma' replaces every MFMA by s_nop 0 "
                          "(what the DMA + LDS-read traffic alone costs), 'dma' drops the in-loop DMA requests (matrix pipe + LDS reads alone), "
-                         "'reads' drops the fragment reads")
+                         "'reads' drops the fragment reads, 'barrier' the per-k-tile block barriers")
     ap.add_argument("--kc", type=int, default=64, choices=(32, 64), help="layout of a k-contiguous A operand")
     ap.add_argument("--kcb", type=int, default=32, choices=(0, 32, 64),
                     help="layout of a k-contiguous B operand (0: same as --kc).  Default 32: with both operands in two 64-k slots every DMA piece "
@@ -329,9 +332,14 @@ def main():
     ap.add_argument("--no-snake", action="store_true", help="row-major MFMA order instead of the serpentine one")
     ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "neko_amd", "csrc",
                                                   "gemm_a16_loop.inc"))
+    ap.add_argument("--ring-lead", type=int, default=3, choices=(3, 4),
+                    help="k-tiles of lead of the 32-k ring requests (a16 only: 4 = the stage of tile t, whose fragments were read during tile "
+                         "t - 1, is refilled with tile t + 4 during tile t -- probe, profiles/r05_gemm_ring_lead.txt)")
     args = ap.parse_args()
-    global ABLATE
+    global ABLATE, RING_LEAD
     ABLATE = args.ablate
+    RING_LEAD = args.ring_lead
+    assert RING_LEAD == 3 or args.geom == "a16"
     if args.geom == "b16":
         return main_b16(args)
     SCHED.update(read_span=args.read_span, dma_first=args.dma_first, dma_step=args.dma_step, snake=not args.no_snake)
