@@ -170,14 +170,22 @@ def time_more_kernels(B: int, Tlen: int, dropout: float):
     out.append({"kernel": "attention backward (one layer)", "ms_per_launch": ms, "achieved": 2.5 * fl / ms / 1e9,
                 "unit": "TFLOP/s", "frac": 2.5 * fl / ms / 1e9 / MFMA_PEAK_TFLOPS, "bound": "mfma"})
     a = torch.randn(M, d, device="cuda").to(torch.bfloat16)
-    for name, N, K in (("c_attn forward", 3 * d, d), ("c_fc forward + GELU", 4 * d, d), ("mlp c_proj forward", d, 4 * d)):
+    # the calls stack_forward makes: both projections with their bias + residual dropout + fp32 residual in / out
+    resid = torch.randn(M, d, device="cuda")
+    rdrop = ops.Drop(dropout, 54321) if dropout > 0 else None
+    for name, N, K in (("c_attn forward", 3 * d, d), ("attn c_proj forward (bias, dropout, fp32 residual)", d, d),
+                       ("c_fc forward + GELU", 4 * d, d), ("mlp c_proj forward (bias, dropout, fp32 residual)", d, 4 * d)):
         x = a if K == d else torch.randn(M, K, device="cuda").to(torch.bfloat16)
         w = (torch.randn(K, N, device="cuda") * 0.02).to(torch.bfloat16)
         bias = torch.zeros(N, device="cuda")
-        y = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
-        pre = torch.empty(M, N, dtype=torch.bfloat16, device="cuda") if "GELU" in name else None
-        act = (3 if engine.GELU_FACTOR else 1) if pre is not None else 0      # the call stack_forward makes
-        ms = _time_events(lambda: ops.gemm(x, w, M, N, K, b_kstrided=True, bias=bias, act=act, pre_out=pre, out_bf16=y))
+        if "c_proj" in name:
+            y32 = torch.empty(M, N, device="cuda")
+            ms = _time_events(lambda: ops.gemm(x, w, M, N, K, b_kstrided=True, bias=bias, resid=resid, out_f32=y32, drop=rdrop))
+        else:
+            y = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+            pre = torch.empty(M, N, dtype=torch.bfloat16, device="cuda") if "GELU" in name else None
+            act = (3 if engine.GELU_FACTOR else 1) if pre is not None else 0      # the call stack_forward makes
+            ms = _time_events(lambda: ops.gemm(x, w, M, N, K, b_kstrided=True, bias=bias, act=act, pre_out=pre, out_bf16=y))
         fl = 2.0 * M * N * K
         out.append({"kernel": f"gemm {name}", "shape_MNK": [M, N, K], "ms_per_launch": ms, "achieved": fl / ms / 1e9,
                     "unit": "TFLOP/s", "frac": fl / ms / 1e9 / MFMA_PEAK_TFLOPS, "bound": "mfma"})
