@@ -22,7 +22,7 @@ def main():
     ap.add_argument("--pad", type=int, default=0, help="left padding of every sequence")
     ap.add_argument("--only", default="")
     ap.add_argument("--drop", type=float, default=0.0, help="attention dropout probability")
-    ap.add_argument("--path", type=int, default=0, help="0 auto (head-resident when applicable; backward: one pass above 256 positions), 1 streaming, 2 / 3 head-resident with the two-kernel / one-pass backward")
+    ap.add_argument("--path", type=int, default=0, help="0 auto (head-resident when applicable; backward: one pass for 256 < T <= 512), 1 streaming, 2 / 3 head-resident with the two-kernel / one-pass backward")
     ap.add_argument("--no-mask", action="store_true", help="backward re-hashes the dropout decisions instead of reusing the forward's")
     ap.add_argument("--zero-pad-grad", action="store_true", help="dO = 0 on the padded rows (training: no loss reaches a padded position)")
     ap.add_argument("--mix-pad", action="store_true", help="left padding 0 / 16 / 36 on a third of the sequences each (the m-mix batch)")

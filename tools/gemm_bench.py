@@ -19,9 +19,11 @@ SHAPES = [
     ("fwd qkv   NN", M, 3 * D, D, False, True, "bias,bf16"),
     ("fwd proj  NN", M, D, D, False, True, "bias,resid,f32"),
     ("fwd fc    NN", M, 4 * D, D, False, True, "bias,gelu,bf16"),
+    ("fwd fc gp NN", M, 4 * D, D, False, True, "bias,gelugp,bf16"),
     ("fwd pr    NN", M, D, 4 * D, False, True, "bias,resid,f32"),
     ("fwd prdrop NN", M, D, 4 * D, False, True, "bias,resid,drop,f32"),
     ("dgrad pr  NT", M, 4 * D, D, False, False, "gelubwd,bf16"),
+    ("dgrad pr4 NT", M, 4 * D, D, False, False, "mulact,bf16"),
     ("dgrad fc  NT", M, D, 4 * D, False, False, "f32"),
     ("dgrad o   NT", M, D, D, False, False, "bf16"),
     ("dgrad fc16 NT", M, D, 4 * D, False, False, "bf16"),
@@ -54,6 +56,7 @@ def main():
     ap.add_argument("--safe", type=int, default=0)
     ap.add_argument("--sk", type=int, default=0, help="force this split-K factor on the split-K shapes")
     ap.add_argument("--dim", type=int, default=0, help="embed dim instead of 768 (2048 = the Gato-1.2B geometry)")
+    ap.add_argument("--digest", default="", help="write sha256 of every output of every shape to this file (A/B of two builds / switches: the files must be equal)")
     ap.add_argument("--rows", type=int, default=0, help="B*T rows instead of 32768 (README batch sizes: 7680 = 32 x 240)")
     args = ap.parse_args()
     if args.dim:
@@ -68,6 +71,7 @@ def main():
             shapes.append((name, args.rows if m == M else m, n, args.rows if k == M else k, aks, bks, ex))
         SHAPES[:] = shapes
     dev = "cuda"
+    torch.manual_seed(0)
     g = torch.Generator(device=dev).manual_seed(0)
     tot_us = 0.0
     for name, m, n, k, aks, bks, ex in SHAPES:
@@ -87,6 +91,12 @@ def main():
         if "gelu," in ex:
             kw["act"] = 1
             kw["pre_out"] = torch.empty(m, n, dtype=BF, device=dev)
+        if "gelugp" in ex:
+            kw["act"] = 3
+            kw["pre_out"] = torch.empty(m, n, dtype=BF, device=dev)
+        if "mulact" in ex:
+            kw["act"] = 4
+            kw["act_in"] = torch.randn(m, n, device=dev).to(BF)
         if "gelubwd" in ex:
             kw["act"] = 2
             kw["act_in"] = torch.randn(m, n, device=dev).to(BF)
@@ -107,6 +117,13 @@ def main():
             kw["accumulate"] = True
         for _ in range(3):
             ops.gemm(A, Bm, m, n, k, **kw)
+        if args.digest:
+            import hashlib
+            torch.cuda.synchronize()
+            with open(args.digest, "a") as fh:
+                for key in ("out_bf16", "out_f32", "pre_out"):
+                    if key in kw and not kw.get("accumulate"):
+                        fh.write(f"{name} {key} {hashlib.sha256(kw[key].view(torch.uint8).cpu().numpy().tobytes()).hexdigest()}\n")
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(args.iters):

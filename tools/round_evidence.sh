@@ -46,8 +46,8 @@ bash tools/pmc_attn.sh $tag 0.1 --B 64 > /dev/null 2>&1
 bash tools/pmc_attn.sh ${tag}_hd128 0.1 --B 8 --H 16 --hd 128 > /dev/null 2>&1
 python3 tools/gemm_bench.py --iters 30 > gpurun_out/${tag}_gemm_bench.txt 2>&1
 { echo "# B = 64, T = 1024, 24 heads of 32; 5 input sets cycled (HBM-cold operands); left padding 0 / 16 / 36 by thirds as in the m-mix batch, dO = 0 on padded rows"
-  echo "# one-pass backward (default), dropout 0.1 / 0"; python3 tools/attn_bench.py --B 64 --drop 0.1 --iters 30 --rotate 5 --mix-pad --zero-pad-grad; python3 tools/attn_bench.py --B 64 --iters 30 --rotate 5 --mix-pad --zero-pad-grad
-  echo "# two-kernel backward (--path 2), dropout 0.1 / 0"; python3 tools/attn_bench.py --B 64 --drop 0.1 --iters 30 --rotate 5 --mix-pad --zero-pad-grad --path 2 --only bwd; python3 tools/attn_bench.py --B 64 --iters 30 --rotate 5 --mix-pad --zero-pad-grad --path 2 --only bwd; } > gpurun_out/${tag}_attn_bench.txt 2>&1
+  echo "# default path (two-kernel backward above 512 positions), dropout 0.1 / 0"; python3 tools/attn_bench.py --B 64 --drop 0.1 --iters 30 --rotate 5 --mix-pad --zero-pad-grad; python3 tools/attn_bench.py --B 64 --iters 30 --rotate 5 --mix-pad --zero-pad-grad
+  echo "# one-pass backward (--path 3), dropout 0.1 / 0"; python3 tools/attn_bench.py --B 64 --drop 0.1 --iters 30 --rotate 5 --mix-pad --zero-pad-grad --path 3 --only bwd; python3 tools/attn_bench.py --B 64 --iters 30 --rotate 5 --mix-pad --zero-pad-grad --path 3 --only bwd; } > gpurun_out/${tag}_attn_bench.txt 2>&1
 { echo "# hd = 128 (configs[4]: 2048d x 16 heads), B = 8, T = 1024: DMA-ring kernels (attention_stream.hip), then the register-staged kernels they replace (--path 1)"
   python3 tools/attn_bench.py --B 8 --H 16 --hd 128 --iters 30; python3 tools/attn_bench.py --B 8 --H 16 --hd 128 --iters 30 --drop 0.1
   python3 tools/attn_bench.py --B 8 --H 16 --hd 128 --iters 30 --path 1; python3 tools/attn_bench.py --B 8 --H 16 --hd 128 --iters 30 --drop 0.1 --path 1
