@@ -36,7 +36,7 @@ extern "C" {
 #define NEKO_ERR_UNSUPPORTED (-2)
 #define NEKO_ERR_LAUNCH (-3)
 
-#define NEKO_ABI_VERSION 17
+#define NEKO_ABI_VERSION 18
 
 int neko_abi_version(void);
 /* human-readable text for a return code (static storage) */
@@ -150,12 +150,16 @@ int neko_layernorm_bwd_bf16dy(const uint16_t* dy, const float* x, const float* g
  *   head-resident backward in one pass for 256 < T <= 512, as two kernels otherwise -- round 5), (1) = always streaming, (2) / (3) =
  *   head-resident with the two-kernel (bit-reproducible) / the one-pass backward at every length; returns the previous
  *   mode (any other argument only queries).  Process-wide tuning knob.
+ *   neko_attn_bwd_reproducible(1 / 0) (ABI v18): the CALLING THREAD's backward calls use the two-kernel form at every length (0: follow
+ *   the knob); returns the previous value, any other argument only queries.  What NEKO_DETERMINISTIC=1 selects -- thread-local, so it
+ *   never changes the schedule of another thread's calls.
  *   drop_mask (optional, only touched when drop_thr > 0): neko_attn_mask_dwords(B, T, H, hd) uint32 of device memory
  *   (0 = the schedule in use does not exchange masks: pass null).  The forward stores its keep decisions there (scalar
  *   stores of the compares' lane masks) and the backward of the SAME forward call applies them instead of re-hashing
  *   every element in both of its kernels; with null both directions hash -- identical decisions either way.
  * ------------------------------------------------------------------------------------------- */
 int neko_attn_set_path(int mode);
+int neko_attn_bwd_reproducible(int on);
 
 /* Packed sequences of DIFFERENT lengths in one launch ("varlen": SURVEY 8(f) rank 3; removes the left-pad of
  * gato/policy/gato_policy.py:408-416 without one attention launch per length bucket).  Rows seq_off[b] .. seq_off[b+1]-1 of qkv /

@@ -783,6 +783,16 @@ static int g_attn_path = [] {              // NEKO_ATTN_PATH=0..3 sets the initi
   return v >= 0 && v <= 3 ? v : 0;
 }();
 int neko_attn_path_mode() { return g_attn_path; }
+// Calling thread's request for the bit-reproducible (two-kernel) head-resident backward at every length: thread-local, so a caller that
+// wants reproducible gradients never changes the schedule another thread's calls see (the process-wide knob was being
+// flipped around every backward call)
+static thread_local int t_bwd_reproducible = 0;
+int neko_attn_bwd_reproducible_mode() { return t_bwd_reproducible; }
+int neko_attn_bwd_reproducible_impl(int on) {
+  const int prev = t_bwd_reproducible;
+  if (on == 0 || on == 1) t_bwd_reproducible = on;
+  return prev;
+}
 int neko_attn_set_path_impl(int mode) {
   const int prev = g_attn_path;
   if (mode >= 0 && mode <= 3) g_attn_path = mode;

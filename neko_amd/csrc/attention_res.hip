@@ -20,6 +20,7 @@
 #include "neko_kernels.h"
 
 extern int neko_attn_path_mode();
+extern int neko_attn_bwd_reproducible_mode();
 
 namespace {
 
@@ -1207,7 +1208,7 @@ __global__ __launch_bounds__(FUSED_W * 64) void attn_bwd_fused_res_kernel(
         }
       }
     }
-    __syncthreads();                                         // every wave's ds_add_f32 has been issued and completed
+    __syncthreads();                                         // every wave's locked read-add-write of the dQ accumulator has completed
     // ---- dQ rows of the phase: fp32 accumulator -> bf16, scaled once ---------------------------------------------------------
     {
       const float qs = scale * (DROP ? drop_scale : 1.0f);
@@ -1302,7 +1303,7 @@ int neko_attn_bwd_res_impl(const bf16_t* qkv, const bf16_t* out, const bf16_t* d
   // the step -- m-mix 64 x 1024: 36.41 -> 36.10 ms over three alternating rounds on one box, profiles/r05_attn_path_ab.txt (round 4
   // measured them level) -- while the single-phase lengths keep the one-pass kernel (c4, T = 494: 11.1 vs 11.15-11.75 ms).  The metric's
   // sequence length therefore runs the bit-reproducible form again.
-  const int pm = neko_attn_path_mode();
+  const int pm = neko_attn_bwd_reproducible_mode() ? 2 : neko_attn_path_mode();       // (a thread's reproducibility request outranks the knob)
   if (pm == 3 || (pm != 2 && T > 256 && T <= FUSED_Q)) {
     const int Tp = (T + 31) & ~31, Rmax = min(Tp, FUSED_Q);
     const size_t lds = (size_t)Rmax * (128 + 128 + 8) + FUSED_W * 2048 + 16 + 64;

@@ -115,6 +115,7 @@ int neko_attn_bwd_varlen(const uint16_t* qkv, const uint16_t* out, const uint16_
                                 drop_mask, S(stream), seq_off, mask_off);
 }
 int neko_attn_set_path(int mode) { return neko_attn_set_path_impl(mode); }
+int neko_attn_bwd_reproducible(int on) { return neko_attn_bwd_reproducible_impl(on); }
 int neko_attn_bwd(const uint16_t* qkv, const uint16_t* out, const uint16_t* dout, const float* kbias,
                   const int* kstart, const float* lse, float* D, int* qflags, uint16_t* dqkv, int B, int T, int H,
                   int hd, int drop_thr, unsigned drop_key, float drop_scale, const uint32_t* drop_mask, void* stream) {

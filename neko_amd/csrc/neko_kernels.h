@@ -64,6 +64,7 @@ int neko_attn_bwd_impl(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout,
                        const float* lse, float* D, int* qflags, bf16_t* dqkv, int B, int T, int H, int hd,
                        int drop_thr, unsigned drop_key, float drop_scale, const uint32_t* dmask, hipStream_t s);
 int neko_attn_set_path_impl(int mode);
+int neko_attn_bwd_reproducible_impl(int on);
 bool neko_attn_res_applicable(int T, int hd);
 bool neko_attn_stream_applicable(int T, int hd);
 int neko_attn_bwd_stream_impl(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const float* kbias, const int* kstart,

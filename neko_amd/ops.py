@@ -302,20 +302,17 @@ def attn_fwd_varlen(qkv, kbias, kstart, geom: VarlenGeom, hd, drop=None, out=Non
 
 
 class _DetAttnPath:
-    """Under NEKO_DETERMINISTIC (SCATTER_DET) the head-resident attention backward runs as its two kernels (neko_attn_set_path(2)):
-    the one-pass form adds dQ up through LDS float atomics in arrival order, the two-kernel form is bit-reproducible."""
+    """Under NEKO_DETERMINISTIC (SCATTER_DET) the head-resident attention backward of THIS thread runs as its two kernels at every length
+    (neko_attn_bwd_reproducible, thread-local in the library: the process-wide schedule knob is not touched): the one-pass form adds dQ
+    up block by block in arrival order, the two-kernel form is bit-reproducible."""
 
     def __enter__(self):
-        self.prev = None
-        if SCATTER_DET:
-            self.prev = attn_set_path(2)
-            if self.prev == 1:                   # a forced streaming schedule stays
-                attn_set_path(1)
+        self.prev = int(_lib.load().neko_attn_bwd_reproducible(1)) if SCATTER_DET else None
         return self
 
     def __exit__(self, *exc):
-        if self.prev is not None and self.prev != 1:
-            attn_set_path(self.prev)
+        if self.prev is not None:
+            _lib.load().neko_attn_bwd_reproducible(self.prev)
         return False
 
 

@@ -1054,7 +1054,12 @@ def test_attention_varlen_equals_per_sequence_calls(ops):
     geom = ops.VarlenGeom(lengths, H, DEV)
     assert geom.rows == rows
     kb_all, ks_all = torch.cat(kbs), torch.cat(kss)
-    for path in (2, 0):        # 2: two-kernel backward, everything bit-equal; 0: one-pass backward, dQ added up in arrival order
+    # 2: two-kernel backward everywhere, everything bit-equal; 3: one-pass backward everywhere, dK / dV bit-equal and dQ added up in
+    # arrival order; 0 (automatic, round 5): the packed launch is sized by its longest sequence (1024 positions: two kernels) while a
+    # 512-position sequence alone takes the one-pass kernel -- the two forms round a partially padded key block's probabilities through
+    # different instruction sequences (fma against multiply + add), so a few elements sit one bf16 ulp apart
+    # (tools/probe/r05_attn_bwd_diff.py: 2 elements of one row at T = 512 with 40 padded keys)
+    for path in (2, 3, 0):
         prev = ops.attn_set_path(path)
         try:
             out, lse, _ = ops.attn_fwd_varlen(qkv, kb_all, ks_all, geom, hd)
@@ -1069,9 +1074,11 @@ def test_attention_varlen_equals_per_sequence_calls(ops):
                 if path == 2:
                     assert torch.equal(dqkv[r0:r0 + T], g1), f"dqkv of sequence {i}"
                 else:
-                    assert torch.equal(dqkv[r0:r0 + T, d:], g1[:, d:]), f"dK / dV of sequence {i}"
-                    dq_a, dq_b = dqkv[r0:r0 + T, :d].float(), g1[:, :d].float()
-                    assert float((dq_a - dq_b).abs().max()) <= 2 ** -7 * float(dq_b.abs().max()), f"dQ of sequence {i}"
+                    if path == 3:
+                        assert torch.equal(dqkv[r0:r0 + T, d:], g1[:, d:]), f"dK / dV of sequence {i}"
+                    for nm, sl in (("dQ", slice(0, d)), ("dK", slice(d, 2 * d)), ("dV", slice(2 * d, 3 * d))):
+                        ga, gb = dqkv[r0:r0 + T, sl].float(), g1[:, sl].float()
+                        assert float((ga - gb).abs().max()) <= 2 ** -7 * float(gb.abs().max()), f"{nm} of sequence {i} (path {path})"
                 r0 += T
         finally:
             ops.attn_set_path(prev)
@@ -1149,8 +1156,12 @@ def test_attention_varlen_dropout_masks_are_consistent(ops):
     drop = ops.Drop(0.1, 0xC0FFEE)
     out, lse, mk = ops.attn_fwd_varlen(qkv, kb, ks, geom, hd, drop=drop, want_mask=True)
     assert mk is not None and mk.numel() == geom.mask_dwords
-    g_mask = ops.attn_bwd_varlen(qkv, out, do, kb, ks, lse, geom, hd, drop=drop, mask=mk)
-    g_hash = ops.attn_bwd_varlen(qkv, out, do, kb, ks, lse, geom, hd, drop=drop, mask=None)
+    prev = ops.attn_set_path(3)                                  # (the automatic choice at 1024 positions is the two-kernel form since round 5)
+    try:
+        g_mask = ops.attn_bwd_varlen(qkv, out, do, kb, ks, lse, geom, hd, drop=drop, mask=mk)
+        g_hash = ops.attn_bwd_varlen(qkv, out, do, kb, ks, lse, geom, hd, drop=drop, mask=None)
+    finally:
+        ops.attn_set_path(prev)
     assert torch.equal(g_mask[:, d:], g_hash[:, d:])             # one-pass backward: dK / dV bit-equal, dQ to fp32 summation order
     assert float((g_mask[:, :d].float() - g_hash[:, :d].float()).abs().max()) <= 2 ** -7 * float(g_hash[:, :d].float().abs().max())
     prev = ops.attn_set_path(2)
@@ -1167,6 +1178,42 @@ def test_attention_varlen_dropout_masks_are_consistent(ops):
     assert float((out.float() - out0.float()).abs().mean()) < 0.35 * float(out0.float().abs().mean())
     out2, lse2, mk2 = ops.attn_fwd_varlen(qkv, kb, ks, geom, hd, drop=drop, want_mask=True)
     assert torch.equal(out, out2) and torch.equal(lse, lse2)
+
+
+def test_attention_backward_reproducible_switch_is_thread_local_and_selects_the_two_kernel_form(ops):
+    """neko_attn_bwd_reproducible (ABI v18; what NEKO_DETERMINISTIC sets around its backward calls): at a length whose automatic
+    backward is the one-pass kernel (T = 384) the calling thread gets the very bits of neko_attn_set_path(2), the process-wide knob is
+    left alone, and another thread still sees the automatic schedule (its switch reads 0)."""
+    import threading
+    from neko_amd import _lib
+    lib = _lib.load()
+    B, T, H, hd = 3, 384, 2, 32
+    d = H * hd
+    g = torch.Generator(device=DEV).manual_seed(384)
+    qkv = (torch.randn(B * T, 3 * d, device=DEV, generator=g) * 0.7).to(torch.bfloat16)
+    do = torch.randn(B * T, d, device=DEV, generator=g).to(torch.bfloat16)
+    kb, ks = ops.mask_bias(torch.ones(B, T, device=DEV))
+    drop = ops.Drop(0.1, 0xBEEF)
+    out, lse, mk = ops.attn_fwd(qkv, kb, ks, B, T, H, hd, drop=drop, want_mask=True)
+    knob = ops.attn_set_path(-1)
+    prev = ops.attn_set_path(2)
+    try:
+        want = ops.attn_bwd(qkv, out, do, kb, ks, lse, B, T, H, hd, drop=drop, mask=mk)
+    finally:
+        ops.attn_set_path(prev)
+    assert lib.neko_attn_bwd_reproducible(-1) == 0
+    prev_det, ops.SCATTER_DET = ops.SCATTER_DET, True
+    try:
+        got = [ops.attn_bwd(qkv, out, do, kb, ks, lse, B, T, H, hd, drop=drop, mask=mk) for _ in range(2)]
+    finally:
+        ops.SCATTER_DET = prev_det
+    assert torch.equal(got[0], want) and torch.equal(got[1], want)
+    assert lib.neko_attn_bwd_reproducible(-1) == 0 and ops.attn_set_path(-1) == knob        # restored / never touched
+    assert lib.neko_attn_bwd_reproducible(1) == 0
+    seen = []
+    t = threading.Thread(target=lambda: seen.append(int(lib.neko_attn_bwd_reproducible(-1))))
+    t.start(); t.join()
+    assert seen == [0] and lib.neko_attn_bwd_reproducible(0) == 1
 
 
 @pytest.mark.parametrize("T,hd,mask_kind", [(2048, 128, "left"), (1500, 64, "holes"), (4096, 128, "none"), (4100, 128, "left")])
