@@ -23,6 +23,10 @@ import time
 os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 # dmabuf IPC for RCCL / cross-process device memory: also read once, when the runtime initialises
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# HIP streams share this many hardware queues (default 4), and two streams on one queue serialise: with the compute stream, the
+# weight-gradient side stream, c10d's communication stream and RCCL's own streams, four were not enough at README batch sizes
+# (c3 with the reducer attached: 6.6 ms per step with 4 queues, 6.0-6.2 with 8; profiles/r05_hwq_matrix.txt)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import torch
 

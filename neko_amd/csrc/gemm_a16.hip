@@ -192,7 +192,11 @@ int neko_gemm_a16_try(const GemmArgs& a, int a_kstrided, int b_kstrided, hipStre
     const long tiles = (long)(a.M / 256) * (a.N / 256) * (a.splitk > 1 ? a.splitk : 1);
     if (klen < 1536) {
       const unsigned f = fast_epi_mask(a, true, to_ws, to_ws || a.Cf != nullptr);
-      if (!(f == F_CB || f == (F_BIAS | F_CB)) || tiles < 512) return 1;
+      // NEKO_GEMM_A16_RULE bit 0 (A/B runs): also the GELU forward epilogues (c_fc)
+      static const int rule = [] { const char* e = getenv("NEKO_GEMM_A16_RULE"); return e ? atoi(e) : 0; }();
+      const bool plain = f == F_CB || f == (F_BIAS | F_CB);
+      const bool gelu_fwd = (f & F_GELU) != 0 && (rule & 1);
+      if (!(plain || gelu_fwd) || tiles < 512) return 1;
     }
     // fewer 256 x 256 tiles than ~3/4 of the CUs (README batch sizes: 7680 rows x 768 columns = 90 tiles): gemm_glds.hip's smaller
     // tiles fill the chip better than this loop's faster k-tiles pay back (c2: 6.03 -> 6.16 ms per step with 90-tile launches)

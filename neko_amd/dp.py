@@ -15,6 +15,7 @@ Works with backend "gloo" on CPU tensors too (used by the world_size-2 CPU tests
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -22,7 +23,7 @@ import torch.distributed as dist
 
 
 class GradReducer:
-    def __init__(self, flat, bucket_bytes: int = 64 << 20, group=None, payload: str = "fp32", force_collectives: bool = False):
+    def __init__(self, flat, bucket_bytes: Optional[int] = None, group=None, payload: str = "fp32", force_collectives: bool = False):
         """payload: "fp32" (default: what DDP sends for the reference's fp32 master gradients) or "bf16" -- every bucket is
         rounded to bf16 into a staging buffer, summed over the ranks in bf16 and widened back into the fp32 gradient:
         half the bytes on each xGMI link (249 instead of 498 MB per step at 768d) for one extra rounding of each rank's
@@ -36,7 +37,14 @@ class GradReducer:
         self.flat = flat
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # One collective per contiguous live slice of a run: RCCL pipelines a large message itself, and every extra call is ~60 us of host
+        # time (c10d bookkeeping + an event pair + the wait) that README-size steps, whose host enqueue IS the step, pay in full --
+        # tools/probe/r05_dp_host_timers.py: 13.8 all-reduce calls per c3 step with 64 MB slices, 0.65 ms of host time.  NEKO_DP_BUCKET_MB
+        # (or bucket_bytes) restores an upper bound on the message size.
+        if bucket_bytes is None:
+            bucket_bytes = int(float(os.environ.get("NEKO_DP_BUCKET_MB", "4096")) * (1 << 20))
         self.bucket_elems = max(1, bucket_bytes // 4)
+        self._dirty_names: Dict[tuple, List[str]] = {}
         self.handles: List = []
         self.pending: Dict[str, bool] = {}
         self.grad_scale = torch.full((1,), 1.0 / self.world, dtype=torch.float32, device=flat.grad.device)
@@ -51,7 +59,6 @@ class GradReducer:
         #: all-reduce is issued: a transformer layer of the 768d model is 28 MB, and at README batch sizes (c3: 5.8 ms per step) every
         #: collective's fixed cost -- an RCCL launch, an event pair and a join of the weight-gradient side stream -- showed in the
         #: one-GPU anchor (6.89 ms with the reducer against 5.77 without it, profiles/r05_c3_forcedp_*).  NEKO_DP_MIN_RUN_MB=0: one per range.
-        import os
         self.min_run_elems = int(float(os.environ.get("NEKO_DP_MIN_RUN_MB", "64")) * (1 << 20)) // 4
         self._run: Optional[List[int]] = None          # [a, b) of the finished, not yet reduced contiguous ranges
 
@@ -132,27 +139,46 @@ class GradReducer:
         if self.model is not None and self.model._flat is not self.flat:
             raise RuntimeError("GradReducer: the model's flat parameter storage was rebuilt after attach() "
                                "(a .to() / .cuda() that really moved parameters); attach after the model is on its device")
+        # Weight gradients may still be running on the side stream (README-size steps).  The collective has to wait for them, the backward
+        # chain on the compute stream does not: the collective is issued with the side stream current (c10d orders its communication
+        # stream behind the current stream), after the side stream has been ordered behind everything enqueued on the compute stream so far
+        # (bias / LayerNorm gradients of the same range).  Round 4 joined the side stream into the compute stream here instead, which
+        # serialised the weight gradients with the chain at every reduce point.
+        import contextlib
+        issue_on = contextlib.nullcontext()
         if self.flat.grad.is_cuda:
             from .engine import SideStream
-            SideStream.join(self.flat.grad.device)      # weight gradients are produced on the side stream
+            side = SideStream.pending(self.flat.grad.device)
+            if side is not None and os.environ.get("NEKO_DP_JOIN_MAIN") == "1":      # round-4 behaviour, for A/B runs
+                SideStream.join(self.flat.grad.device)
+                side = None
+            if side is not None:
+                side.wait_stream(torch.cuda.current_stream(self.flat.grad.device))
+                issue_on = torch.cuda.stream(side)
         dirty = getattr(self.flat, "_dirty", None)
         if dirty is not None:       # a reduced slice may hold other ranks' gradients even if this rank never wrote it
-            dirty.update(n for n, (o, _, _) in self.flat.offsets.items() if a <= o < b)
-        for (la, lb) in self._live_ranges(a, b):
-            for s in range(la, lb, self.bucket_elems):
-                e = min(lb, s + self.bucket_elems)
-                g = self.flat.grad[s:e]
-                if self.payload == "bf16":
-                    st = torch.empty(e - s, dtype=torch.bfloat16, device=g.device)
-                    if g.is_cuda:
-                        from . import ops
-                        ops.cast_f32_bf16(g, st)
+            names = self._dirty_names.get((a, b))
+            if names is None:
+                names = self._dirty_names[(a, b)] = [n for n, (o, _, _) in self.flat.offsets.items() if a <= o < b]
+            dirty.update(names)
+        if os.environ.get("NEKO_DP_DRY") == "1":      # probe: hooks, stream ordering and bookkeeping without the collectives themselves
+            return
+        with issue_on:
+            for (la, lb) in self._live_ranges(a, b):
+                for s in range(la, lb, self.bucket_elems):
+                    e = min(lb, s + self.bucket_elems)
+                    g = self.flat.grad[s:e]
+                    if self.payload == "bf16":
+                        st = torch.empty(e - s, dtype=torch.bfloat16, device=g.device)
+                        if g.is_cuda:
+                            from . import ops
+                            ops.cast_f32_bf16(g, st)
+                        else:
+                            st.copy_(g)
+                        h = dist.all_reduce(st, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                        self.handles.append((h, st, g))
                     else:
-                        st.copy_(g)
-                    h = dist.all_reduce(st, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-                    self.handles.append((h, st, g))
-                else:
-                    self.handles.append((dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True), None, g))
+                        self.handles.append((dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True), None, g))
 
     def reduce_flags(self, flags: torch.Tensor) -> None:
         if self.world > 1 or self.force:   # stream-ordered (NCCL: the current stream waits on the comm stream, the host does not)
@@ -164,7 +190,12 @@ class GradReducer:
             h.wait()
             if staged is not None:
                 g.copy_(staged)          # widen the summed bf16 payload back into the fp32 gradient (stream-ordered)
+                if staged.is_cuda:       # (allocated while the side stream was current, read here on the compute stream)
+                    staged.record_stream(torch.cuda.current_stream(staged.device))
         self.handles.clear()
+        if self.flat.grad.is_cuda:
+            from .engine import SideStream
+            SideStream.join(self.flat.grad.device)      # nothing of the backward is left on the side stream when the optimiser starts
 
     def attach(self, model, optimizer) -> None:
         model._dp = self

@@ -167,6 +167,15 @@ class SideStream:
         cls._dirty[side.device.index] = True
 
     @classmethod
+    def pending(cls, dev=None) -> Optional["torch.cuda.Stream"]:
+        """The side stream if launches are outstanding on it, else None.  A consumer that runs on a stream of its own (the gradient
+        all-reduce) orders itself behind it instead of making the compute stream wait for the weight gradients (join())."""
+        if not cls.enabled or not torch.cuda.is_available():
+            return None
+        key = torch.device(dev).index if (dev is not None and torch.device(dev).index is not None) else torch.cuda.current_device()
+        return cls._streams[key] if cls._dirty.get(key) else None
+
+    @classmethod
     def join(cls, dev=None) -> None:
         if not cls.enabled or not torch.cuda.is_available():
             return

@@ -14,6 +14,7 @@ from datetime import datetime
 
 os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")     # see bench.py: before the HIP runtime initialises
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC for RCCL: read when the runtime initialises
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")           # compute + side + communication streams on distinct hardware queues (bench.py)
 
 import torch
 
