@@ -113,6 +113,46 @@ def test_layout_edge_cases():
         build_layout([{"images": torch.zeros(1, 3, 20, 32), "text": [1]}], True, 64, False)
 
 
+def test_layout_signature_decides_the_descriptors_and_collect_sources_repeats_build_layout():
+    """The structural memo of GatoPolicy._prepare (round 5): two batches with the same layout_signature have the same descriptor table
+    whatever their values, a different structure changes the signature, host-resident text switches the memo off, and collect_sources
+    hands out the very source tensors build_layout does, in its order."""
+    from neko_amd.policy.gato_policy import build_layout, collect_sources, layout_signature
+    from neko_amd.tasks import synthetic as S
+
+    def control_batch(seed, n=6):
+        g = torch.Generator().manual_seed(seed)
+        out = []
+        for i in range(n):
+            ts, no, na = (7, 5, 2) if i % 3 == 0 else ((4, 11, 3) if i % 3 == 1 else (9, 3, 1))
+            ex = {"continuous_obs": torch.randn(ts, no, generator=g), "continuous_actions": torch.randn(ts, na, generator=g)}
+            if i % 3 == 2:
+                ex = {"images": torch.randint(0, 255, (ts, 3, 32, 48), generator=g, dtype=torch.uint8),
+                      "discrete_actions": torch.randint(0, 18, (ts, 1), generator=g, dtype=torch.int32)}
+            out.append(ex)
+        return out
+
+    a, b = control_batch(1), control_batch(2)
+    assert layout_signature(a) is not None and layout_signature(a) == layout_signature(b)
+    for rg in (0, 2):
+        pa, pbb = build_layout(a, True, 256, False, ragged_groups=rg), build_layout(b, True, 256, False, ragged_groups=rg)
+        assert np.array_equal(pa.desc, pbb.desc) and pa.segments == pbb.segments and pa.order == pbb.order
+    assert layout_signature(a[:-1]) != layout_signature(a) and layout_signature(list(reversed(a))) != layout_signature(a)
+    c = control_batch(1)
+    c[0]["continuous_obs"] = c[0]["continuous_obs"][:, :4]
+    assert layout_signature(c) != layout_signature(a)
+    assert layout_signature([{"text": [1, 2, 3]}]) is None and layout_signature([{"text": torch.tensor([1, 2, 3])}]) is None
+    for batch in (a, S.metric_mix_batch(3, 0, "cpu")):
+        full = build_layout(batch, True, 1024, False)
+        if any(ex.get("text") is not None for ex in batch):
+            continue                                         # (host text: collect_sources is not used for such a batch)
+        src = collect_sources(batch)
+        for name in ("cont", "disc", "images", "given_img_emb"):
+            x, y = getattr(full, name), getattr(src, name)
+            assert len(x) == len(y) and all(u.data_ptr() == v.data_ptr() and u.shape == v.shape for u, v in zip(x, y)), name
+        assert full.img_order == src.img_order
+
+
 def test_lr_schedule_matches_oracle():
     from neko_amd.training.schedulers import get_linear_warmup_cosine_decay_scheduler
     p = torch.nn.Parameter(torch.zeros(1))

@@ -306,3 +306,58 @@ def test_training_step_is_bit_reproducible_and_matches_the_atomic_scatter():
     for k in g0:
         sc = float(g0[k].abs().max())
         assert float((ga[k] - g0[k]).abs().max()) <= 2e-6 * sc + 1e-12, k
+
+
+def test_layout_memo_reuses_descriptors_without_changing_a_bit():
+    """GatoPolicy._prepare remembers the uploaded descriptor table, its sorted tail and the loss rows of a batch STRUCTURE (round 5:
+    at README batch sizes the host enqueue is the step).  A second batch of the same structure with other values must hit the memo and
+    give the very loss, logits and gradients a policy with the memo off gives; a batch of another structure must miss; with
+    deterministic scatters everything is compared bit for bit.  Text ids on the device take part (K_DEVID rows), ragged groups too."""
+    from neko_amd import ops
+    from neko_amd.policy import gato_policy as gp
+    cfg = O.OracleConfig(embed_dim=64, layers=2, heads=2, text_tokens=100, context_len=64)
+    m, _ = make_policy(cfg, 7, train=False)
+
+    def batch(seed, wide=False):
+        g = torch.Generator().manual_seed(seed)
+        b = []
+        for i in range(5):
+            if i % 3 == 0:
+                b.append({"continuous_obs": torch.randn(5, 6 if wide else 4, generator=g).to(DEV), "continuous_actions": torch.randn(5, 2, generator=g).to(DEV)})
+            elif i % 3 == 1:
+                b.append({"images": torch.randint(0, 255, (2, 3, 32, 32), generator=g, dtype=torch.uint8),
+                          "discrete_actions": torch.randint(0, 8, (2, 1), generator=g, dtype=torch.int32).to(DEV)})
+            else:
+                b.append({"text": torch.randint(0, 100, (1, 11), generator=g).to(DEV)})
+        return b
+
+    def run(b, rg):
+        m.ragged_groups = rg
+        m.zero_grad(set_to_none=True)
+        m._flat.zero_grad()
+        m.image_embedding.eval()                       # patch positions without the random draw
+        logits, loss = m(b, compute_loss=True, return_logits=(rg == 0))
+        loss.backward()
+        torch.cuda.synchronize()
+        return float(loss), (logits.detach().clone() if rg == 0 else None), {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
+
+    prev_det, ops.SCATTER_DET = ops.SCATTER_DET, True
+    prev_n = gp.LAYOUT_CACHE
+    try:
+        for rg in (0, 2):
+            gp.LAYOUT_CACHE = 0
+            m._layout_cache.clear()
+            ref = [run(batch(s), rg) for s in (1, 2)]
+            assert len(m._layout_cache) == 0
+            gp.LAYOUT_CACHE = 8
+            got = [run(batch(s), rg) for s in (1, 2)]
+            assert len(m._layout_cache) == 1                                   # second batch: same structure, a hit
+            run(batch(3, wide=True), rg)
+            assert len(m._layout_cache) == 2                                   # other structure: a miss
+            for (l0, lg0, g0), (l1, lg1, g1) in zip(ref, got):
+                assert l0 == l1
+                assert lg0 is None or torch.equal(lg0, lg1)
+                assert g0.keys() == g1.keys() and all(torch.equal(g0[k], g1[k]) for k in g0)
+    finally:
+        ops.SCATTER_DET, gp.LAYOUT_CACHE = prev_det, prev_n
+        m.ragged_groups = 0
