@@ -52,10 +52,15 @@ readme = f"""<!-- bench:begin -->
 CPU restatement of the reference path (`oracle/`, `cpu_baseline` of the bench line, dropout masks included): {mm['cpu_baseline']['value']:.0f} tokens/s on {mm['cpu_baseline']['cores']} host threads.
 <!-- bench:end -->"""
 
+floor_path = os.path.join(root, "profiles", f"{tag}_floor_table.md")
+floor = "<!-- floor:begin -->\n" + (open(floor_path).read().strip() if os.path.exists(floor_path) else "") + "\n<!-- floor:end -->"
+
 for name, block in (("DESIGN.md", design), ("README.md", readme)):
     p = os.path.join(root, name)
     s = open(p).read()
     assert "<!-- bench:begin -->" in s, name
     s = re.sub(r"<!-- bench:begin -->.*?<!-- bench:end -->", lambda m: block, s, flags=re.S)
+    if "<!-- floor:begin -->" in s:          # the floor table of tools/floor_table.py, verbatim
+        s = re.sub(r"<!-- floor:begin -->.*?<!-- floor:end -->", lambda m: floor, s, flags=re.S)
     open(p, "w").write(s)
     print("updated", name)
