@@ -237,11 +237,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
 }
 
 // dgamma[d] (+)= sum_b part[b][0][:], dbeta likewise.  One thread per column, coalesced over b rows.
-// block = 64 columns x 4 row slices (256 threads); 4 independent loads in flight per thread.
-__global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float* __restrict__ part, int nblk, int d,
-                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                              float* __restrict__ dcol, int accumulate) {
-  __shared__ float red[4][64];
+// block = 64 columns x 16 row slices (1024 threads), 4 independent loads in flight per thread; the 16 slice sums meet in LDS and are added
+// in a fixed order (bit-reproducible).  (Round 5: 4 slices x 256 threads took 12-14 us for 512 partial rows on 36 blocks -- pure latency,
+// twelve launches per step.)
+constexpr int LNR_SLICES = 16;
+__global__ __launch_bounds__(64 * LNR_SLICES) void ln_param_reduce_kernel(const float* __restrict__ part, int nblk, int d,
+                                                                          float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                          float* __restrict__ dcol, int accumulate) {
+  __shared__ float red[LNR_SLICES][64];
   const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
   const int ncol = (dcol ? 3 : 2) * d;
@@ -249,18 +252,20 @@ __global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float* __res
   if (c < ncol) {
     const long ld = 3L * d;
     int b = sl;
-    for (; b + 12 < nblk; b += 16) {
+    for (; b + 3 * LNR_SLICES < nblk; b += 4 * LNR_SLICES) {
       s0 += part[(long)b * ld + c];
-      s1 += part[(long)(b + 4) * ld + c];
-      s2 += part[(long)(b + 8) * ld + c];
-      s3 += part[(long)(b + 12) * ld + c];
+      s1 += part[(long)(b + LNR_SLICES) * ld + c];
+      s2 += part[(long)(b + 2 * LNR_SLICES) * ld + c];
+      s3 += part[(long)(b + 3 * LNR_SLICES) * ld + c];
     }
-    for (; b < nblk; b += 4) s0 += part[(long)b * ld + c];
+    for (; b < nblk; b += LNR_SLICES) s0 += part[(long)b * ld + c];
   }
   red[sl][cl] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (sl == 0 && c < ncol) {
-    const float s = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+    float s = 0.f;
+#pragma unroll
+    for (int u = 0; u < LNR_SLICES; u += 4) s += (red[u][cl] + red[u + 1][cl]) + (red[u + 2][cl] + red[u + 3][cl]);
     if (c >= 2 * d) {
       dcol[c - 2 * d] += s;          // a bias gradient: always accumulated, like neko_colsum_bf16(accumulate = 1)
     } else {
@@ -350,7 +355,7 @@ int neko_layernorm_bwd_impl(const void* dy, int dy16, const float* x, const floa
   else if (nv <= 8) rc = bwd_launch<8>(dy, dy16, dy_map, x, gamma, mean, rstd, g_in, dx, dx16, workspace, nblk, M, d, drop_thr, drop_key, drop_scale, wc, s);
   else rc = bwd_launch<16>(dy, dy16, dy_map, x, gamma, mean, rstd, g_in, dx, dx16, workspace, nblk, M, d, drop_thr, drop_key, drop_scale, wc, s);
   if (rc != NEKO_OK) return rc;
-  hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(((wc ? 3 : 2) * d + 63) / 64), dim3(256), 0, s, workspace, nblk, d, dgamma,
+  hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(((wc ? 3 : 2) * d + 63) / 64), dim3(64 * LNR_SLICES), 0, s, workspace, nblk, d, dgamma,
                      dbeta, dcolsum16, accumulate);
   NEKO_CHECK_LAUNCH();
   return NEKO_OK;

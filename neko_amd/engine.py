@@ -647,13 +647,14 @@ LNF_ROWS = os.environ.get("NEKO_LNF_ROWS", "1") != "0"
 
 
 def lm_head_backward_selected(Hp: HeadParams, hsel: torch.Tensor, dlogits: torch.Tensor, grad_out: torch.Tensor,
-                              idx: torch.Tensor, n: int, M: int):
+                              idx: torch.Tensor, n: int, M: int, row_map: Optional[torch.Tensor] = None):
     """Backward of lm_head_loss_selected -> (dhf, row_map): either the gradient rows scattered back into a zero [M,d] buffer and
     None, or the compact rows [npad, d] and the int32 [M] map row -> compact row (-1: zero), see LNF_ROWS."""
     dsel = lm_head_backward(Hp, hsel, dlogits, grad_out)
     if LNF_ROWS:
-        row_map = torch.full((M,), -1, dtype=torch.int32, device=hsel.device)
-        row_map.index_copy_(0, idx[:n].long(), torch.arange(n, dtype=torch.int32, device=hsel.device))
+        if row_map is None:          # (callers that pack on the host hand the map over with the loss rows: GatoPolicy._prepare)
+            row_map = torch.full((M,), -1, dtype=torch.int32, device=hsel.device)
+            row_map.index_copy_(0, idx[:n].long(), torch.arange(n, dtype=torch.int32, device=hsel.device))
         return dsel, row_map
     dhf = torch.zeros(M, hsel.shape[1], dtype=F32, device=hsel.device)
     ops.scatter_rows_f32(dsel, idx, n, dhf)
