@@ -594,14 +594,15 @@ def lm_head_logits(Hp: HeadParams, hf16: torch.Tensor) -> torch.Tensor:
     return logits
 
 
-def lm_head_loss(Hp: HeadParams, hf16: torch.Tensor, target: torch.Tensor, sel: torch.Tensor, count: torch.Tensor,
-                 want_grad: bool, chunk_rows: int = 4096):
+def lm_head_loss(Hp: HeadParams, hf16: torch.Tensor, target: torch.Tensor, sel: Optional[torch.Tensor], count: Optional[torch.Tensor],
+                 want_grad: bool, chunk_rows: int = 4096, weight: Optional[torch.Tensor] = None):
     """Chunked LM head + CE.  Never materialises (B,T,V) fp32 logits nor the (N,V) gathered copy
     (gato_policy.py:184-185): per chunk of rows it runs logits GEMM -> CE (loss rows + bf16 dlogits).
     Returns (loss scalar tensor, dlogits bf16 [M,Vpad] | None)."""
     M, d = hf16.shape
     dev = hf16.device
-    weight = sel / count.clamp(min=1.0)
+    if weight is None:
+        weight = sel / count.clamp(min=1.0)
     loss_rows = torch.empty(M, dtype=F32, device=dev)
     R = min(chunk_rows if want_grad else min(chunk_rows, 4096), M)      # without a gradient the logits live in an R-row scratch buffer
     # the GEMM writes bf16 logits straight into the gradient buffer and the CE kernel turns them into dlogits in place
@@ -620,11 +621,35 @@ def lm_head_loss(Hp: HeadParams, hf16: torch.Tensor, target: torch.Tensor, sel: 
     return loss, (dlogits if want_grad else None)
 
 
-def lm_head_loss_selected(Hp: HeadParams, hf16: torch.Tensor, target: torch.Tensor, idx: torch.Tensor, n: int,
-                          want_grad: bool, chunk_rows: int = 4096):
+_SEL_WEIGHT: dict = {}
+
+
+def _selected_weight(n: int, npad: int, dev) -> torch.Tensor:
+    """fp32 [npad]: 1 / n on the n loss rows, 0 on the padding rows -- the weight of every selected row (mean over the loss positions,
+    gato_policy.py:186).  A constant of (n, npad): kept per device (README-size steps are made of launches; this one replaced six)."""
+    if torch.cuda.is_current_stream_capturing():        # a captured step keeps its own copy inside the graph's memory
+        w = torch.zeros(npad, dtype=F32, device=dev)
+        w[:n] = 1.0 / float(max(n, 1))
+        return w
+    key = (n, npad, str(dev))
+    w = _SEL_WEIGHT.get(key)
+    if w is None:
+        if len(_SEL_WEIGHT) > 256:
+            _SEL_WEIGHT.clear()
+        w = torch.zeros(npad, dtype=F32, device=dev)
+        w[:n] = 1.0 / float(max(n, 1))
+        _SEL_WEIGHT[key] = w
+    return w
+
+
+def lm_head_loss_selected(Hp: HeadParams, hf16: torch.Tensor, target: Optional[torch.Tensor], idx: torch.Tensor, n: int,
+                          want_grad: bool, chunk_rows: int = 4096, tokens_flat: Optional[torch.Tensor] = None,
+                          tgt_idx: Optional[torch.Tensor] = None):
     """Same loss as lm_head_loss, but only the n selected positions (idx: int32 flat row indices, known on the
     host from the packing descriptors) go through the LM head -- the HIP counterpart of the reference's
     boolean-mask gather (gato_policy.py:183-185), done before the GEMM instead of after it.
+    The targets of the selected rows come either from `target` (the shifted token tensor of shift_targets) or, when the packer handed
+    over tgt_idx = idx + 1, straight from the flat token tensor (position t predicts token t + 1, gato_policy.py:176-181).
     Returns (loss, hsel bf16 [npad,d], dlogits bf16 [npad,Vpad] | None)."""
     # multiple of 64: keeps the wgrad contraction on the fast GEMM path; of 256 once the batch is large: whole 256-row tiles for
     # the dH product and a contraction of whole loop trips for dW (gemm_a16.hip); the padding rows are zero rows with weight 0
@@ -632,11 +657,11 @@ def lm_head_loss_selected(Hp: HeadParams, hf16: torch.Tensor, target: torch.Tens
     dev = hf16.device
     hsel = ops.gather_rows_bf16(hf16, idx, n, npad)
     tsel = torch.zeros(npad, dtype=torch.int64, device=dev)
-    tsel[:n] = target.index_select(0, idx[:n].long())
-    sel = torch.zeros(npad, dtype=F32, device=dev)
-    sel[:n] = 1.0
-    count = torch.full((), float(max(n, 1)), dtype=F32, device=dev)
-    loss, dlogits = lm_head_loss(Hp, hsel, tsel, sel, count, want_grad, chunk_rows)
+    if tgt_idx is not None:
+        torch.index_select(tokens_flat, 0, tgt_idx[:n], out=tsel[:n])
+    else:
+        tsel[:n] = target.index_select(0, idx[:n].long())
+    loss, dlogits = lm_head_loss(Hp, hsel, tsel, None, None, want_grad, chunk_rows, weight=_selected_weight(n, npad, dev))
     return loss, hsel, dlogits
 
 

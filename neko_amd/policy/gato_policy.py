@@ -315,13 +315,17 @@ class _PolicyCoreFn(torch.autograd.Function):
         dlogits = None
         ctx.sel_idx = ctx.sel_map = None
         if compute_loss:
-            target, sel, count = engine.shift_targets(tokens, tmask, pmask)
             if pack is not None and pack.n_loss > 0 and policy.lm_head_selected_rows:
+                # the loss rows and their targets' positions are known on the host (_prepare): no shifted copy of the tokens, no
+                # selection mask and no count have to be formed on the device
                 idx, n = pack.loss_idx, pack.n_loss
+                target = None if pack.tgt_idx is not None else engine.shift_targets(tokens, tmask, pmask)[0]
                 loss, hf16, dlogits = engine.lm_head_loss_selected(hp, hf16, target, idx, n, want_grad=need,
-                                                                   chunk_rows=policy.lm_head_chunk_rows)
+                                                                   chunk_rows=policy.lm_head_chunk_rows,
+                                                                   tokens_flat=tokens.reshape(-1), tgt_idx=pack.tgt_idx)
                 ctx.sel_idx, ctx.sel_n, ctx.sel_map = idx, n, pack.row_map
             else:
+                target, sel, count = engine.shift_targets(tokens, tmask, pmask)
                 if segments is not None:        # the shifted selection above crosses sequence boundaries in the bucketed
                     sel = torch.zeros_like(sel)  # layout; it is only reached when the batch has no loss position at all
                     count = sel.sum()
@@ -364,10 +368,11 @@ class _PackInfo:
     """What the host knows about a batch it has just packed: the loss positions (row (b, t) is selected when position t
     is real and position t+1 is a target, gato_policy.py:176-183) as a device index list, and the length buckets of the
     ragged layout.  Handed from `_tokenize` to the policy core of the SAME forward call, never cached across calls."""
-    __slots__ = ("loss_idx", "n_loss", "segments", "order", "rows", "row_map")
+    __slots__ = ("loss_idx", "n_loss", "segments", "order", "rows", "row_map", "tgt_idx")
 
-    def __init__(self, loss_idx, n_loss, segments, order, rows, row_map=None):
+    def __init__(self, loss_idx, n_loss, segments, order, rows, row_map=None, tgt_idx=None):
         self.loss_idx, self.n_loss, self.segments, self.order, self.rows = loss_idx, n_loss, segments, order, rows
+        self.tgt_idx = tgt_idx      # int32: loss_idx + 1, the flat position of every loss row's target token
         #: int32 [rows]: index of row r among the loss rows, -1 where r carries no loss -- the inverse of loss_idx, built on the host
         #: with it (round 5: three torch launches per step made it on the device; ln_f's backward reads the loss rows' gradients through it)
         self.row_map = row_map
@@ -379,7 +384,7 @@ LAYOUT_CACHE = int(os.environ.get("NEKO_LAYOUT_CACHE", "32"))
 
 
 class _LayoutEntry:
-    __slots__ = ("B", "T", "segments", "order", "has_text", "desc_dev", "idx_dev", "n_sel", "map_dev")
+    __slots__ = ("B", "T", "segments", "order", "has_text", "desc_dev", "idx_dev", "n_sel", "map_dev", "tgt_dev")
 
 
 class _Prepared:
@@ -394,7 +399,7 @@ class _Prepared:
         self.pack: Optional[_PackInfo] = None
 
     def tensors(self) -> List[torch.Tensor]:
-        ts = [self.desc, self.pack.loss_idx] + ([self.pack.row_map] if self.pack.row_map is not None else [])
+        ts = [self.desc, self.pack.loss_idx] + [t for t in (self.pack.row_map, self.pack.tgt_idx) if t is not None]
         ts += [t for t in (self.cont, self.disc) if t is not None]
         for X, pos, _, _ in self.img_groups:
             ts += [X, pos]
@@ -629,7 +634,7 @@ class GatoPolicy(nn.Module):
         pr = _Prepared()
         pr.B, pr.T = pb.B, pb.T
         if hit is not None:
-            pr.desc, idx_dev, n_sel, map_dev = hit.desc_dev, hit.idx_dev, hit.n_sel, hit.map_dev
+            pr.desc, idx_dev, n_sel, map_dev, tgt_dev = hit.desc_dev, hit.idx_dev, hit.n_sel, hit.map_dev, hit.tgt_dev
         else:
             # behind the descriptors: the (local position | separator) destinations of the packing backward, sorted on the host
             # (ops.sorted_pairs; _PackEmbedV2.backward hands them to neko_pack_embed_bwd_sorted) -- one flat int32 tensor of 6 ints per row
@@ -652,20 +657,21 @@ class GatoPolicy(nn.Module):
                 selm[r0:r0 + Bk * Tk] = sk.reshape(-1)
             sel_idx = np.flatnonzero(selm).astype(np.int32)
             n_sel = int(sel_idx.size)
-            # one upload: [loss rows (at least one slot) | row -> loss-row index, -1 elsewhere]
+            # one upload: [loss rows (at least one slot) | their target positions = row + 1 | row -> loss-row index, -1 elsewhere]
             nslot = max(n_sel, 1)
-            both = np.full(nslot + B * T, -1, dtype=np.int32)
-            both[:nslot] = 0
+            both = np.full(2 * nslot + B * T, -1, dtype=np.int32)
+            both[:2 * nslot] = 0
             both[:n_sel] = sel_idx
-            both[nslot + sel_idx] = np.arange(n_sel, dtype=np.int32)
+            both[nslot:nslot + n_sel] = sel_idx + 1
+            both[2 * nslot + sel_idx] = np.arange(n_sel, dtype=np.int32)
             both_dev = self.image_embedding._upload(torch.from_numpy(both), dev)
-            idx_dev, map_dev = both_dev[:nslot], both_dev[nslot:]
+            idx_dev, tgt_dev, map_dev = both_dev[:nslot], both_dev[nslot:2 * nslot], both_dev[2 * nslot:]
             if key is not None:
                 # the cached device tensors are read-only inputs of the packing kernels and of the LM head's row gather; clones, so that
                 # nothing else owns their storage
                 ent = _LayoutEntry()
                 ent.B, ent.T, ent.segments, ent.order, ent.has_text = pb.B, pb.T, pb.segments, pb.order, has_text
-                ent.desc_dev, ent.idx_dev, ent.n_sel, ent.map_dev = pr.desc.clone(), idx_dev.clone(), n_sel, map_dev.clone()
+                ent.desc_dev, ent.idx_dev, ent.n_sel, ent.map_dev, ent.tgt_dev = pr.desc.clone(), idx_dev.clone(), n_sel, map_dev.clone(), tgt_dev.clone()
                 self._layout_cache[key] = ent
                 while len(self._layout_cache) > LAYOUT_CACHE:
                     self._layout_cache.popitem(last=False)
@@ -676,7 +682,7 @@ class GatoPolicy(nn.Module):
         # positions drawn per example (in order), kernels batched per image shape
         pr.img_groups = self.image_embedding.prepare_many([pb.images[i] for i in pr.img_ids]) if pr.img_ids else []
         pr.given = [e.to(dev, torch.float32) for e in pb.given_img_emb]
-        pr.pack = _PackInfo(idx_dev, n_sel, pb.segments, pb.order, pb.B * pb.T, map_dev)
+        pr.pack = _PackInfo(idx_dev, n_sel, pb.segments, pb.order, pb.B * pb.T, map_dev, tgt_dev)
         return pr
 
     def _embed_prepared(self, pr: "_Prepared"):

@@ -137,6 +137,7 @@ class CapturedTrainStep:
         st.pack = copy.copy(pr.pack)
         st.pack.loss_idx = pr.pack.loss_idx.clone()
         st.pack.row_map = pr.pack.row_map.clone() if pr.pack.row_map is not None else None
+        st.pack.tgt_idx = pr.pack.tgt_idx.clone() if pr.pack.tgt_idx is not None else None
         e.static = st
         torch.cuda.synchronize()
         e.graph = torch.cuda.CUDAGraph()
