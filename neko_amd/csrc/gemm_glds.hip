@@ -629,6 +629,159 @@ using C256x256 = Cfg<2, 4, 4, 2, 4>;
 using C256x256w4 = Cfg<2, 2, 4, 4, 4>;     // 4 waves x (128 x 128), one wave per SIMD, 256 accumulator AGPRs (the vendor kernel's geometry)
 
 
+// ---- A k-contiguous in 64-k slots of WHOLE 128-B lines (round 5; NEKO_GEMM_KC64=0 returns to 32-k stages) ---------------------------
+// The 8-wave 256 x 256 loop above requests a k-contiguous A tile as 64-B half lines (32 k per stage); gemm_a16.hip measured 4-10 % from
+// requesting whole lines for that operand (two 64-k slots).  Same here (profiles/r05_gemm_kc64_ab.txt: -1...-6 % per launch, bit-identical): A lives in THREE slots of [256 rows][64 k] (96 KB: a slot is requested
+// three k-tiles before its first use), B keeps its four 32-k stages (64 KB) -- 160 KB, one workgroup per CU as before.  A slot row is 128 B
+// and its 16-B chunk index is XORed with row & 7 on the DMA source side; fragments read chunk (4 (kt & 1) + 2 ks + lane / 32) ^ (row & 7).
+// Per k-tile a wave issues its two B pieces, and on even k-tiles also the four A pieces of the slot two ahead; the counted waits follow that
+// order (entry 8, middle of an even k-tile 2, of an odd one 6 -- or 2 when no slot was requested before it).
+template <bool B_KC>
+__global__ __launch_bounds__(512, 2) void gemm_glds64_kernel(GemmArgs p) {
+  using C = Cfg<2, 4, 4, 2, 4>;
+  if (p.drop_thr) p.drop_key += neko_drop_salt();
+  constexpr int BM = 256, BN = 256, TM = 4, TN = 2, NW = 8;
+  constexpr int A_SLOT = 32768, A_REGION = 3 * A_SLOT, B_STAGE = 16384;
+  __shared__ __attribute__((aligned(1024))) char smem[A_REGION + 4 * B_STAGE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / C::WN, wn = wave % C::WN;
+  int tm, tn, slice;
+  tile_coords<BM, BN>(p, tm, tn, slice);
+  const int m0 = tm * BM, n0 = tn * BN;
+  int kbeg = 0, kend = p.K;
+  if (p.splitk > 1) {
+    kbeg = slice * p.k_per_split;
+    kend = min(p.K, kbeg + p.k_per_split);
+  }
+  const int nkt = (kend - kbeg) / BK;            // even, >= 4 (the launcher checks)
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // DMA sources: A piece q of this wave = rows (4 wave + q) * 8 .. + 7 of a slot, lane -> (row = lane / 8, chunk = lane & 7)
+  unsigned voffA[4], voffB[2];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int row = (wave * 4 + q) * 8 + (lane >> 3);
+    const int gr = min(m0 + row, p.M - 1) - m0;
+    voffA[q] = (unsigned)((gr * p.lda + (((lane & 7) ^ (row & 7)) << 3)) * 2);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+    voffB[i] = B_KC ? piece_off_kc<BN, NW>(p.ldb, n0, p.N, wave, lane, i) : piece_off_ks<BN, NW>(p.ldb, n0, p.N, wave, lane, i);
+  const bf16_t* const gA0 = p.A + (long)m0 * p.lda + kbeg;
+  const bf16_t* const gB0 = B_KC ? p.B + (long)n0 * p.ldb + kbeg : p.B + (long)kbeg * p.ldb;
+  const long gstepB = B_KC ? (long)BK : (long)BK * p.ldb;
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane(
+      (unsigned)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)smem));
+  const unsigned ldsA = lds0 + wave * 4 * 1024, ldsB = lds0 + A_REGION + wave * 2 * 1024;
+  auto issue_a = [&](int S, int q) { glds16_s(gA0 + (long)S * 64, voffA[q], ldsA + (unsigned)(S % 3) * A_SLOT + q * 1024); };
+  auto issue_b = [&](int kt, int i) { glds16_s(gB0 + kt * gstepB, voffB[i], ldsB + (unsigned)(kt & 3) * B_STAGE + i * 1024); };
+  auto frag_a = [&](int kt, int ks, int i) {
+    const int row = (wm * TM + i) * 32 + (lane & 31);
+    const int c = ((kt & 1) << 2) + ks * 2 + (lane >> 5);
+    const uint4 v = *reinterpret_cast<const uint4*>(smem + ((kt >> 1) % 3) * A_SLOT + row * 128 + ((c ^ (row & 7)) << 4));
+    return __builtin_bit_cast(bf16x8_v, v);
+  };
+  auto frag_b = [&](int kt, int ks, int j) {
+    const char* lb = smem + A_REGION + (kt & 3) * B_STAGE;
+    return B_KC ? frag_kc(lb, (wn * TN + j) * 32, ks, lane) : frag_ks<BN>(lb, (wn * TN + j) * 32, ks, lane);
+  };
+
+  // prologue: slot 0, B0, slot 1, B1, B2 (14 pieces; the first six must have landed at the loop entry)
+#pragma unroll
+  for (int q = 0; q < 4; ++q) issue_a(0, q);
+  issue_b(0, 0); issue_b(0, 1);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) issue_a(1, q);
+  issue_b(1, 0); issue_b(1, 1);
+  issue_b(2, 0); issue_b(2, 1);
+
+  auto load_frags = [&](int kt, int ks, bf16x8_v (&a)[TM], bf16x8_v (&b)[TN]) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) b[j] = frag_b(kt, ks, j);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) a[i] = frag_a(kt, ks, i);
+  };
+  auto mfma_step = [&](const bf16x8_v (&a)[TM], const bf16x8_v (&b)[TN]) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+  };
+  // one k-step: TM * TN MFMAs with the TM + TN fragment reads of the NEXT k-step and NPC DMA pieces spread between them (as step_il above)
+  auto step = [&](const bf16x8_v (&a)[TM], const bf16x8_v (&b)[TN], bf16x8_v (&an)[TM], bf16x8_v (&bn)[TN], int kt_load, int ks_load,
+                  auto npc_tag, int kt_now) {
+    constexpr int NPC = decltype(npc_tag)::value;      // 0: no DMA, 2: B pieces of tile kt_now + 3, 6: + the A slot kt_now / 2 + 2
+    constexpr int NL = TM + TN;
+    int pc = 0, lc = 0;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+        const int m = i * TN + j;
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+          if (l == lc && m == (l * TM * TN) / NL) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (l == 0) an[0] = frag_a(kt_load, ks_load, 0);
+            else if (l <= TN) bn[l - 1] = frag_b(kt_load, ks_load, l - 1);
+            else an[l - TN] = frag_a(kt_load, ks_load, l - TN);
+            __builtin_amdgcn_sched_barrier(0);
+            ++lc;
+          }
+        }
+        if constexpr (NPC > 0) {
+          if (pc < NPC && m == ((pc + 1) * TM * TN) / NPC - 1) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (NPC == 6 && pc < 4) issue_a(kt_now / 2 + 2, pc);
+            else issue_b(kt_now + 3, NPC == 6 ? pc - 4 : pc);
+            __builtin_amdgcn_sched_barrier(0);
+            ++pc;
+          }
+        }
+      }
+  };
+
+  bf16x8_v a0[TM], b0[TN], a1[TM], b1[TN];
+  wait_dma_only_and_barrier<8>();        // slot 0 and B0 visible
+  load_frags(0, 0, a0, b0);
+  // k-tiles in (even, odd) pairs -- a static schedule, no branch in the loop: the even tile requests the A slot two ahead (tiles kt + 4,
+  // kt + 5) and B of tile kt + 3, the odd one B of tile kt + 4; what may still be in flight at the middle of a tile follows from that order
+  int kt = 0;
+  for (; kt + 4 < nkt; kt += 2) {
+    step(a0, b0, a1, b1, kt, 1, std::integral_constant<int, 0>{}, kt);
+    wait_dma_only_and_barrier<2>();                                       // B of tile kt + 2 may be in flight
+    step(a1, b1, a0, b0, kt + 1, 0, std::integral_constant<int, 6>{}, kt);
+    step(a0, b0, a1, b1, kt + 1, 1, std::integral_constant<int, 0>{}, kt + 1);
+    wait_dma_only_and_barrier<6>();                                       // the slot and the B tile just requested may be in flight
+    step(a1, b1, a0, b0, kt + 2, 0, std::integral_constant<int, 2>{}, kt + 1);
+  }
+  // kt == nkt - 4: the last B tile (nkt - 1) is still to be requested, every A slot has been
+  step(a0, b0, a1, b1, kt, 1, std::integral_constant<int, 0>{}, kt);
+  wait_dma_only_and_barrier<2>();
+  step(a1, b1, a0, b0, kt + 1, 0, std::integral_constant<int, 2>{}, kt);
+  for (int kd = nkt - 3; kd < nkt; ++kd) {      // drain: nothing left to request
+    load_frags(kd, 1, a1, b1);
+    mfma_step(a0, b0);
+    if (kd + 1 < nkt) {
+      wait_dma_only_and_barrier<0>();
+      load_frags(kd + 1, 0, a0, b0);
+    }
+    mfma_step(a1, b1);
+  }
+  __syncthreads();   // all waves done with the ring before the slabs overwrite it
+  if (!try_epilogue_fast<C>(p, ParkAcc32<C>{acc}, smem, m0, n0, wm, wn, wave, lane, slice))
+    epilogue<C>(p, acc, smem, m0, n0, wm, wn, wave, lane, slice);
+}
+
 thread_local int t_colsum_bands = 0;
 
 template <bool A_KC, bool B_KC, class C>
@@ -643,6 +796,17 @@ int launch_cfg(const GemmArgs& a_in, hipStream_t s) {
   if (!fold) a.colsum_ws = nullptr;
   t_colsum_bands = fold ? a.M / (32 * C::TM) : 0;
   dim3 grid(nbm * nbn * (a.splitk > 1 ? a.splitk : 1));
+  if constexpr (A_KC && std::is_same<C, Cfg<2, 4, 4, 2, 4>>::value) {
+    static const int kc64 = [] { const char* e = getenv("NEKO_GEMM_KC64"); return e ? atoi(e) : 1; }();      // 0: the 32-k stages for A too (A/B runs)
+    const int klen = a.splitk > 1 ? a.k_per_split : a.K;
+    const long last = a.splitk > 1 ? (long)a.K - (long)(a.splitk - 1) * a.k_per_split : a.K;
+    // whole 64-k slots in every slice, at least two of them, 32-bit per-lane byte offsets
+    if (kc64 && klen % 64 == 0 && klen >= 128 && last % 64 == 0 && last >= 128 && 256L * a.lda * 2 < (1L << 31)) {
+      hipLaunchKernelGGL((gemm_glds64_kernel<B_KC>), grid, dim3(512), 0, s, a);
+      NEKO_CHECK_LAUNCH();
+      return NEKO_OK;
+    }
+  }
   hipLaunchKernelGGL((gemm_glds_kernel<A_KC, B_KC, C>), grid, dim3(C::NT), 0, s, a);
   NEKO_CHECK_LAUNCH();
   return NEKO_OK;

@@ -183,6 +183,42 @@ def test_gemm_a16_epilogues(a16, epi):
         assert torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("layout", ["nt", "nn"])
+@pytest.mark.parametrize("M,N,K,splitk", [(4196, 2304, 128, 1), (4196, 2304, 192, 1), (4100, 2176, 768, 1), (4352, 2304, 320, 1), (512, 512, 5120, 40)])
+def test_gemm_glds_whole_line_slots_for_a_k_contiguous_operand(ops, layout, M, N, K, splitk):
+    """gemm_glds64_kernel (round 5): the 8-wave 256 x 256 loop with its k-contiguous A operand in three 64-k slots of whole 128-B lines
+    (XOR-swizzled 16-B chunks, pieces requested two slots ahead on even k-tiles).  Shapes that take it with the hand-placed loops off:
+    the shortest contraction (two slots, no steady-state trip), one and several trips, edge tiles in M and N (clamped DMA rows / columns),
+    B k-contiguous and k-strided, split-K slices of two slots each -- against the fp32 product of the same bf16 operands."""
+    g = torch.Generator().manual_seed(M + 3 * N + 7 * K)
+    A = rb(torch.randn(M, K, generator=g)); Bm = rb(torch.randn(K, N, generator=g) * 0.25)
+    A = rb(A * (1.0 + 0.01 * torch.arange(M).float().unsqueeze(1) % 0.37))      # rows individually recognisable
+    ref = A @ Bm
+    b_ks = layout == "nn"
+    A_dev = bf(A)
+    B_dev = bf(Bm) if b_ks else bf(Bm.t())
+    prev = ops.gemm_set_mainloop(0)
+    try:
+        if splitk > 1:
+            outs = []
+            for _ in range(2):
+                out = torch.full((M, N), float("nan"), device=DEV)
+                ops.gemm(A_dev, B_dev, M, N, K, b_kstrided=b_ks, out_f32=out, splitk=splitk, k_per_split=K // splitk)
+                outs.append(out)
+            close(outs[0], ref, 2e-4, 2e-4 * math.sqrt(K), f"kc64 split-K {layout}")
+            assert torch.equal(outs[0], outs[1])
+        else:
+            out16 = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+            ops.gemm(A_dev, B_dev, M, N, K, b_kstrided=b_ks, out_bf16=out16)
+            close(out16, ref, 2 ** -7, 2e-4 * math.sqrt(K), f"kc64 bf16 {layout} {M}x{N}x{K}")
+            out = torch.full((M, N), float("nan"), device=DEV)
+            bias = torch.randn(N, generator=g)
+            ops.gemm(A_dev, B_dev, M, N, K, b_kstrided=b_ks, bias=bias.to(DEV), out_f32=out)
+            close(out, ref + bias, 2e-4, 2e-4 * math.sqrt(K), f"kc64 f32 + bias {layout} {M}x{N}x{K}")
+    finally:
+        ops.gemm_set_mainloop(prev)
+
+
 @pytest.fixture
 def b16(ops):
     """every launch the two-workgroups-per-CU main loop (gemm_b16.hip) can serve goes to it"""
