@@ -32,9 +32,9 @@ PATCH_VALU_WAVE_INSTS = (2601 + 4310) * 4 * float(PATCHES)
 # "K-sum": contraction length summed over the launches of the class that share the row (the N = 768 dgrads have K = 768 / 2304 / 3072)
 GEMMS = [
     ("c_attn fwd (bias, bf16)", "gemm_a16_kernelILb1ELb0", 2304, 6, 256, 256, M, 3 * D, D),
-    ("c_fc fwd + GELU + gelu' (2 x bf16 out)", "gemm_glds_kernelILb1ELb0", 3072, 6, 256, 256, M, 4 * D, D),
+    ("c_fc fwd + GELU + gelu' (2 x bf16 out)", "gemm_glds64_kernelILb0", 3072, 6, 256, 256, M, 4 * D, D),
     ("attn + MLP c_proj fwd (bias, dropout, fp32 residual in / out)", "gemm_b16_kernel", 1536, 12, 128, 256, M, D, (D + 4 * D) / 2.0),
-    ("dgrad MLP c_proj x gelu' (+ c_fc bias gradient)", "gemm_glds_kernelILb1ELb1", 3072, 6, 256, 256, M, 4 * D, D),
+    ("dgrad MLP c_proj x gelu' (+ c_fc bias gradient)", "gemm_glds64_kernelILb1", 3072, 6, 256, 256, M, 4 * D, D),
     ("N = 768 dgrads (c_fc, attn c_proj, c_attn: K = 3072 / 768 / 2304)", "gemm_a16_kernelILb1ELb1", 768, 18, 256, 256, M, D, (4 * D + D + 3 * D) / 3.0),
     ("wgrads c_fc / MLP c_proj (split-K)", "gemm_a16_kernelILb0ELb0", 252, 12, 256, 256, 4 * D, D, M),
     ("wgrads c_attn / attn c_proj (split-K)", "gemm_a16_kernelILb0ELb0", 243, 12, 256, 256, 2 * D, D, M),
@@ -97,7 +97,8 @@ def clock_of(clocks, key, blocks, default):
 
 DEMANGLED = {"gemm_a16_kernelILb1ELb0": "gemm_a16_kernel<true, false>", "gemm_a16_kernelILb1ELb1": "gemm_a16_kernel<true, true>",
              "gemm_a16_kernelILb0ELb0": "gemm_a16_kernel<false, false>", "gemm_glds_kernelILb1ELb0": "gemm_glds_kernel<true, false",
-             "gemm_glds_kernelILb1ELb1": "gemm_glds_kernel<true, true", "gemm_b16_kernel": "gemm_b16_kernel"}
+             "gemm_glds_kernelILb1ELb1": "gemm_glds_kernel<true, true", "gemm_b16_kernel": "gemm_b16_kernel",
+             "gemm_glds64_kernelILb0": "gemm_glds64_kernel<false>", "gemm_glds64_kernelILb1": "gemm_glds64_kernel<true>"}
 
 
 def main():
