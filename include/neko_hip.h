@@ -36,7 +36,7 @@ extern "C" {
 #define NEKO_ERR_UNSUPPORTED (-2)
 #define NEKO_ERR_LAUNCH (-3)
 
-#define NEKO_ABI_VERSION 18
+#define NEKO_ABI_VERSION 19
 
 int neko_abi_version(void);
 /* human-readable text for a return code (static storage) */
@@ -86,6 +86,15 @@ int neko_gemm_bf16(const uint16_t* A, long lda, int a_kstrided, const uint16_t* 
  * which products are summed into an output element; the loops add them in a different order (fp32).  (ABI v16; replaces v14's
  * neko_gemm_set_persistent, whose kernel moved to tools/probe/) */
 int neko_gemm_set_mainloop(int mode);
+/* ABI v19 (round 6).  A fourth main loop, neko_amd/csrc/gemm_p16.hip: 256 x 256 per workgroup of EIGHT waves (128 x 64 per wave, 128
+ * accumulators), the two waves of a SIMD alternating between a matrix segment (32 MFMAs) and a load segment (fragment reads + L2 -> LDS
+ * requests) of hand-placed instruction streams; serves launches of interior 256 x 256 tiles whose contraction range is a multiple of 384
+ * (A k-contiguous) or 128 (both operands k-strided).  neko_gemm_set_mainloop(3) sends every launch it can serve to it.
+ * neko_gemm_last_mainloop(): which loop served the calling thread's last neko_gemm_bf16 / neko_gemm_dgrad_gelu_colsum launch --
+ * 0 gemm_glds (32 x 32 x 16 loop, any tile configuration), 1 gemm_a16, 2 gemm_b16, 3 gemm_glds64 (the 8-wave 256 x 256 loop with
+ * whole-line A slots), 4 the register-staged fallback (gemm_bf16.hip), 5 gemm_p16; -1 before the first launch.  Thread-local; exists so
+ * that tests can assert WHICH loop they exercised (reference: the Conv1D / Linear products of gato/transformers/trajectory_gpt2.py:139-141). */
+int neko_gemm_last_mainloop(void);
 
 /* Backward of the MLP's first Linear + GELU in one launch (trajectory_gpt2.py:266,274: h = act(c_fc(x)); autograd's
  * d_pre = (d_h . W_proj^T) * gelu'(pre) and the c_fc bias gradient sum_rows d_pre):

@@ -33,6 +33,7 @@ SIGNATURES = {
     "neko_attn_set_path": [_i],
     "neko_attn_bwd_reproducible": [_i],
     "neko_gemm_set_mainloop": [_i],
+    "neko_gemm_last_mainloop": [],
     "neko_attn_varlen_supported": [_i, _i],
     "neko_attn_fwd_varlen": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, C.c_uint, _f, _vp, _vp],
     "neko_attn_bwd_varlen": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _l, _i, _i, _i, _i, C.c_uint, _f, _vp, _vp],

@@ -17,12 +17,12 @@ import sys
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 BUILD = os.path.join(CSRC, "build")
 LIB = os.path.join(CSRC, "libneko_hip.so")
-SOURCES = ["gemm_bf16.hip", "gemm_glds.hip", "gemm_a16.hip", "gemm_b16.hip", "gemv_bf16.hip", "layernorm.hip", "attention.hip", "attention_res.hip", "attention_stream.hip", "attention_decode.hip", "cross_entropy.hip", "elementwise.hip",
+SOURCES = ["gemm_bf16.hip", "gemm_glds.hip", "gemm_a16.hip", "gemm_b16.hip", "gemm_p16.hip", "gemv_bf16.hip", "layernorm.hip", "attention.hip", "attention_res.hip", "attention_stream.hip", "attention_decode.hip", "cross_entropy.hip", "elementwise.hip",
            "pack_embed.hip", "patch_embed.hip", "rows.hip", "segsum.hip", "dropout.hip", "neko_capi.hip"]
 HEADERS = ["neko_common.h", "neko_kernels.h", os.path.join("..", "..", "include", "neko_hip.h")]
 # headers only some sources include (a change rebuilds just those)
 EXTRA_DEPS = {"gemm_glds.hip": ["gemm_epi.h"], "gemm_a16.hip": ["gemm_epi.h", "gemm_a16_loop.inc"],
-              "gemm_b16.hip": ["gemm_epi.h", "gemm_b16_loop.inc"]}
+              "gemm_b16.hip": ["gemm_epi.h", "gemm_b16_loop.inc"], "gemm_p16.hip": ["gemm_epi.h", "gemm_p16_loop.inc"]}
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=on", "-Wno-unused-result"]
 FLAGS += os.environ.get("NEKO_EXTRA_HIPCC_FLAGS", "").split()

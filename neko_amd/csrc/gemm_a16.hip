@@ -154,18 +154,18 @@ int launch_a16(const GemmArgs& a, hipStream_t s) {
 
 }  // namespace
 
-// -1: per-shape choice, 0: neither hand-placed loop, 1: gemm_a16.hip wherever it applies (never gemm_b16.hip), 2: gemm_b16.hip wherever
-// it applies (then the per-shape choice)
+// -1: per-shape choice, 0: no hand-placed loop, 1: gemm_a16.hip wherever it applies (never gemm_b16.hip / gemm_p16.hip), 2: gemm_b16.hip
+// wherever it applies (then the per-shape choice), 3: gemm_p16.hip wherever it applies (then the per-shape choice)
 int neko_gemm_set_mainloop_impl(int mode) {
   const int prev = g_mainloop_mode;
-  g_mainloop_mode = mode < 0 ? -1 : (mode > 2 ? 1 : mode);
+  g_mainloop_mode = mode < 0 ? -1 : (mode > 3 ? 1 : mode);
   return prev;
 }
 int neko_gemm_mainloop_mode() { return g_mainloop_mode; }
 
 // 1 = not applicable (the caller runs gemm_glds.hip's loop), otherwise a status code
 int neko_gemm_a16_try(const GemmArgs& a, int a_kstrided, int b_kstrided, hipStream_t s) {
-  const int mode = g_mainloop_mode == 2 ? env_mode() : (g_mainloop_mode >= 0 ? g_mainloop_mode : env_mode());
+  const int mode = g_mainloop_mode >= 2 ? env_mode() : (g_mainloop_mode >= 0 ? g_mainloop_mode : env_mode());
   if (mode == 0) return 1;
   if ((a.M & 255) || (a.N & 255)) return 1;
   const int klen = a.splitk > 1 ? a.k_per_split : a.K;
@@ -202,6 +202,7 @@ int neko_gemm_a16_try(const GemmArgs& a, int a_kstrided, int b_kstrided, hipStre
     // tiles fill the chip better than this loop's faster k-tiles pay back (c2: 6.03 -> 6.16 ms per step with 90-tile launches)
     if (tiles < 192) return 1;
   }
+  g_neko_last_mainloop = 1;
   if (a_kstrided && b_kstrided) return launch_a16<false, false>(a, s);
   if (a_kstrided) return launch_a16<false, true>(a, s);
   if (b_kstrided) return launch_a16<true, false>(a, s);

@@ -178,7 +178,7 @@ int dispatch_b16(const GemmArgs& a, bool b_kc, unsigned f, hipStream_t s) {
 int neko_gemm_b16_try(const GemmArgs& a_in, int a_kstrided, int b_kstrided, int mainloop_mode, int* colsum_bands, hipStream_t s) {
   *colsum_bands = 0;
   // neko_gemm_set_mainloop: 0 = no hand-placed loop, 1 = gemm_a16.hip's only, 2 = this one wherever it applies; -1 = NEKO_GEMM_B16 / per shape
-  const int mode = (mainloop_mode == 0 || mainloop_mode == 1) ? 0 : (mainloop_mode == 2 ? 1 : env_mode_b16());
+  const int mode = (mainloop_mode == 0 || mainloop_mode == 1 || mainloop_mode == 3) ? 0 : (mainloop_mode == 2 ? 1 : env_mode_b16());
   if (mode == 0 || a_kstrided) return 1;
   GemmArgs a = a_in;
   if ((a.M & 127) || (a.N & 255) || a.K < 384 || (a.K % 384)) return 1;
@@ -213,6 +213,7 @@ int neko_gemm_b16_try(const GemmArgs& a_in, int a_kstrided, int b_kstrided, int 
   }
   a.epi_lock = 0;
   const int rc = dispatch_b16(a, !b_kstrided, f, s);
+  if (rc == NEKO_OK) g_neko_last_mainloop = 2;
   if (rc == NEKO_OK && fold) *colsum_bands = a.M / 64;
   return rc;
 }

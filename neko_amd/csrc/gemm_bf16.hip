@@ -252,6 +252,8 @@ int launch(const GemmArgs& a, hipStream_t s) {
 
 }  // namespace
 
+thread_local int g_neko_last_mainloop = -1;
+
 // Host-side entry used by neko_capi.hip.  a_kstrided / b_kstrided select the operand storage.
 int neko_gemm_bf16_impl(GemmArgs a, int a_kstrided, int b_kstrided, int safe_transpose, hipStream_t s) {
   if (a.M <= 0 || a.N <= 0 || a.K <= 0) return NEKO_OK;
@@ -274,6 +276,7 @@ int neko_gemm_bf16_impl(GemmArgs a, int a_kstrided, int b_kstrided, int safe_tra
     if (rc != 1) return rc;
   }
   safe_transpose = (safe_transpose == 1);
+  g_neko_last_mainloop = 4;
   if (a_kstrided && b_kstrided)
     return safe_transpose ? launch<false, false, true>(a, s) : launch<false, false, false>(a, s);
   if (a_kstrided)

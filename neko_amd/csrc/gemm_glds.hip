@@ -804,11 +804,13 @@ int launch_cfg(const GemmArgs& a_in, hipStream_t s) {
     if (kc64 && klen % 64 == 0 && klen >= 128 && last % 64 == 0 && last >= 128 && 256L * a.lda * 2 < (1L << 31)) {
       hipLaunchKernelGGL((gemm_glds64_kernel<B_KC>), grid, dim3(512), 0, s, a);
       NEKO_CHECK_LAUNCH();
+      g_neko_last_mainloop = 3;
       return NEKO_OK;
     }
   }
   hipLaunchKernelGGL((gemm_glds_kernel<A_KC, B_KC, C>), grid, dim3(C::NT), 0, s, a);
   NEKO_CHECK_LAUNCH();
+  g_neko_last_mainloop = 0;
   return NEKO_OK;
 }
 
@@ -959,6 +961,14 @@ int neko_gemm_glds_try(const GemmArgs& a_in, int a_kstrided, int b_kstrided, hip
   if (a.bias && (reinterpret_cast<uintptr_t>(a.bias) & 15)) return 1;
   if (a.act_in && ((reinterpret_cast<uintptr_t>(a.act_in) & 7) || (a.ldact & 3))) return 1;
   if (a.pre_out && ((reinterpret_cast<uintptr_t>(a.pre_out) & 7) || (a.ldpre & 3))) return 1;
+  {                         // two waves per SIMD in alternating roles, hand-placed (gemm_p16.hip), where it applies
+    int bands = 0;
+    const int rc = neko_gemm_p16_try(a, a_kstrided, b_kstrided, neko_gemm_mainloop_mode(), &bands, s);
+    if (rc != 1) {
+      t_colsum_bands = bands;
+      return rc;
+    }
+  }
   {                         // two workgroups per CU, hand-placed 64 x 128 wave tiles (gemm_b16.hip), where it applies
     int bands = 0;
     const int rc = neko_gemm_b16_try(a, a_kstrided, b_kstrided, neko_gemm_mainloop_mode(), &bands, s);

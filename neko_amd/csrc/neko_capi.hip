@@ -29,6 +29,7 @@ int neko_gemm_bf16(const uint16_t* A, long lda, int a_kstrided, const uint16_t* 
 }
 
 int neko_gemm_set_mainloop(int mode) { return neko_gemm_set_mainloop_impl(mode); }
+int neko_gemm_last_mainloop(void) { return g_neko_last_mainloop; }
 long neko_gemm_colsum_ws_floats(int M, int N) { return (long)((M + 63) / 64) * (long)N; }
 int neko_gemm_dgrad_gelu_colsum(const uint16_t* dY, long lda, const uint16_t* W, long ldb, int M, int N, int K,
                                 const uint16_t* act_in, long ldact, int act_in_is_factor, uint16_t* Cb, long ldcb,

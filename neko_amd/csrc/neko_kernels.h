@@ -45,6 +45,11 @@ int neko_gemm_set_mainloop_impl(int mode);
 int neko_gemm_mainloop_mode();
 // gemm_b16.hip (two workgroups per CU): 1 = not applicable; mainloop_mode = neko_gemm_mainloop_mode()
 int neko_gemm_b16_try(const GemmArgs& a, int a_kstrided, int b_kstrided, int mainloop_mode, int* colsum_bands, hipStream_t s);
+// gemm_p16.hip (two waves per SIMD, role-alternating; round 6): 1 = not applicable; *colsum_bands = 128-row bands filled
+int neko_gemm_p16_try(const GemmArgs& a, int a_kstrided, int b_kstrided, int mainloop_mode, int* colsum_bands, hipStream_t s);
+// which main loop served the calling thread's last neko_gemm_bf16 launch: 0 gemm_glds (32 x 32 x 16 loop), 1 gemm_a16, 2 gemm_b16,
+// 3 gemm_glds64 (8-wave loop, whole-line A slots), 4 gemm_bf16 (register-staged fallback), 5 gemm_p16; -1 = none yet
+extern thread_local int g_neko_last_mainloop;
 // bands of colsum_ws the last neko_gemm_glds_try() of this thread filled (0: the column sums were not folded into it)
 int neko_gemm_glds_colsum_bands();
 int neko_colsum_bands_reduce_impl(const float* ws, int bands, int N, float* out, hipStream_t s);   // out[N] += sum over bands, fixed order

@@ -202,6 +202,14 @@ def gemm_set_mainloop(mode: int) -> int:
     return int(_lib.load().neko_gemm_set_mainloop(int(mode)))
 
 
+MAINLOOP_NAMES = {0: "glds", 1: "a16", 2: "b16", 3: "glds64", 4: "bf16", 5: "p16", -1: "none"}
+
+
+def gemm_last_mainloop() -> int:
+    """Which main loop served this thread's last `gemm` launch (neko_gemm_last_mainloop; names: MAINLOOP_NAMES)."""
+    return int(_lib.load().neko_gemm_last_mainloop())
+
+
 def attn_set_path(mode: int) -> int:
     """0 = automatic (head-resident kernels when hd = 32 and T <= 1024; their backward in one pass for 256 < T <= 512, as two kernels
     otherwise), 1 = always the streaming kernels, 2 / 3 = head-resident with the two-kernel (bit-reproducible) / one-pass backward at

@@ -24,7 +24,7 @@ def test_abi_exports_every_declared_symbol():
         assert hasattr(lib, name), f"libneko_hip.so lacks {name}"
     # every binding in _lib.SIGNATURES is a declared symbol and vice versa (status_string is bound separately)
     assert set(_lib.SIGNATURES) | {"neko_status_string"} == declared
-    assert lib.neko_abi_version() == 18
+    assert lib.neko_abi_version() == 19
     assert lib.neko_status_string(-1).decode().startswith("invalid argument")
 
 

@@ -54,18 +54,21 @@ class Geom:
     tile t, so three stages carry the same three tiles of lookahead as a16's four).  The slot period (4 tiles) and the ring period (3)
     give a loop body of 12 k-tiles: the contraction range must be a multiple of 384."""
 
-    def __init__(self, name, fa, fb, ring, region, slot64, npiece64, v_ks, v_frag, boff, trip):
+    def __init__(self, name, fa, fb, ring, region, slot64, npiece64, v_ks, v_frag, boff, trip, nslot=2, npiece_ring=4, nsets=2):
         self.name, self.fa, self.fb, self.ring, self.region, self.slot64, self.npiece64 = name, fa, fb, ring, region, slot64, npiece64
         self.v_ks, self.v_frag, self.boff, self.trip = v_ks, v_frag, boff, trip
+        self.nslot, self.npiece_ring, self.nsets = nslot, npiece_ring, nsets      # 64-k slots of a kc64 operand; pieces per wave per ring stage
         self.set = 4 * (fa + fb)                 # registers of one fragment set
         self.nm = fa * fb                        # MFMAs per k-tile
         self.vlo = min(list(v_ks.values()) + [v_frag])
-        self.vhi = v_frag + 2 * self.set         # clobbered VGPRs: [vlo, vhi)
+        self.vhi = v_frag + nsets * self.set     # clobbered VGPRs: [vlo, vhi)
 
 
 GEOMS = {
     "a16": Geom("A16", 8, 8, 4, {"a": 0, "b": 65536}, {"a": 32768, "b": 32768}, {"a": 8, "b": 8}, {"a": 96, "b": 104}, 128, 32, 4),
     "b16": Geom("B16", 4, 8, 3, {"a": 0, "b": 32768}, {"a": 16384}, {"a": 4}, {"b": 24}, 32, 16, 12),
+    # p16 (round 6): 256 x 256 per workgroup of EIGHT waves (two per SIMD), 128 x 64 per wave; see stream_p16
+    "p16": Geom("P16", 8, 4, 4, {"a": 0, "b": 98304}, {"a": 32768}, {"a": 4}, {"a": 48, "b": 56}, 64, 32, 12, nslot={"a": 3, "b": 2}, npiece_ring=2, nsets=1),
 }
 G = GEOMS["a16"]
 
@@ -75,7 +78,8 @@ class Op:
 
     def __init__(self, which, mode):
         self.w, self.mode = which, mode
-        self.npiece = G.npiece64[which] if mode == "kc64" else 4     # per wave per request unit (stage or slot)
+        self.nslot = G.nslot[which] if isinstance(G.nslot, dict) else G.nslot      # 64-k slots (kc64)
+        self.npiece = G.npiece64[which] if mode == "kc64" else G.npiece_ring     # per wave per request unit (stage or slot)
         self.nfrag = G.fa if which == "a" else G.fb
         assert mode != "ks" or which in G.v_ks, f"geometry {G.name}: operand {which} cannot be k-strided"
 
@@ -88,8 +92,10 @@ class Op:
         for t in range(self.nfrag):
             r = self.frag(setp, t)
             if self.mode == "kc64":
-                slot, half = (tile >> 1) & 1, tile & 1
-                out.append(f"ds_read_b128 v[{r}:{r + 3}], %[r{self.w}{half}] offset:{slot * G.slot64[self.w] + t * 2048}")
+                slot, half = (tile >> 1) % self.nslot, tile & 1
+                # (the DS offset field has 16 bits: the third slot of p16 is addressed from a second pair of base registers)
+                hi = 2 if slot >= 2 else 0
+                out.append(f"ds_read_b128 v[{r}:{r + 3}], %[r{self.w}{half + hi}] offset:{(slot - hi) * G.slot64[self.w] + t * 2048}")
             elif self.mode == "kc32":
                 out.append(f"ds_read_b128 v[{r}:{r + 3}], %[r{self.w}0] offset:{(tile % G.ring) * 16384 + t * 1024}")
             else:
@@ -107,7 +113,7 @@ class Op:
         out = []
         for pc in range(self.npiece):
             if self.mode == "kc64":
-                dst = G.region[self.w] + (unit % 2) * G.slot64[self.w] + pc * 1024
+                dst = G.region[self.w] + (unit % self.nslot) * G.slot64[self.w] + pc * 1024
             else:
                 dst = G.region[self.w] + (unit % G.ring) * 16384 + pc * 1024
             sg = S_G[self.w]
@@ -314,6 +320,189 @@ def main_b16(args):
     print(out, sum(len(t) for t in txt), "bytes")
 
 
+# ---- p16 (round 6): two waves per SIMD, alternating roles -------------------------------------------------------------------------------
+# One workgroup = 8 waves = one 256 x 256 tile; wave w owns rows 128 (w >> 2) .. +127 and columns 64 (w & 3) .. +63: 8 x 4 blocks of
+# v_mfma_f32_16x16x32_bf16, 128 accumulators a[0:127] (block (ti, tj) = a[4 (4 ti + tj) : +3]), ONE fragment set of 48 VGPRs (v[64:111]).
+# Waves w and w + 4 share a SIMD (a workgroup's waves are dealt to the SIMDs cyclically); the first half (w < 4, "X") and the second half
+# ("Y", static s_setprio 1: MI355X_MICROARCH.md "Two waves per SIMD" item 4) run two different instruction streams, and every k-tile j
+# is two segments separated by block barriers:
+#     S0(j):  X  C(j)   = the 32 MFMAs of tile j, nothing else in the stream      |  Y  L(j)   = fragment reads of tile j + DMA requests
+#     -- B0(j): every wave has waited for its own pieces of tile j + 1 -> tile j + 1 is visible; tile j has been read by both halves --
+#     S1(j):  X  L(j+1) = fragment reads of tile j + 1 + DMA requests             |  Y  C(j)
+#     -- B1(j) --
+# so on every SIMD one wave issues matrix instructions back to back while its partner issues the LDS reads and the L2 -> LDS requests
+# (one in-order wave per SIMD had to issue all three streams itself: 1385-1550 clocks per k-tile against 1024 of bare MFMAs, DESIGN 4.2).
+# L(j) requests into what tile j - 1 has freed (both halves have read tile j - 1 before B0(j-1)):
+#   32-k ring operand (4 stages): the stage of tile j + 3;
+#   k-contiguous operand in 64-k slots of whole 128-B lines (tools/probe/dma_rate_probe.hip: 64-B half-line pieces travel at HALF the
+#   rate of whole lines, 28 against 55 B/clk/CU): A in THREE slots (96 KB at 0), B in two (64 KB at 96 KB); the slot freed by an odd tile
+#   f is requested piece by piece in L(f + 1 + delay[piece]) -- the delays (P16_DELAY) level the load segments at four requests each.
+# The loop body is lcm(6, 4) = 12 k-tiles when A is k-contiguous, 4 otherwise.
+P16_DELAY = {}          # (operand, other operand's mode) -> per-piece delays, filled by main_p16
+
+
+def p16_requests(op, other, j):
+    """[(unit, piece)] of operand op that L(j) issues"""
+    out = []
+    if op.mode == "kc64":
+        ns = op.nslot
+        for pc, d in enumerate(P16_DELAY[(op.w, other.mode)]):
+            assert d <= 2 * ns - 4, "a piece requested in the segment in front of the barrier that needs it"
+            f = j - 1 - d
+            if f % 2 == 1:
+                out.append(((f - 1) // 2 + ns, pc))
+    else:
+        out += [(j - 1 + G.ring, pc) for pc in range(op.npiece)]
+    return [(u, pc) for u, pc in out if u >= 0]
+
+
+def p16_last_piece(op, other):
+    """the piece of a unit that is issued last (the source base advances behind it)"""
+    if op.mode != "kc64":
+        return op.npiece - 1
+    d = P16_DELAY[(op.w, other.mode)]
+    return max(range(len(d)), key=lambda pc: (d[pc], pc))
+
+
+def p16_loader(A, B, j, issue, sched, zero=None):
+    """L(j): the fragment reads of tile j (none in the prologue, j < 0: accumulator zeroing instead) and the DMA requests; an M0 write
+    may not sit directly in front of the LDS-DMA that uses it, so a read (or a zeroing move) goes between them"""
+    reads = (B.reads(j, 0) + A.reads(j, 0)) if j >= 0 else []
+    reqs = []
+    for op, other in ((A, B), (B, A)):
+        for unit, pc in p16_requests(op, other, j):
+            setm0, req = op.pieces(unit)[pc]
+            reqs.append((setm0, req, (op.w, unit), op.advance() if pc == p16_last_piece(op, other) else []))
+    lines = []
+    ri = min(sched["p16_reads_first"], len(reads))
+    lines += reads[:ri]
+
+    def filler():
+        nonlocal ri
+        if ri < len(reads):
+            ri += 1
+            return reads[ri - 1]
+        if zero:
+            return zero.pop(0)
+        return "s_nop 0"
+    for setm0, req, tag, adv in reqs:
+        lines += [setm0, filler(), req]
+        issue.add(tag)
+        lines += adv
+        for _ in range(sched["p16_reads_per_piece"] - 1):
+            if ri < len(reads) or zero:
+                lines.append(filler())
+    lines += reads[ri:]
+    return lines
+
+
+def p16_compute(A, B):
+    order = [(ti, tj) for ti in range(G.fa) for tj in (range(G.fb) if ti % 2 == 0 else range(G.fb - 1, -1, -1))]
+    return [mfma(A, B, ti, tj, 0) for ti, tj in order]
+
+
+def p16_wait(A, B, issue, j):
+    """vmcnt in front of B0(j): this wave's pieces of tile j + 1 have landed"""
+    need = {("a", A.unit_of_tile(j + 1)), ("b", B.unit_of_tile(j + 1))}
+    for tag in need:
+        assert tag in issue.log, f"tile {j + 1}: {tag} not requested before the barrier that publishes it"
+    return issue.wait_count(need)
+
+
+def stream_p16(a_mode, b_mode, sched):
+    A, B = Op("a", a_mode), Op("b", b_mode)
+    trip = 12 if "kc64" in (a_mode, b_mode) else 4
+    L = ["s_nop 4", f"s_mov_b32 s{S_M0}, m0"]
+    for op in (A, B):
+        sg = S_G[op.w]
+        L += [f"s_mov_b32 s{sg}, %[g{op.w}lo]", f"s_mov_b32 s{sg + 1}, %[g{op.w}hi]", f"s_mov_b32 s{S_NEXT[op.w]}, 0",
+              f"s_lshr_b32 s{S_LIM[op.w]}, %[nkt], 1" if op.mode == "kc64" else f"s_mov_b32 s{S_LIM[op.w]}, %[nkt]"]
+    L += [f"s_mov_b32 s{S_CNT}, %[ntrips]"]
+    for op in (A, B):
+        if op.mode == "ks":                      # per-block LDS addresses: base + ((t ^ h) << 5), h = hh(k-row) ^ first block of the wave
+            vb = G.v_ks[op.w]
+            for t in range(op.nfrag):
+                L += [f"v_xor_b32 v{vb + t}, {t}, %[h{op.w}]", f"v_lshl_add_u32 v{vb + t}, v{vb + t}, 5, %[r{op.w}0]"]
+    zero = [f"v_accvgpr_write_b32 a{i}, 0" for i in range(4 * G.nm)]
+    issue = Issue()
+    # prologue: what L(-7) .. L(-1) would have requested, in that order (accumulators zeroed underneath)
+    for j in range(-7, 0):
+        L += p16_loader(A, B, j, issue, dict(sched, p16_reads_per_piece=4), zero)
+    L += zero
+    need0 = {("a", A.unit_of_tile(0)), ("b", B.unit_of_tile(0))}
+    assert all(t in issue.log for t in need0)
+    n0 = issue.wait_count(need0)
+    L += [f"s_waitcnt vmcnt({n0})", "s_barrier", "s_cmp_eq_u32 %[half], 0", "s_cbranch_scc0 YPROG_%="]
+    # The two halves issue the same requests in the same order (L(0), L(1), ...) and either stream has issued exactly L(0) .. L(j) when it
+    # waits in front of B0(j), so one replay of the issue order serves both.
+    ld = {0: p16_loader(A, B, 0, issue, sched)}
+    counts = {}
+    for j in range(3 * trip):
+        counts[j] = p16_wait(A, B, issue, j)
+        ld[j + 1] = p16_loader(A, B, j + 1, issue, sched)
+    comp = p16_compute(A, B)
+
+    def body_x(rep):          # C(j) | B0 | L(j + 1) | B1
+        out = []
+        for j in range(trip * rep, trip * (rep + 1)):
+            out += comp + [f"s_waitcnt vmcnt({counts[j]})", "s_barrier"] + ld[j + 1] + ["s_waitcnt lgkmcnt(0)", "s_barrier"]
+        return out
+
+    def body_y(rep):          # L(j) | B0 | C(j) | B1
+        out = []
+        for j in range(trip * rep, trip * (rep + 1)):
+            out += ld[j] + [f"s_waitcnt vmcnt({counts[j]})", "s_waitcnt lgkmcnt(0)", "s_barrier"] + comp + ["s_barrier"]
+        return out
+    # one loop body per half: the first trip (which follows the prologue's issue order) must equal the steady state
+    assert body_x(0) == body_x(1) == body_x(2), "X: loop body not periodic from the first trip on"
+    assert body_y(0) == body_y(1) == body_y(2), "Y: loop body not periodic from the first trip on"
+    assert sum(i == "s_barrier" for i in body_x(1)) == sum(i == "s_barrier" for i in body_y(1)) == 2 * trip
+    loop_tail = [f"s_sub_u32 s{S_CNT}, s{S_CNT}, 1", f"s_cmp_lg_u32 s{S_CNT}, 0"]
+    X = ld[0] + ["s_waitcnt lgkmcnt(0)", "XLOOP_%=:"] + body_x(1) + loop_tail + ["s_cbranch_scc1 XLOOP_%=", "s_branch PEND_%="]
+    Y = ["s_setprio 1", "YLOOP_%=:"] + body_y(1) + loop_tail + ["s_cbranch_scc1 YLOOP_%=", "s_setprio 0"]
+    L += X + ["YPROG_%=:"] + Y + ["PEND_%=:"]
+    # surplus DMA landed, surplus fragment reads returned, accumulators readable
+    L += ["s_waitcnt vmcnt(0)", "s_waitcnt lgkmcnt(0)", "s_nop 15", "s_nop 15", "s_barrier", f"s_mov_b32 m0, s{S_M0}"]
+    check_scc(L)
+    return ablate(L), [counts[j] for j in range(trip, 2 * trip)], n0, trip
+
+
+SCHED_P16 = {"p16_reads_first": 0, "p16_reads_per_piece": 2}
+
+
+def main_p16(args):
+    """gemm_p16_loop.inc: (A, B) layouts kc/ks (forward), kc/kc (dgrad, LM-head logits), ks/ks (weight gradients)"""
+    global G
+    G = GEOMS["p16"]
+    sched = dict(SCHED_P16)
+    sched["p16_reads_first"] = args.p16_reads_first
+    sched["p16_reads_per_piece"] = args.p16_reads_per_piece
+    kcb = f"kc{args.p16_kcb}"
+    # per-piece delays (load segments after the one that follows the freeing tile): next to a ring operand (2 requests per segment) A's
+    # slot goes 2 + 2 -> 4 requests in every load segment; next to a 64-k-slot B (4 requests after every odd tile) A's slot waits one segment
+    P16_DELAY.update({("a", "ks"): [0, 0, 1, 1], ("a", "kc32"): [0, 0, 1, 1], ("a", "kc64"): [1, 1, 1, 1], ("b", "kc64"): [0, 0, 0, 0]})
+    if args.p16_no_spread:
+        P16_DELAY.update({("a", "ks"): [0, 0, 0, 0], ("a", "kc32"): [0, 0, 0, 0], ("a", "kc64"): [0, 0, 0, 0]})
+    G.npiece64["b"] = 4
+    G.slot64["b"] = 32768
+    out = args.out.replace("gemm_a16_loop.inc", "gemm_p16_loop.inc")
+    txt = ["// GENERATED by tools/gen_gemm_a16.py --geom p16 -- do not edit; the generator is the source (design notes above stream_p16).",
+           f"// schedule: {sched}; request delays {dict((k[0] + '|' + k[1], v) for k, v in P16_DELAY.items())}",
+           f"#define NEKO_P16_KC_MODE_B {64 if kcb == 'kc64' else 32}", ""]
+    for a_kc, b_kc in ((True, False), (True, True), (False, False)):
+        name = f"NEKO_P16_LOOP_{'KC' if a_kc else 'KS'}_{'KC' if b_kc else 'KS'}"
+        L, counts, n0, trip = stream_p16("kc64" if a_kc else "ks", kcb if b_kc else "ks", sched)
+        txt.append(f"// {name}: {trip} k-tiles per loop trip; vmcnt at the prologue wait {n0}, in front of B0 of the tiles of a trip {counts}")
+        txt.append(f"#define {name} \\")
+        txt += [f'  "{ins}\\n\\t" \\' for ins in L[:-1]]
+        txt.append(f'  "{L[-1]}"')
+        txt.append("")
+    txt.append(f"#define NEKO_P16_CLOBBERS {clobbers()}")
+    txt.append("")
+    open(out, "w").write("\n".join(txt))
+    print(out, sum(len(t) for t in txt), "bytes")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--geom", default="a16", choices=tuple(GEOMS), help="workgroup geometry (see Geom)")
@@ -332,6 +521,10 @@ def main():
     ap.add_argument("--no-snake", action="store_true", help="row-major MFMA order instead of the serpentine one")
     ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "neko_amd", "csrc",
                                                   "gemm_a16_loop.inc"))
+    ap.add_argument("--p16-kcb", type=int, default=64, choices=(32, 64), help="p16: a k-contiguous B in two 64-k slots of whole lines (default) or in the 32-k ring")
+    ap.add_argument("--p16-no-spread", action="store_true", help="p16: a slot's four requests in ONE load segment (A/B runs)")
+    ap.add_argument("--p16-reads-first", type=int, default=SCHED_P16["p16_reads_first"], help="p16: fragment reads in front of the first DMA request of a load segment")
+    ap.add_argument("--p16-reads-per-piece", type=int, default=SCHED_P16["p16_reads_per_piece"], help="p16: fragment reads issued with every DMA request")
     ap.add_argument("--ring-lead", type=int, default=3, choices=(3, 4),
                     help="k-tiles of lead of the 32-k ring requests (a16 only: 4 = the stage of tile t, whose fragments were read during tile "
                          "t - 1, is refilled with tile t + 4 during tile t -- probe, profiles/r05_gemm_ring_lead.txt)")
@@ -342,6 +535,8 @@ def main():
     assert RING_LEAD == 3 or args.geom == "a16"
     if args.geom == "b16":
         return main_b16(args)
+    if args.geom == "p16":
+        return main_p16(args)
     SCHED.update(read_span=args.read_span, dma_first=args.dma_first, dma_step=args.dma_step, snake=not args.no_snake)
     kc = f"kc{args.kc}"
     kcb = f"kc{args.kcb or args.kc}"
