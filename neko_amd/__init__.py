@@ -6,6 +6,7 @@ import os as _os
 # sooner (measured: C2 step -4 %, metric step -1 %).  Only effective when set before the HIP runtime initialises, i.e.
 # when this package (or the entry script) is imported before the first GPU call; harmless otherwise.
 _os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
-# Hardware queues the process's HIP streams share (default 4): the compute stream, the weight-gradient side stream, c10d's communication
-# stream and RCCL's own streams need one each, or launches that should overlap serialise (profiles/r05_hwq_matrix.txt).  Same condition.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# (GPU_MAX_HW_QUEUES=8 -- compute, weight-gradient side stream, c10d and RCCL streams on hardware queues of their own,
+# profiles/r05_hwq_matrix.txt -- is a process-wide HIP runtime setting under which OTHER multi-stream captured graphs of a host process
+# replay slower (profiles/r05_capture_hwq.txt), so the package no longer sets it on import: the entry scripts bench.py / train.py do, and
+# INTEGRATION.md section 3 tells an embedding application to.)

@@ -18,7 +18,7 @@
 #endif
 #include NEKO_P16_LOOP_INC
 #ifndef NEKO_P16_TRACE
-#define NEKO_P16_TRACE 0     // 1 (diagnostic builds): s_memtime at the loop's ends of wave 0 into colsum_ws[2 * block] (tools/probe/p16_trace.py)
+#define NEKO_P16_TRACE 0     // 1 (diagnostic builds): s_memtime around the asm loop (prologue requests included) of wave 0, behind the bands of colsum_ws (tools/probe/p16_trace.py)
 #endif
 
 namespace {
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(512, 2) void gemm_p16_kernel(GemmArgs p) {
     kbeg = slice * p.k_per_split;
     kend = min(p.K, kbeg + p.k_per_split);
   }
-  const unsigned nkt = (unsigned)(kend - kbeg) / 32u, ntrips = nkt / (A_KC ? 12u : 4u);
+  const unsigned nkt = (unsigned)(kend - kbeg) / 32u, ntrips = nkt / (A_KC ? (unsigned)NEKO_P16_TRIP_KC : 4u);
 
   const unsigned lds0 = __builtin_amdgcn_readfirstlane(
       (unsigned)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)smem));
@@ -174,11 +174,14 @@ __global__ __launch_bounds__(512, 2) void gemm_p16_kernel(GemmArgs p) {
 #if NEKO_P16_TRACE
   if (tid == 0 && p.colsum_ws) {
     tr1 = __builtin_amdgcn_s_memtime();
-    reinterpret_cast<unsigned long long*>(p.colsum_ws)[blockIdx.x] = tr1 - tr0;
+    reinterpret_cast<unsigned long long*>(p.colsum_ws + (long)(p.M / 128) * p.N)[blockIdx.x] = tr1 - tr0;      // behind the bands this kernel fills
   }
 #endif
 
   // the loop ends behind a block barrier with every DMA landed: the ring is free for the slabs
+#if NEKO_GEMM_DIAG == 4
+  if (p.M != 12345) return;      // ablation (timing only): no epilogue at all
+#endif
   const bool to_ws = p.splitk > 1;
   float* Cf_out = to_ws ? p.splitk_ws + (long)slice * p.M * p.N : p.Cf;
   const long ldcf_out = to_ws ? p.N : p.ldcf;
@@ -252,7 +255,7 @@ int neko_gemm_p16_try(const GemmArgs& a_in, int a_kstrided, int b_kstrided, int 
   if (a_kstrided && !b_kstrided) return 1;
   GemmArgs a = a_in;
   if ((a.M & 255) || (a.N & 255)) return 1;
-  const int unit = a_kstrided ? 128 : 384;                                   // k-tiles per loop trip x 32
+  const int unit = a_kstrided ? 128 : 32 * NEKO_P16_TRIP_KC;                                   // k-tiles per loop trip x 32
   const int klen = a.splitk > 1 ? a.k_per_split : a.K;
   if (klen < unit || (klen % unit)) return 1;
   if (a.splitk > 1) {                                                         // every slice a whole number of loop trips
@@ -280,7 +283,11 @@ int neko_gemm_p16_try(const GemmArgs& a_in, int a_kstrided, int b_kstrided, int 
     // per-shape choice: NEKO_GEMM_P16_RULE (bit mask) selects launch classes for A/B runs: 1 residual epilogues, 2 GELU forward,
     // 4 GELU' dgrad, 8 plain K <= 1536 (forward qkv, dgrad attention out), 16 LM-head logits (N > 16384), 32 long contractions (K > 1536,
     // A k-contiguous), 64 weight gradients (both operands k-strided)
-    static const int rule = [] { const char* e = getenv("NEKO_GEMM_P16_RULE"); return e ? atoi(e) : 0; }();
+    // Default 63 = every class with a k-contiguous A operand: per launch at 65536 rows -6 ... -11 % against gemm_a16 / gemm_b16 /
+    // gemm_glds64 (profiles/r06_p16_first_bench.txt), m-mix step 36.16 -> 35.20 ms (profiles/r06_p16_step_ab.txt); the weight gradients
+    // (both operands k-strided, long contraction) are level with gemm_a16 and stay there.
+    static const int rule = [] { const char* e = getenv("NEKO_GEMM_P16_RULE"); return e ? atoi(e) : 63; }();
+    static const int min_tiles = [] { const char* e = getenv("NEKO_GEMM_P16_MIN_TILES"); return e ? atoi(e) : 512; }();
     const long tiles = (long)(a.M / 256) * (a.N / 256) * (a.splitk > 1 ? a.splitk : 1);
     int cls;
     if (a_kstrided) cls = 64;
@@ -289,7 +296,7 @@ int neko_gemm_p16_try(const GemmArgs& a_in, int a_kstrided, int b_kstrided, int 
     else if (f & F_GELUBWD) cls = 4;
     else if (a.N > 16384) cls = 16;
     else cls = klen <= 1536 ? 8 : 32;
-    if (!(rule & cls) || tiles < 192) return 1;
+    if (!(rule & cls) || tiles < min_tiles) return 1;
   }
   a.epi_lock = 0;
   const int rc = dispatch_p16(a, !a_kstrided, !b_kstrided, f, s);

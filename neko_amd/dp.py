@@ -77,6 +77,10 @@ class GradReducer:
         if (self.world == 1 and not self.force) or not self.sync or gname not in self.flat.group_ranges or gname in self.DEFERRED:
             return
         a, b = self.flat.group_ranges[gname]
+        if gname == "head":
+            # first range of a backward: a run left behind by a backward that raised (or by a caller that skipped flush()) must not be
+            # issued now, on this rank only -- the collective sequences of the ranks would diverge
+            self._run = None
         # ranges finish from the end of the flat buffer towards its start (head, ln_f, layer L-1 .. 0): extend the waiting run downwards,
         # or start a new one behind a gap.  The decision depends on the range order and sizes only, so every rank issues the same collectives.
         if self._run is not None and self._run[0] == b:
@@ -96,7 +100,9 @@ class GradReducer:
             self._reduce_range(a, b)
 
     def flush(self) -> None:
-        """After backward: reduce what is still waiting, then the ranges that are not guaranteed to be touched on every rank."""
+        """After backward: reduce what is still waiting, then the ranges that are not guaranteed to be touched on every rank.
+        MANDATORY after every synchronised backward: a trailing run below `min_run_elems` and the DEFERRED ranges are only reduced here
+        (`finish()` refuses to go on when a run is still waiting)."""
         if (self.world == 1 and not self.force) or not self.sync:
             return
         self._issue_run()
@@ -186,6 +192,9 @@ class GradReducer:
 
     def finish(self) -> None:
         """Make the current stream wait for every outstanding reduction (no host block on CUDA)."""
+        if self._run is not None:
+            raise RuntimeError("GradReducer.finish(): finished gradient ranges are still waiting for their all-reduce -- flush() has to be "
+                               "called after backward and before finish()")
         for h, staged, g in self.handles:
             h.wait()
             if staged is not None:

@@ -11,7 +11,9 @@ statistics, softmax, logits, loss and all gradients of parameters are fp32; MFMA
 """
 from __future__ import annotations
 
+import contextlib
 import os
+import threading
 from dataclasses import dataclass, field
 from typing import Callable, List, Optional
 
@@ -144,6 +146,22 @@ class SideStream:
     rows_hint = 0            # rows of the step being differentiated (set by the backward entry points)
     _streams: dict = {}
     _dirty: dict = {}
+    _tls = threading.local()  # .off > 0: this THREAD keeps everything on its current stream (a step being captured; ADVICE r05: the
+                              # capture used to flip the class-wide `enabled`, which another thread's eager backward would have seen)
+
+    @classmethod
+    def _on(cls) -> bool:
+        return cls.enabled and getattr(cls._tls, "off", 0) == 0
+
+    @classmethod
+    @contextlib.contextmanager
+    def suspended(cls):
+        """`with SideStream.suspended():` -- launches of the calling thread stay on its current stream (stream capture)."""
+        cls._tls.off = getattr(cls._tls, "off", 0) + 1
+        try:
+            yield
+        finally:
+            cls._tls.off -= 1
 
     @classmethod
     def _get(cls, dev) -> "torch.cuda.Stream":
@@ -155,7 +173,7 @@ class SideStream:
     @classmethod
     def fork(cls, fn: Callable[[], None], *temps: torch.Tensor) -> None:
         dev = temps[0].device if temps else torch.device("cuda", torch.cuda.current_device())
-        if not cls.enabled or dev.type != "cuda" or (cls.auto and cls.rows_hint >= cls.ONE_STREAM_ROWS):
+        if not cls._on() or dev.type != "cuda" or (cls.auto and cls.rows_hint >= cls.ONE_STREAM_ROWS):
             fn()
             return
         side = cls._get(dev)
@@ -170,14 +188,14 @@ class SideStream:
     def pending(cls, dev=None) -> Optional["torch.cuda.Stream"]:
         """The side stream if launches are outstanding on it, else None.  A consumer that runs on a stream of its own (the gradient
         all-reduce) orders itself behind it instead of making the compute stream wait for the weight gradients (join())."""
-        if not cls.enabled or not torch.cuda.is_available():
+        if not cls._on() or not torch.cuda.is_available():
             return None
         key = torch.device(dev).index if (dev is not None and torch.device(dev).index is not None) else torch.cuda.current_device()
         return cls._streams[key] if cls._dirty.get(key) else None
 
     @classmethod
     def join(cls, dev=None) -> None:
-        if not cls.enabled or not torch.cuda.is_available():
+        if not cls._on() or not torch.cuda.is_available():
             return
         key = torch.device(dev).index if (dev is not None and torch.device(dev).index is not None) else torch.cuda.current_device()
         if cls._dirty.get(key):

@@ -250,7 +250,9 @@ class VarlenGeom:
     (that form stalls the host in eager mode and leaves a dangling host pointer in a captured graph)."""
 
     _cache: "dict" = {}
-    _CACHE_MAX = 256
+    _CACHE_MAX = 256          # unpinned entries
+    _PINNED_WARN = 64         # warn once when captured steps hold this many
+    _warned = False
 
     def __init__(self, lengths, H: int, device):
         self.lengths = [int(t) for t in lengths]
@@ -261,7 +263,7 @@ class VarlenGeom:
             nb = (t + 31) // 32
             moff.append(moff[-1] + self.H * nb * nb * 32)
         self.rows, self.mask_dwords = off[-1], moff[-1]
-        self.pinned_by_capture = False
+        self.pinned_by_capture = False          # set on first use under stream capture; never cleared (the graph may be replayed any time)
         pin = torch.device(device).type == "cuda"
         self._host_off = torch.tensor(off, dtype=torch.int32)
         self._host_moff = torch.tensor(moff[:-1], dtype=torch.int64)
@@ -275,13 +277,18 @@ class VarlenGeom:
         key = (tuple(int(t) for t in lengths), int(H), str(device))
         g = cls._cache.get(key)
         if g is None:
-            if len(cls._cache) >= cls._CACHE_MAX:
-                # evict the oldest geometry that no captured graph points at (a HIP graph bakes seq_off / mask_off and,
-                # when the geometry was built inside the capture, the pinned sources of their uploads into its nodes)
-                for k, old in cls._cache.items():
-                    if not old.pinned_by_capture:
-                        del cls._cache[k]
-                        break
+            # only geometries that no captured graph points at count against the limit and are evicted (a HIP graph bakes
+            # seq_off / mask_off and, when the geometry was built inside the capture, the pinned sources of their uploads into its nodes;
+            # with every entry pinned nothing was evicted and the cache grew without a bound that anybody saw)
+            free = [k for k, old in cls._cache.items() if not old.pinned_by_capture]
+            if len(free) >= cls._CACHE_MAX:
+                del cls._cache[free[0]]
+            npinned = len(cls._cache) - len(free)
+            if npinned >= cls._PINNED_WARN and not cls._warned:
+                cls._warned = True
+                import warnings
+                warnings.warn(f"VarlenGeom: {npinned} packed-attention geometries are held by captured steps (each keeps pinned host "
+                              "buffers and device tensors for the life of the process)")
             g = cls._cache[key] = cls(lengths, H, device)
         if not g.pinned_by_capture and torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
             g.pinned_by_capture = True           # used (or built) while a step is being captured: lives as long as the process

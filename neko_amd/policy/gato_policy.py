@@ -384,7 +384,7 @@ LAYOUT_CACHE = int(os.environ.get("NEKO_LAYOUT_CACHE", "32"))
 
 
 class _LayoutEntry:
-    __slots__ = ("B", "T", "segments", "order", "has_text", "desc_dev", "idx_dev", "n_sel", "map_dev", "tgt_dev")
+    __slots__ = ("B", "T", "segments", "order", "has_text", "desc_dev", "idx_dev", "n_sel", "map_dev", "tgt_dev")      # (the key holds sorted_tail)
 
 
 class _Prepared:
@@ -394,6 +394,7 @@ class _Prepared:
 
     def __init__(self):
         self.B = self.T = 0
+        self.sorted_tail = False     # the tail of `desc` really holds host-sorted (key, row) pairs (not the KEY_NONE placeholder)
         self.desc = self.cont = self.disc = None
         self.img_order, self.img_ids, self.img_groups, self.given = [], [], [], []
         self.pack: Optional[_PackInfo] = None
@@ -633,6 +634,7 @@ class GatoPolicy(nn.Module):
                                "embed_token never receive gradients (GradReducer.declare_unused_rows)")
         pr = _Prepared()
         pr.B, pr.T = pb.B, pb.T
+        pr.sorted_tail = sorted_tail        # (part of the cache key: a hit was built in the same mode)
         if hit is not None:
             pr.desc, idx_dev, n_sel, map_dev, tgt_dev = hit.desc_dev, hit.idx_dev, hit.n_sel, hit.map_dev, hit.tgt_dev
         else:
@@ -697,7 +699,7 @@ class GatoPolicy(nn.Module):
                 parts.append(e.reshape(-1, self.embed_dim))
             img_emb = parts[0] if len(parts) == 1 else torch.cat(parts, dim=0)
         params = [self._flat.param_of[n] for n in self._frontend_names()]
-        x, tokens, tmask, pmask = _PackEmbedV2.apply(self, pr.desc, pr.cont, pr.disc, img_emb, pr.B * pr.T, *params)
+        x, tokens, tmask, pmask = _PackEmbedV2.apply(self, pr.desc, pr.cont, pr.disc, img_emb, pr.B * pr.T, bool(pr.sorted_tail), *params)
         B, T, d = pr.B, pr.T, self.embed_dim
         self.last_pack = pr.pack
         return x.view(B, T, d), tokens.view(B, T), tmask.view(B, T), pmask.view(B, T), pr.pack
@@ -881,7 +883,7 @@ class _PackEmbedV2(torch.autograd.Function):
     d_x into embed_token / pos_embed_observation / separator_token grads and returns d(img_emb)."""
 
     @staticmethod
-    def forward(ctx, policy: GatoPolicy, desc, cont, disc, img_emb, ntok, *params):
+    def forward(ctx, policy: GatoPolicy, desc, cont, disc, img_emb, ntok, sorted_tail, *params):
         f = policy._flat
         d = policy.embed_dim
         img = None if img_emb is None else img_emb.detach().contiguous()
@@ -890,6 +892,8 @@ class _PackEmbedV2(torch.autograd.Function):
             f.view("separator_token"), ntok, d, policy.mu, policy.M, policy.continuous_tokens,
             policy.token_starts["continuous"], policy.token_starts["discrete"])
         ctx.policy, ctx.desc, ctx.tokens, ctx.ntok = policy, desc, tokens, ntok
+        # explicit, never inferred from desc.numel(): a batch prepared under no_grad carries a placeholder tail
+        ctx.sorted_tail = bool(sorted_tail)
         ctx.img_rows = 0 if img_emb is None else img_emb.shape[0]
         ctx.mark_non_differentiable(tokens, tmask, pmask)
         return x, tokens, tmask, pmask
@@ -906,7 +910,7 @@ class _PackEmbedV2(torch.autograd.Function):
             d_img = torch.zeros(ctx.img_rows, d, dtype=torch.float32, device=gx.device)
         ops.pack_embed_bwd(ctx.desc, ctx.tokens, gx.view(-1, d), f.gview("embed_token.weight"),
                            f.gview("pos_embed_observation.weight"), f.gview("separator_token"), d_img, ctx.ntok, d,
-                           sorted_tail=ctx.desc.numel() >= 6 * ctx.ntok)
+                           sorted_tail=ctx.sorted_tail)
         f.attach_grads(names)
         if policy._dp is not None:
             policy._dp.group_ready("frontend")

@@ -145,9 +145,6 @@ class CapturedTrainStep:
         # replays on queues of its own -- level with one stream at best (c2: 6.2 vs 6.0 ms with 4 hardware queues) and 1.5x SLOWER
         # with the 8 queues the package asks for (9.3 ms; profiles/r05_capture_hwq.txt)
         from .. import engine
-        side_prev, engine.SideStream.enabled = engine.SideStream.enabled, False
-        try:
+        with engine.SideStream.suspended():          # thread-local, not the class-wide switch
             with torch.cuda.graph(e.graph):
                 e.loss, e.gnorm = self._body(st)
-        finally:
-            engine.SideStream.enabled = side_prev

@@ -40,9 +40,10 @@ def _dev_batch(batch):
 
 def _compare(cfg: O.OracleConfig, batch, seed: int, row_stride: int, loss_tol=1e-3, logit_tol=2e-2, gn_tol=2e-2,
              total_tol=5e-3, det=False):
-    """det: the embedding / patch-position table gradients through the fixed-order segment sums (what NEKO_DETERMINISTIC=1 selects)
-    instead of fp32 atomics -- at 24 layers the atomically summed patch-position parameters measured 0.9-1.4e-2 of their norm from run
-    to run (70 % of the 2e-2 gate); with the sorted sums the number is the same every run."""
+    """det: ALSO the `embed_token` rows through the fixed-order segment sums (what NEKO_DETERMINISTIC=1 selects).  Since round 5 the
+    position / separator / patch-position tables are host-sorted segment sums by default (the atomically summed patch-position parameters
+    had measured 0.9-1.4e-2 of their norm from run to run at 24 layers), so the 24-layer cases run in the default
+    mode: the shipped path is what the oracle gate covers."""
     from neko_amd import ops as _ops
     prev_det = _ops.SCATTER_DET
     _ops.SCATTER_DET = bool(det) or prev_det
@@ -144,7 +145,7 @@ def test_c5_full_depth_24_layers_2048d_hd128_vs_oracle():
               "discrete_actions": torch.randint(0, 4, (2, 1), generator=g).to(torch.int32)}]
     # measured: loss 4e-5, logits 7e-3, worst per-parameter gradient norm 7e-3, total norm 4e-3 (24 layers of bf16-operand
     # rounding accumulate in the total: its gate is 1e-2 here, the others are the standard ones)
-    _compare(cfg, batch, seed=14, row_stride=5, total_tol=1e-2, det=True)
+    _compare(cfg, batch, seed=14, row_stride=5, total_tol=1e-2)       # default mode: host-sorted segment sums for the position tables
 
 
 def _control(n_obs, n_act, n_ts, g):
@@ -180,7 +181,7 @@ def test_c5_full_size_2048d_24L_T1024_V52305_vs_oracle():
     gradient norm 1e-2 (24 layers of bf16-operand rounding accumulate in it, as in the T = 201 case above)."""
     from neko_amd.tasks import synthetic as S
     cfg = O.OracleConfig(embed_dim=2048, layers=24, heads=16)
-    _compare(cfg, S.metric_mix_batch(1, 8, "cpu"), seed=17, row_stride=61, total_tol=1e-2, det=True)
+    _compare(cfg, S.metric_mix_batch(1, 8, "cpu"), seed=17, row_stride=61, total_tol=1e-2)      # default mode (ADVICE r05)
 
 
 def test_training_trace_100_steps_on_the_metric_model_vs_oracle():

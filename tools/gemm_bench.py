@@ -53,6 +53,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--only", default="")
+    ap.add_argument("--names", default="", help="comma-separated exact shape names (stripped) instead of --only")
+    ap.add_argument("--p16-trace", action="store_true", help="with a -DNEKO_P16_TRACE=1 build: clocks of gemm_p16's loop per k-tile (GELU' dgrad shape)")
     ap.add_argument("--safe", type=int, default=0)
     ap.add_argument("--sk", type=int, default=0, help="force this split-K factor on the split-K shapes")
     ap.add_argument("--dim", type=int, default=0, help="embed dim instead of 768 (2048 = the Gato-1.2B geometry)")
@@ -76,6 +78,8 @@ def main():
     tot_us = 0.0
     for name, m, n, k, aks, bks, ex in SHAPES:
         if args.only and args.only not in name:
+            continue
+        if args.names and " ".join(name.split()) not in [" ".join(x.split()) for x in args.names.split(",")]:
             continue
         A = (torch.randn((k, m) if aks else (m, k), device=dev, generator=g)).to(BF)
         Bm = (torch.randn((k, n) if bks else (n, k), device=dev, generator=g) * 0.05).to(BF)
@@ -137,6 +141,26 @@ def main():
               + (f"  splitk={kw['splitk']}" if kw.get("splitk", 1) > 1 else ""))
         del A, Bm, kw
     print(f"sum {tot_us:.1f} us")
+    if args.p16_trace:
+        from neko_amd import _lib
+        rows = args.rows or M
+        m, n, k = rows, 4 * D, D
+        dY = torch.randn(m, k, device=dev, generator=g).to(BF)
+        W = (torch.randn(n, k, device=dev, generator=g) * 0.05).to(BF)
+        fac = torch.rand(m, n, device=dev, generator=g).to(BF)
+        out = torch.empty(m, n, dtype=BF, device=dev)
+        cs = torch.zeros(n, device=dev)
+        ws = torch.zeros(int(_lib.load().neko_gemm_colsum_ws_floats(m, n)), device=dev)
+        for _ in range(3):
+            _lib.call("neko_gemm_dgrad_gelu_colsum", dY.data_ptr(), k, W.data_ptr(), k, m, n, k, fac.data_ptr(), n, 1, out.data_ptr(), n,
+                      ws.data_ptr(), cs.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert ops.gemm_last_mainloop() == 5, "the trace needs gemm_p16 (NEKO_GEMM_P16=1)"
+        nblk = (m // 256) * (n // 256)
+        t = ws[(m // 128) * n:].view(torch.int64)[:nblk].cpu().double()
+        nkt = k // 32
+        print(f"p16 trace (GELU' dgrad {m} x {n} x {k}, {nblk} blocks): asm loop incl. prologue requests {float(t.mean()):.0f} clocks "
+              f"(p10 {float(t.quantile(0.1)):.0f}, p90 {float(t.quantile(0.9)):.0f}) = {float(t.mean()) / nkt:.1f} per k-tile of 32")
 
 
 if __name__ == "__main__":

@@ -411,7 +411,7 @@ def p16_wait(A, B, issue, j):
 
 def stream_p16(a_mode, b_mode, sched):
     A, B = Op("a", a_mode), Op("b", b_mode)
-    trip = 12 if "kc64" in (a_mode, b_mode) else 4
+    trip = 12 if a_mode == "kc64" and A.nslot == 3 else 4
     L = ["s_nop 4", f"s_mov_b32 s{S_M0}, m0"]
     for op in (A, B):
         sg = S_G[op.w]
@@ -426,10 +426,16 @@ def stream_p16(a_mode, b_mode, sched):
     zero = [f"v_accvgpr_write_b32 a{i}, 0" for i in range(4 * G.nm)]
     issue = Issue()
     # prologue: what L(-7) .. L(-1) would have requested, in that order (accumulators zeroed underneath)
+    need0 = {("a", A.unit_of_tile(0)), ("b", B.unit_of_tile(0))}
+    early = False
     for j in range(-7, 0):
         L += p16_loader(A, B, j, issue, dict(sched, p16_reads_per_piece=4), zero)
+        if sched["p16_early_wait"] and not early and all(t in issue.log for t in need0):
+            # --p16-early-wait: tile 0's units land before the rest of the prologue is requested (every CU of the chip is in its
+            # prologue at the same time: ~160 KB per CU requested at once delay the 48 KB the first k-tile needs)
+            L += [f"s_waitcnt vmcnt({issue.wait_count(need0)})"]
+            early = True
     L += zero
-    need0 = {("a", A.unit_of_tile(0)), ("b", B.unit_of_tile(0))}
     assert all(t in issue.log for t in need0)
     n0 = issue.wait_count(need0)
     L += [f"s_waitcnt vmcnt({n0})", "s_barrier", "s_cmp_eq_u32 %[half], 0", "s_cbranch_scc0 YPROG_%="]
@@ -441,25 +447,29 @@ def stream_p16(a_mode, b_mode, sched):
         counts[j] = p16_wait(A, B, issue, j)
         ld[j + 1] = p16_loader(A, B, j + 1, issue, sched)
     comp = p16_compute(A, B)
+    # B1 is a scheduling barrier only (LDS visibility and slot reuse hang on B0): --p16-no-b1 drops it, the two halves then overlap
+    # [L, C] with [C, L] between two B0s as the hardware arbitrates
+    b1 = ["s_barrier"] if sched["p16_b1"] else []
 
     def body_x(rep):          # C(j) | B0 | L(j + 1) | B1
         out = []
         for j in range(trip * rep, trip * (rep + 1)):
-            out += comp + [f"s_waitcnt vmcnt({counts[j]})", "s_barrier"] + ld[j + 1] + ["s_waitcnt lgkmcnt(0)", "s_barrier"]
+            out += comp + [f"s_waitcnt vmcnt({counts[j]})", "s_barrier"] + ld[j + 1] + ["s_waitcnt lgkmcnt(0)"] + b1
         return out
 
     def body_y(rep):          # L(j) | B0 | C(j) | B1
         out = []
         for j in range(trip * rep, trip * (rep + 1)):
-            out += ld[j] + [f"s_waitcnt vmcnt({counts[j]})", "s_waitcnt lgkmcnt(0)", "s_barrier"] + comp + ["s_barrier"]
+            out += ld[j] + [f"s_waitcnt vmcnt({counts[j]})", "s_waitcnt lgkmcnt(0)", "s_barrier"] + comp + b1
         return out
     # one loop body per half: the first trip (which follows the prologue's issue order) must equal the steady state
     assert body_x(0) == body_x(1) == body_x(2), "X: loop body not periodic from the first trip on"
     assert body_y(0) == body_y(1) == body_y(2), "Y: loop body not periodic from the first trip on"
-    assert sum(i == "s_barrier" for i in body_x(1)) == sum(i == "s_barrier" for i in body_y(1)) == 2 * trip
+    assert sum(i == "s_barrier" for i in body_x(1)) == sum(i == "s_barrier" for i in body_y(1)) == (2 if sched["p16_b1"] else 1) * trip
     loop_tail = [f"s_sub_u32 s{S_CNT}, s{S_CNT}, 1", f"s_cmp_lg_u32 s{S_CNT}, 0"]
     X = ld[0] + ["s_waitcnt lgkmcnt(0)", "XLOOP_%=:"] + body_x(1) + loop_tail + ["s_cbranch_scc1 XLOOP_%=", "s_branch PEND_%="]
-    Y = ["s_setprio 1", "YLOOP_%=:"] + body_y(1) + loop_tail + ["s_cbranch_scc1 YLOOP_%=", "s_setprio 0"]
+    Y = (["s_setprio 1"] if sched["p16_setprio"] else []) + ["YLOOP_%=:"] + body_y(1) + loop_tail + ["s_cbranch_scc1 YLOOP_%="] + \
+        (["s_setprio 0"] if sched["p16_setprio"] else [])
     L += X + ["YPROG_%=:"] + Y + ["PEND_%=:"]
     # surplus DMA landed, surplus fragment reads returned, accumulators readable
     L += ["s_waitcnt vmcnt(0)", "s_waitcnt lgkmcnt(0)", "s_nop 15", "s_nop 15", "s_barrier", f"s_mov_b32 m0, s{S_M0}"]
@@ -467,7 +477,7 @@ def stream_p16(a_mode, b_mode, sched):
     return ablate(L), [counts[j] for j in range(trip, 2 * trip)], n0, trip
 
 
-SCHED_P16 = {"p16_reads_first": 0, "p16_reads_per_piece": 2}
+SCHED_P16 = {"p16_reads_first": 0, "p16_reads_per_piece": 2, "p16_setprio": True, "p16_b1": True, "p16_early_wait": False}
 
 
 def main_p16(args):
@@ -477,18 +487,23 @@ def main_p16(args):
     sched = dict(SCHED_P16)
     sched["p16_reads_first"] = args.p16_reads_first
     sched["p16_reads_per_piece"] = args.p16_reads_per_piece
+    sched["p16_setprio"] = not args.p16_no_setprio
+    sched["p16_b1"] = not args.p16_no_b1
+    sched["p16_early_wait"] = args.p16_early_wait
+    G.nslot["a"] = args.p16_nslot_a
     kcb = f"kc{args.p16_kcb}"
     # per-piece delays (load segments after the one that follows the freeing tile): next to a ring operand (2 requests per segment) A's
     # slot goes 2 + 2 -> 4 requests in every load segment; next to a 64-k-slot B (4 requests after every odd tile) A's slot waits one segment
     P16_DELAY.update({("a", "ks"): [0, 0, 1, 1], ("a", "kc32"): [0, 0, 1, 1], ("a", "kc64"): [1, 1, 1, 1], ("b", "kc64"): [0, 0, 0, 0]})
-    if args.p16_no_spread:
+    if args.p16_no_spread or args.p16_nslot_a == 2:
         P16_DELAY.update({("a", "ks"): [0, 0, 0, 0], ("a", "kc32"): [0, 0, 0, 0], ("a", "kc64"): [0, 0, 0, 0]})
     G.npiece64["b"] = 4
     G.slot64["b"] = 32768
     out = args.out.replace("gemm_a16_loop.inc", "gemm_p16_loop.inc")
     txt = ["// GENERATED by tools/gen_gemm_a16.py --geom p16 -- do not edit; the generator is the source (design notes above stream_p16).",
            f"// schedule: {sched}; request delays {dict((k[0] + '|' + k[1], v) for k, v in P16_DELAY.items())}",
-           f"#define NEKO_P16_KC_MODE_B {64 if kcb == 'kc64' else 32}", ""]
+           f"#define NEKO_P16_KC_MODE_B {64 if kcb == 'kc64' else 32}",
+           f"#define NEKO_P16_TRIP_KC {12 if args.p16_nslot_a == 3 else 4}      // k-tiles per loop trip with a k-contiguous A operand", ""]
     for a_kc, b_kc in ((True, False), (True, True), (False, False)):
         name = f"NEKO_P16_LOOP_{'KC' if a_kc else 'KS'}_{'KC' if b_kc else 'KS'}"
         L, counts, n0, trip = stream_p16("kc64" if a_kc else "ks", kcb if b_kc else "ks", sched)
@@ -522,6 +537,10 @@ def main():
     ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "neko_amd", "csrc",
                                                   "gemm_a16_loop.inc"))
     ap.add_argument("--p16-kcb", type=int, default=64, choices=(32, 64), help="p16: a k-contiguous B in two 64-k slots of whole lines (default) or in the 32-k ring")
+    ap.add_argument("--p16-nslot-a", type=int, default=3, choices=(2, 3), help="p16: 64-k slots of a k-contiguous A operand (2: four k-tiles per loop trip, any K % 128 == 0)")
+    ap.add_argument("--p16-no-b1", action="store_true", help="p16: no barrier between a half's matrix segment and the other half's (one barrier per k-tile)")
+    ap.add_argument("--p16-early-wait", action="store_true", help="p16: the prologue waits for tile 0's units before it requests the rest")
+    ap.add_argument("--p16-no-setprio", action="store_true", help="p16: no static s_setprio 1 on the second half (A/B runs)")
     ap.add_argument("--p16-no-spread", action="store_true", help="p16: a slot's four requests in ONE load segment (A/B runs)")
     ap.add_argument("--p16-reads-first", type=int, default=SCHED_P16["p16_reads_first"], help="p16: fragment reads in front of the first DMA request of a load segment")
     ap.add_argument("--p16-reads-per-piece", type=int, default=SCHED_P16["p16_reads_per_piece"], help="p16: fragment reads issued with every DMA request")
