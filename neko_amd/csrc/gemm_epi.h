@@ -26,13 +26,20 @@ constexpr int BK = 32;
 // B panels pairwise.  (As a 2-D grid the tiles of a slice were dealt round-robin over all eight XCDs and every L2 fetched
 // nearly every panel of every slice: the fc / proj weight gradients moved 730 MB over the fabric for 250 MB of operands.)
 template <int BM, int BN>
+__device__ __forceinline__ void tile_coords_of(const GemmArgs& p, int block, int& tm, int& tn, int& slice);
+template <int BM, int BN>
 __device__ __forceinline__ void tile_coords(const GemmArgs& p, int& tm, int& tn, int& slice) {
+  tile_coords_of<BM, BN>(p, (int)blockIdx.x, tm, tn, slice);
+}
+// (the tile of any block of the launch: gemm_p16.hip asks for the tile of the block that follows its own on the same XCD)
+template <int BM, int BN>
+__device__ __forceinline__ void tile_coords_of(const GemmArgs& p, int block, int& tm, int& tn, int& slice) {
 #ifndef NEKO_GEMM_GROUP_M
 #define NEKO_GEMM_GROUP_M 8        // row panels per rasterisation group (4 / 16 measured in round 3: profiles/r03_step_ab.txt)
 #endif
   const int GROUP_M = p.group_m > 0 ? p.group_m : NEKO_GEMM_GROUP_M;
   const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
-  int bid = xcd_remap(blockIdx.x, gridDim.x);
+  int bid = xcd_remap(block, gridDim.x);
   slice = bid / (nbm * nbn);
   bid -= slice * (nbm * nbn);
   const int per_group = GROUP_M * nbn;
@@ -77,6 +84,50 @@ struct FastEpi {
   static constexpr int CPR = SW / 4, RPI = 64 / CPR;           // float4 chunks per row, rows per wave-instruction
   static_assert(C::NW * SLAB_BYTES <= C::LDS_BYTES, "padded slabs must fit the ring");
 };
+
+// Output stores of the fast epilogue.  NEKO_EPI_STORE_POLICY: 0 plain (write-back: the line stays in the XCD's L2), 1 nt (streaming
+// hint; the default since round 6), 2 sc1 (the line is written through and dropped from the L2: MI355X_MICROARCH.md, stores of each
+// flavour), 3 sc0 sc1.  A tile's output is never read again by the launch that writes it, and the 128-256 KB a workgroup stores per tile
+// (x 32 CUs per XCD = a whole 4 MB L2 per round) compete with the operand panels the main loops of the same launch re-read: with nt the
+// k-loop of the forward qkv GEMM runs at 1200 instead of 1500 clocks per k-tile (profiles/r06_p16_phase_trace.txt), per launch -4 ... -15 %
+// (profiles/r06_p16_variants.txt), per step m-mix -0.16 ms, c4 -6.5 %, c2 -2 %, m-text -2 % (profiles/r06_store_policy_step_ab.txt,
+// r06_nt_sizes_ab.txt); sc1 / sc0 sc1 measured level with plain.
+#ifndef NEKO_EPI_STORE_POLICY
+#define NEKO_EPI_STORE_POLICY 1
+#endif
+#ifndef NEKO_EPI_STORE_POLICY_CF
+#define NEKO_EPI_STORE_POLICY_CF NEKO_EPI_STORE_POLICY      // the fp32 outputs (16-B stores) can take their own policy
+#endif
+typedef uint32_t epi_u32x2 __attribute__((ext_vector_type(2)));
+typedef float epi_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void epi_store8(void* dst, uint2 v) {
+#if NEKO_EPI_STORE_POLICY == 0
+  *reinterpret_cast<uint2*>(dst) = v;
+#else
+  const epi_u32x2 w = {v.x, v.y};
+#if NEKO_EPI_STORE_POLICY == 1
+  asm volatile("global_store_dwordx2 %0, %1, off nt" ::"v"(dst), "v"(w) : "memory");
+#elif NEKO_EPI_STORE_POLICY == 2
+  asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(dst), "v"(w) : "memory");
+#else
+  asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(dst), "v"(w) : "memory");
+#endif
+#endif
+}
+__device__ __forceinline__ void epi_store16(void* dst, float4 v) {
+#if NEKO_EPI_STORE_POLICY_CF == 0
+  *reinterpret_cast<float4*>(dst) = v;
+#else
+  const epi_f32x4 w = {v.x, v.y, v.z, v.w};
+#if NEKO_EPI_STORE_POLICY_CF == 1
+  asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(dst), "v"(w) : "memory");
+#elif NEKO_EPI_STORE_POLICY_CF == 2
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(w) : "memory");
+#else
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(w) : "memory");
+#endif
+#endif
+}
 
 template <int N, int I = 0, class Fn>
 __device__ __forceinline__ void static_for(Fn&& fn) {
@@ -179,14 +230,14 @@ __device__ __forceinline__ void epilogue_fast(const GemmArgs& p, const Park& par
 #if NEKO_EPI_ABL == 1
           asm volatile("" ::"v"(d01), "v"(d23));
 #else
-          *reinterpret_cast<uint2*>(ppre) = make_uint2(pack_bf16x2(d01.x, d01.y), pack_bf16x2(d23.x, d23.y));
+          epi_store8(ppre, make_uint2(pack_bf16x2(d01.x, d01.y), pack_bf16x2(d23.x, d23.y)));
 #endif
           v[0] = g01.x; v[1] = g01.y; v[2] = g23.x; v[3] = g23.y;
         } else {
 #if NEKO_EPI_ABL == 1
           if (F & F_PRE) asm volatile("" ::"v"(p01), "v"(p23));
 #else
-          if (F & F_PRE) *reinterpret_cast<uint2*>(ppre) = make_uint2(p01, p23);
+          if (F & F_PRE) epi_store8(ppre, make_uint2(p01, p23));
 #endif
 #if NEKO_EPI_ABL == 2
           const f32x2_v g01 = x01, g23 = x23;
@@ -216,12 +267,12 @@ __device__ __forceinline__ void epilogue_fast(const GemmArgs& p, const Park& par
           const float4 q = pre_acc[st];
           o.x += q.x; o.y += q.y; o.z += q.z; o.w += q.w;
         }
-        *reinterpret_cast<float4*>(pcf) = o;
+        epi_store16(pcf, o);
       }
 #if NEKO_EPI_ABL == 1
       if (F & F_CB) asm volatile("" ::"v"(pack_bf16x2(v[0], v[1])), "v"(pack_bf16x2(v[2], v[3])));
 #else
-      if (F & F_CB) *reinterpret_cast<uint2*>(pcb) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+      if (F & F_CB) epi_store8(pcb, make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])));
 #endif
       // next RPI rows
       if (F & F_CF) pcf += scf;

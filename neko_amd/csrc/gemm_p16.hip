@@ -18,7 +18,22 @@
 #endif
 #include NEKO_P16_LOOP_INC
 #ifndef NEKO_P16_TRACE
-#define NEKO_P16_TRACE 0     // 1 (diagnostic builds): s_memtime around the asm loop (prologue requests included) of wave 0, behind the bands of colsum_ws (tools/probe/p16_trace.py)
+#define NEKO_P16_TRACE 0     // 1 (diagnostic builds): s_memtime around the asm loop (prologue requests included) of wave 0, behind the bands of colsum_ws
+                             // (tools/gemm_bench.py --p16-trace); 2: per block 8 x u64 {s_memrealtime at entry / loop start / loop end / stores
+                             // issued / stores drained, HW_ID | XCC_ID << 32, s_memtime at loop start / loop end} into the buffer set with
+                             // neko_gemm_p16_trace() (tools/probe/p16_phase_trace.py)
+#endif
+#if NEKO_P16_TRACE == 2
+__device__ unsigned long long* g_neko_p16_trace = nullptr;
+extern "C" int neko_gemm_p16_trace(void* buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_neko_p16_trace), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
+}
+#define P16_STAMP(slot, val)                                                              \
+  do {                                                                                    \
+    if (g_neko_p16_trace && threadIdx.x == 0) g_neko_p16_trace[(long)blockIdx.x * 8 + (slot)] = (val); \
+  } while (0)
+#else
+#define P16_STAMP(slot, val) do { } while (0)
 #endif
 
 namespace {
@@ -61,6 +76,8 @@ __device__ __forceinline__ int ks_hh_p(int k) { return (k & 3) | (((k >> 3) & 1)
 // moves accumulator tuples through scratch memory).
 template <bool A_KC, bool B_KC, unsigned F>
 __global__ __launch_bounds__(512, 2) void gemm_p16_kernel(GemmArgs p) {
+  P16_STAMP(0, __builtin_amdgcn_s_memrealtime());
+  P16_STAMP(5, (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32));
   if ((F & F_DROP) && p.drop_thr) p.drop_key += neko_drop_salt();
   using C = CP16;
   __shared__ __attribute__((aligned(1024))) char smem[P16_LDS];
@@ -153,25 +170,33 @@ __global__ __launch_bounds__(512, 2) void gemm_p16_kernel(GemmArgs p) {
   const unsigned galo = __builtin_amdgcn_readfirstlane((unsigned)gAu), gahi = __builtin_amdgcn_readfirstlane((unsigned)(gAu >> 32));
   const unsigned gblo = __builtin_amdgcn_readfirstlane((unsigned)gBu), gbhi = __builtin_amdgcn_readfirstlane((unsigned)(gBu >> 32));
   const unsigned half = (unsigned)wm;      // waves 0-3: first half (X), 4-7: second half (Y); w and w + 4 share a SIMD
+  // (every scalar operand of the loop through v_readfirstlane: an "s" constraint on a value hipcc's uniformity analysis gave up on is
+  // silently assigned a VGPR and the assembler then rejects the instruction)
+#define P16_U(x) ((unsigned)__builtin_amdgcn_readfirstlane((int)(x)))
 
-#if NEKO_P16_TRACE
+#if NEKO_P16_TRACE == 1
   unsigned long long tr0 = 0, tr1 = 0;
   if (tid == 0) tr0 = __builtin_amdgcn_s_memtime();
 #endif
+  P16_STAMP(1, __builtin_amdgcn_s_memrealtime());
+  P16_STAMP(6, __builtin_amdgcn_s_memtime());
   f32x32 acc[4];
 #define NEKO_P16_OPERANDS                                                                                                     \
   "={a[0:31]}"(acc[0]), "={a[32:63]}"(acc[1]), "={a[64:95]}"(acc[2]), "={a[96:127]}"(acc[3])                                     \
   : [voa0] "v"(voa[0]), [voa1] "v"(voa[1]), [voa2] "v"(voa[2]), [voa3] "v"(voa[3]), [vob0] "v"(vob[0]), [vob1] "v"(vob[1]),     \
     [vob2] "v"(vob[2]), [vob3] "v"(vob[3]), [ra0] "v"(ra[0]), [ra1] "v"(ra[1]), [ra2] "v"(ra[2]), [ra3] "v"(ra[3]), [rb0] "v"(rb[0]),  \
     [rb1] "v"(rb[1]), [ha] "v"(ha), [hb] "v"(hb),                                                                               \
-    [galo] "s"(galo), [gahi] "s"(gahi), [gblo] "s"(gblo), [gbhi] "s"(gbhi), [sa] "s"(stepa), [sb] "s"(stepb), [nkt] "s"(nkt),     \
-    [ntrips] "s"(ntrips), [ldswa] "s"(ldswa), [ldswb] "s"(ldswb), [half] "s"(half)                                              \
+    [galo] "s"(galo), [gahi] "s"(gahi), [gblo] "s"(gblo), [gbhi] "s"(gbhi), [sa] "s"(P16_U(stepa)), [sb] "s"(P16_U(stepb)),       \
+    [nkt] "s"(P16_U(nkt)), [ntrips] "s"(P16_U(ntrips)), [ldswa] "s"(P16_U(ldswa)), [ldswb] "s"(P16_U(ldswb)), [half] "s"(P16_U(half)) \
   : NEKO_P16_CLOBBERS
   if constexpr (A_KC && B_KC) asm volatile(NEKO_P16_LOOP_KC_KC : NEKO_P16_OPERANDS);
   else if constexpr (A_KC && !B_KC) asm volatile(NEKO_P16_LOOP_KC_KS : NEKO_P16_OPERANDS);
   else asm volatile(NEKO_P16_LOOP_KS_KS : NEKO_P16_OPERANDS);
 #undef NEKO_P16_OPERANDS
-#if NEKO_P16_TRACE
+#undef P16_U
+  P16_STAMP(2, __builtin_amdgcn_s_memrealtime());
+  P16_STAMP(7, __builtin_amdgcn_s_memtime());
+#if NEKO_P16_TRACE == 1
   if (tid == 0 && p.colsum_ws) {
     tr1 = __builtin_amdgcn_s_memtime();
     reinterpret_cast<unsigned long long*>(p.colsum_ws + (long)(p.M / 128) * p.N)[blockIdx.x] = tr1 - tr0;      // behind the bands this kernel fills
@@ -186,6 +211,11 @@ __global__ __launch_bounds__(512, 2) void gemm_p16_kernel(GemmArgs p) {
   float* Cf_out = to_ws ? p.splitk_ws + (long)slice * p.M * p.N : p.Cf;
   const long ldcf_out = to_ws ? p.N : p.ldcf;
   epilogue_fast<C, F>(p, ParkAgprP16{acc}, smem, m0, n0, wm, wn, wave, lane, Cf_out, ldcf_out);
+#if NEKO_P16_TRACE == 2
+  P16_STAMP(3, __builtin_amdgcn_s_memrealtime());
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  P16_STAMP(4, __builtin_amdgcn_s_memrealtime());
+#endif
 }
 
 // -1: per-shape choice (default), 0: never, 1: wherever it applies
@@ -272,7 +302,7 @@ int neko_gemm_p16_try(const GemmArgs& a_in, int a_kstrided, int b_kstrided, int 
   // column sums ride along only with the GELU' dgrad feature sets (every tile is interior here)
   const bool fold = a.colsum_ws && (a.act == 2 || a.act == 4) && a.Cb && !a.Cf && !a.bias && !a.resid && !a.drop_thr && a.alpha == 1.0f &&
                     !a.alpha_dev && a.splitk <= 1;
-#if !NEKO_P16_TRACE
+#if NEKO_P16_TRACE != 1
   if (!fold) a.colsum_ws = nullptr;
 #endif
   GemmArgs am = a;

@@ -116,6 +116,7 @@ def test_gemm_a16_main_loop_layouts(a16, layout, M, N, K):
     B_dev = bf(Bm) if b_ks else bf(Bm.t())
     out = torch.full((M, N), float("nan"), device=DEV)
     a16.gemm(A_dev, B_dev, M, N, K, a_kstrided=a_ks, b_kstrided=b_ks, out_f32=out)
+    assert a16.gemm_last_mainloop() == 1, a16.MAINLOOP_NAMES[a16.gemm_last_mainloop()]      # served by gemm_a16, not by a fall-through
     close(out, ref, 2e-4, 2e-4 * math.sqrt(K), f"a16 {layout} {M}x{N}x{K}")
     out16 = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
     a16.gemm(A_dev, B_dev, M, N, K, a_kstrided=a_ks, b_kstrided=b_ks, out_bf16=out16)
@@ -125,6 +126,7 @@ def test_gemm_a16_main_loop_layouts(a16, layout, M, N, K):
     try:
         other = torch.full((M, N), float("nan"), device=DEV)
         a16.gemm(A_dev, B_dev, M, N, K, a_kstrided=a_ks, b_kstrided=b_ks, out_f32=other)
+        assert a16.gemm_last_mainloop() in (0, 3)
     finally:
         a16.gemm_set_mainloop(prev)
     close(out, other, 1e-5, 4e-5 * math.sqrt(K), f"a16 vs default loop {layout}")
@@ -181,6 +183,7 @@ def test_gemm_a16_epilogues(a16, epi):
             outs.append(out)
         close(outs[0], ref, 2e-4, 2e-4 * math.sqrt(K), epi)
         assert torch.equal(outs[0], outs[1])
+    assert a16.gemm_last_mainloop() == 1, f"{epi}: served by {a16.MAINLOOP_NAMES[a16.gemm_last_mainloop()]}"
 
 
 @pytest.mark.parametrize("layout", ["nt", "nn"])
@@ -215,6 +218,7 @@ def test_gemm_glds_whole_line_slots_for_a_k_contiguous_operand(ops, layout, M, N
             bias = torch.randn(N, generator=g)
             ops.gemm(A_dev, B_dev, M, N, K, b_kstrided=b_ks, bias=bias.to(DEV), out_f32=out)
             close(out, ref + bias, 2e-4, 2e-4 * math.sqrt(K), f"kc64 f32 + bias {layout} {M}x{N}x{K}")
+        assert ops.gemm_last_mainloop() == 3, f"served by {ops.MAINLOOP_NAMES[ops.gemm_last_mainloop()]}, not by gemm_glds64_kernel"
     finally:
         ops.gemm_set_mainloop(prev)
 
@@ -242,6 +246,7 @@ def test_gemm_b16_main_loop_layouts(b16, layout, M, N, K):
     B_dev = bf(Bm) if b_ks else bf(Bm.t())
     out16 = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
     b16.gemm(A_dev, B_dev, M, N, K, b_kstrided=b_ks, out_bf16=out16)
+    assert b16.gemm_last_mainloop() == 2, b16.MAINLOOP_NAMES[b16.gemm_last_mainloop()]
     close(out16, ref, 2 ** -7, 2e-4 * math.sqrt(K), f"b16 bf16 {layout} {M}x{N}x{K}")
     prev = b16.gemm_set_mainloop(0)
     try:
@@ -255,6 +260,7 @@ def test_gemm_b16_main_loop_layouts(b16, layout, M, N, K):
     if not b_ks:                                      # the fp32-out kernel exists for the dgrad layout
         out = torch.full((M, N), float("nan"), device=DEV)
         b16.gemm(A_dev, B_dev, M, N, K, b_kstrided=False, out_f32=out)
+        assert b16.gemm_last_mainloop() == 2
         close(out, ref, 2e-4, 2e-4 * math.sqrt(K), f"b16 f32 {layout} {M}x{N}x{K}")
 
 
@@ -274,7 +280,9 @@ def test_gemm_b16_epilogues(b16, epi):
     bias = torch.randn(N, generator=g); resid = torch.randn(M, N, generator=g)
 
     def twice(fn):
-        a, b = fn(), fn()
+        a = fn()
+        assert b16.gemm_last_mainloop() == 2, f"{epi}: served by {b16.MAINLOOP_NAMES[b16.gemm_last_mainloop()]}"
+        b = fn()
         for x, y in zip(a, b):
             assert torch.equal(x, y), f"{epi}: not run-to-run identical"
         return a

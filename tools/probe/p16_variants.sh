@@ -10,6 +10,18 @@ declare -A D          # extra -D flags of a variant
 D[noepi]="-DNEKO_GEMM_DIAG=4"
 D[nostores]="-DNEKO_EPI_ABL=1"
 D[noslab]="-DNEKO_EPI_ABL=3"
+D[nt]="-DNEKO_EPI_STORE_POLICY=1"
+V[nt]=""
+D[trace2]="-DNEKO_P16_TRACE=2"
+V[trace2]=""
+D[trace2_nt]="-DNEKO_P16_TRACE=2 -DNEKO_EPI_STORE_POLICY=1"
+V[trace2_nt]=""
+D[st_nt]="-DNEKO_EPI_STORE_POLICY=1"
+D[st_sc1]="-DNEKO_EPI_STORE_POLICY=2"
+D[st_sc01]="-DNEKO_EPI_STORE_POLICY=3"
+V[st_nt]=""
+V[st_sc1]=""
+V[st_sc01]=""
 V[noepi]=""
 V[nostores]=""
 V[noslab]=""
