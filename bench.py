@@ -135,9 +135,10 @@ def time_dominant_kernel(model, rows: int, iters: int = 10):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
     flops = 2.0 * rows * D * hp.V          # useful columns only (the call computes Vpad = V + 175 of them)
-    # which main loop neko_gemm_bf16 takes for this call (gemm_a16.hip's per-shape rule): every tile interior, >= 512 tiles
-    a16 = rows % 256 == 0 and hp.Vpad % 256 == 0 and (rows // 256) * (hp.Vpad // 256) >= 512 and os.environ.get("NEKO_GEMM_A16", "-1") != "0"
-    return {"kernel": ("gemm_a16_kernel" if a16 else "gemm_glds_kernel") + "<A k-contig, B k-contig> (LM head logits)",
+    # which main loop neko_gemm_bf16 took for this call: asked from the library (neko_gemm_last_mainloop, ABI v19), not re-derived here
+    loop = {0: "gemm_glds_kernel", 1: "gemm_a16_kernel", 2: "gemm_b16_kernel", 3: "gemm_glds64_kernel", 4: "gemm_bf16_kernel",
+            5: "gemm_p16_kernel"}.get(ops.gemm_last_mainloop(), "?")
+    return {"kernel": loop + "<A k-contig, B k-contig> (LM head logits)",
             "shape": [rows, hp.V, D], "ms": ms, "tflops": flops / ms / 1e9}
 
 

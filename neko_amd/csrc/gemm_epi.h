@@ -114,17 +114,21 @@ __device__ __forceinline__ void epi_store8(void* dst, uint2 v) {
 #endif
 #endif
 }
+// (the s_nop: a VMEM store of more than 64 bits reads its data registers for a few cycles after it has issued, and the instruction
+// behind it may not overwrite them (the ISA's "store of more than 8 bytes followed by a write of its data VGPRs" wait states).  hipcc's
+// hazard recogniser pads its own stores but does not look inside inline asm: without the wait states the first dword of a float4 was
+// replaced by the next step's value in the hand-placed kernels' fp32 outputs -- tools/probe/gemm_determinism.py, tools/probe/resid_bug.py)
 __device__ __forceinline__ void epi_store16(void* dst, float4 v) {
 #if NEKO_EPI_STORE_POLICY_CF == 0
   *reinterpret_cast<float4*>(dst) = v;
 #else
   const epi_f32x4 w = {v.x, v.y, v.z, v.w};
 #if NEKO_EPI_STORE_POLICY_CF == 1
-  asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(dst), "v"(w) : "memory");
+  asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(dst), "v"(w) : "memory");
 #elif NEKO_EPI_STORE_POLICY_CF == 2
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(w) : "memory");
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(w) : "memory");
 #else
-  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(w) : "memory");
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(dst), "v"(w) : "memory");
 #endif
 #endif
 }

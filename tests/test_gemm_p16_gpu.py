@@ -240,3 +240,36 @@ def test_gemm_p16_declines_what_it_cannot_serve(p16):
         p16.gemm(bf(A.t()) if a_ks else bf(A), bf(Bm) if b_ks else bf(Bm.t()), M, N, K, a_kstrided=a_ks, b_kstrided=b_ks, out_f32=out)
         assert p16.gemm_last_mainloop() != P16
         close(out, A @ Bm, 2e-4, 2e-4 * math.sqrt(K), f"declined {layout} {M}x{N}x{K}")
+
+
+@pytest.mark.parametrize("mode", [3, 2, 1, 0])
+def test_gemm_fp32_and_bf16_outputs_every_loop_at_step_size(mode):
+    """Round 6 regression: the fast epilogue's fp32 outputs are 16-byte stores issued from inline asm (streaming policy); a store of more
+    than 64 bits reads its data registers for a few cycles after it issued, and without the wait states behind it the NEXT step's value
+    replaced the first dword -- only in launches with several row passes per wave and many tiles, which the small cases above never
+    showed.  16384 x 768 outputs (192-384 tiles), every main loop, fp32 (+ residual) and bf16 outputs: against the fp32 product of the
+    same operands, and bit-identical over reruns."""
+    from neko_amd import ops
+    M, N, K = 16384, 768, 768
+    g = torch.Generator().manual_seed(17)
+    A = rb(torch.randn(M, K, generator=g)); Bm = rb(torch.randn(K, N, generator=g) * 0.05)
+    bias = torch.randn(N, generator=g); resid = torch.randn(M, N, generator=g)
+    ref = A @ Bm + bias
+    Ad, Bd, biasd, residd = bf(A), bf(Bm), bias.to(DEV), resid.to(DEV)
+    prev = ops.gemm_set_mainloop(mode)
+    try:
+        for what in ("f32", "f32+resid", "bf16"):
+            outs = []
+            for _ in range(3):
+                if what == "bf16":
+                    o = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+                    ops.gemm(Ad, Bd, M, N, K, b_kstrided=True, bias=biasd, out_bf16=o)
+                else:
+                    o = torch.full((M, N), float("nan"), device=DEV)
+                    ops.gemm(Ad, Bd, M, N, K, b_kstrided=True, bias=biasd, out_f32=o, resid=residd if what == "f32+resid" else None)
+                outs.append(o)
+            want = ref + (resid if what == "f32+resid" else 0)
+            close(outs[0], want, 2 ** -7 if what == "bf16" else 2e-4, 2e-4 * math.sqrt(K), f"mode {mode} {what}")
+            assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), f"mode {mode} {what}: not run-to-run identical"
+    finally:
+        ops.gemm_set_mainloop(prev)

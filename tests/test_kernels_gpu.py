@@ -187,12 +187,14 @@ def test_gemm_a16_epilogues(a16, epi):
 
 
 @pytest.mark.parametrize("layout", ["nt", "nn"])
-@pytest.mark.parametrize("M,N,K,splitk", [(4196, 2304, 128, 1), (4196, 2304, 192, 1), (4100, 2176, 768, 1), (4352, 2304, 320, 1), (512, 512, 5120, 40)])
+@pytest.mark.parametrize("M,N,K,splitk", [(11000, 2304, 128, 1), (11000, 2304, 192, 1), (11012, 2176, 768, 1), (11008, 2304, 320, 1), (512, 512, 5120, 40)])
 def test_gemm_glds_whole_line_slots_for_a_k_contiguous_operand(ops, layout, M, N, K, splitk):
     """gemm_glds64_kernel (round 5): the 8-wave 256 x 256 loop with its k-contiguous A operand in three 64-k slots of whole 128-B lines
     (XOR-swizzled 16-B chunks, pieces requested two slots ahead on even k-tiles).  Shapes that take it with the hand-placed loops off:
     the shortest contraction (two slots, no steady-state trip), one and several trips, edge tiles in M and N (clamped DMA rows / columns),
-    B k-contiguous and k-strided, split-K slices of two slots each -- against the fp32 product of the same bf16 operands."""
+    B k-contiguous and k-strided, split-K slices of two slots each -- against the fp32 product of the same bf16 operands.  (Round 6: the
+    row counts are 43 tiles of 256: with fewer than 384 tiles of 256 x 256 the launcher picks the 256 x 128 configuration for these wide
+    outputs and the round-5 shapes never reached this kernel -- `neko_gemm_last_mainloop()` now says which loop served the call.)"""
     g = torch.Generator().manual_seed(M + 3 * N + 7 * K)
     A = rb(torch.randn(M, K, generator=g)); Bm = rb(torch.randn(K, N, generator=g) * 0.25)
     A = rb(A * (1.0 + 0.01 * torch.arange(M).float().unsqueeze(1) % 0.37))      # rows individually recognisable

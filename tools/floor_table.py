@@ -23,24 +23,28 @@ M, D, L, T, B, H = 65536, 768, 6, 1024, 64, 24
 ROWS_LM, VPAD, V = 22784, 52480, 52305
 PATCHES = 21 * 256 + 22 * 26 * 36
 PEAK, HBM = 2.5e15, 6.3e12
-DMA_RATE = 28.0                       # bytes per clock and CU the L2 -> LDS DMA path sustains under the k-loops (see the docstring)
+DMA_RATE = 55.0                       # bytes per clock and CU the L2 -> LDS path delivers for whole-line requests (round 6: tools/probe/dma_rate_probe.hip;
+                                      # round 5 priced 28 here, which was the one-wave-per-SIMD loops' issue rate, not the path's)
 VALU_LANES_PER_CLK = 1024 * 16        # SIMDs x lanes issued per clock
 ATTN_VALU_WAVE_INSTS = (1.322e8 + 1.677e8) * 6          # per step: forward + backward launch, 6 layers
 PATCH_VALU_WAVE_INSTS = (2601 + 4310) * 4 * float(PATCHES)
 
 # GEMM launch classes of the step: (label, kernel substring, blocks, launches per step, FLOPs per launch, tile_M, tile_N, M, N, K-sum)
 # "K-sum": contraction length summed over the launches of the class that share the row (the N = 768 dgrads have K = 768 / 2304 / 3072)
+# Round 6: every class with a k-contiguous A operand runs on gemm_p16_kernel<A_KC, B_KC, F> (F = epilogue feature mask, gemm_epi.h);
+# the round-5 kernel of each class is listed behind it so that older tables still parse.
 GEMMS = [
-    ("c_attn fwd (bias, bf16)", "gemm_a16_kernelILb1ELb0", 2304, 6, 256, 256, M, 3 * D, D),
-    ("c_fc fwd + GELU + gelu' (2 x bf16 out)", "gemm_glds64_kernelILb0", 3072, 6, 256, 256, M, 4 * D, D),
-    ("attn + MLP c_proj fwd (bias, dropout, fp32 residual in / out)", "gemm_b16_kernel", 1536, 12, 128, 256, M, D, (D + 4 * D) / 2.0),
-    ("dgrad MLP c_proj x gelu' (+ c_fc bias gradient)", "gemm_glds64_kernelILb1", 3072, 6, 256, 256, M, 4 * D, D),
-    ("N = 768 dgrads (c_fc, attn c_proj, c_attn: K = 3072 / 768 / 2304)", "gemm_a16_kernelILb1ELb1", 768, 18, 256, 256, M, D, (4 * D + D + 3 * D) / 3.0),
-    ("wgrads c_fc / MLP c_proj (split-K)", "gemm_a16_kernelILb0ELb0", 252, 12, 256, 256, 4 * D, D, M),
-    ("wgrads c_attn / attn c_proj (split-K)", "gemm_a16_kernelILb0ELb0", 243, 12, 256, 256, 2 * D, D, M),
-    ("LM-head logits", "gemm_a16_kernelILb1ELb1", 18245, 1, 256, 256, ROWS_LM, VPAD, D),
-    ("LM-head dH (split-K)", "gemm_a16_kernelILb1ELb0", 1869, 1, 256, 256, ROWS_LM, D, VPAD),
-    ("LM-head dW (split-K)", "gemm_a16_kernelILb0ELb0", 1230, 1, 256, 256, VPAD, D, ROWS_LM),
+    ("c_attn fwd (bias, bf16)", ("gemm_p16_kernelILb1ELb0ELj257E", "gemm_a16_kernelILb1ELb0"), 2304, 6, 256, 256, M, 3 * D, D),
+    ("c_fc fwd + GELU + gelu' (2 x bf16 out)", ("gemm_p16_kernelILb1ELb0ELj2311E", "gemm_glds64_kernelILb0"), 3072, 6, 256, 256, M, 4 * D, D),
+    ("attn + MLP c_proj fwd (bias, dropout, fp32 residual in / out)", ("gemm_p16_kernelILb1ELb0ELj113E",), 768, 12, 256, 256, M, D, (D + 4 * D) / 2.0),
+    ("attn + MLP c_proj fwd (bias, dropout, fp32 residual in / out)", ("gemm_b16_kernel",), 1536, 12, 128, 256, M, D, (D + 4 * D) / 2.0),
+    ("dgrad MLP c_proj x gelu' (+ c_fc bias gradient)", ("gemm_p16_kernelILb1ELb1ELj5384E", "gemm_glds64_kernelILb1"), 3072, 6, 256, 256, M, 4 * D, D),
+    ("N = 768 dgrads (c_fc, attn c_proj, c_attn: K = 3072 / 768 / 2304)", ("gemm_p16_kernelILb1ELb1ELj256E", "gemm_a16_kernelILb1ELb1"), 768, 18, 256, 256, M, D, (4 * D + D + 3 * D) / 3.0),
+    ("wgrads c_fc / MLP c_proj (split-K)", ("gemm_a16_kernelILb0ELb0",), 252, 12, 256, 256, 4 * D, D, M),
+    ("wgrads c_attn / attn c_proj (split-K)", ("gemm_a16_kernelILb0ELb0",), 243, 12, 256, 256, 2 * D, D, M),
+    ("LM-head logits", ("gemm_p16_kernelILb1ELb1ELj256E", "gemm_a16_kernelILb1ELb1"), 18245, 1, 256, 256, ROWS_LM, VPAD, D),
+    ("LM-head dH (split-K)", ("gemm_a16_kernelILb1ELb0",), 1869, 1, 256, 256, ROWS_LM, D, VPAD),
+    ("LM-head dW (split-K)", ("gemm_a16_kernelILb0ELb0",), 1230, 1, 256, 256, VPAD, D, ROWS_LM),
 ]
 
 
@@ -91,14 +95,17 @@ def clock_of(clocks, key, blocks, default):
     """key: substring of the DEMANGLED kernel text of the counters file"""
     for name, b, ghz, _ in clocks:
         if key in name and b == blocks and ghz > 0:
-            return ghz
+            return min(ghz, 2.4)       # (sub-60-us kernels read above the 2.4 GHz maximum: GRBM_GUI_ACTIVE counts the dispatch around them)
     return default
 
 
 DEMANGLED = {"gemm_a16_kernelILb1ELb0": "gemm_a16_kernel<true, false>", "gemm_a16_kernelILb1ELb1": "gemm_a16_kernel<true, true>",
              "gemm_a16_kernelILb0ELb0": "gemm_a16_kernel<false, false>", "gemm_glds_kernelILb1ELb0": "gemm_glds_kernel<true, false",
              "gemm_glds_kernelILb1ELb1": "gemm_glds_kernel<true, true", "gemm_b16_kernel": "gemm_b16_kernel",
-             "gemm_glds64_kernelILb0": "gemm_glds64_kernel<false>", "gemm_glds64_kernelILb1": "gemm_glds64_kernel<true>"}
+             "gemm_glds64_kernelILb0": "gemm_glds64_kernel<false>", "gemm_glds64_kernelILb1": "gemm_glds64_kernel<true>",
+             "gemm_p16_kernelILb1ELb0ELj257E": "gemm_p16_kernel<true, false, 257", "gemm_p16_kernelILb1ELb0ELj2311E": "gemm_p16_kernel<true, false, 2311",
+             "gemm_p16_kernelILb1ELb0ELj113E": "gemm_p16_kernel<true, false, 113", "gemm_p16_kernelILb1ELb1ELj5384E": "gemm_p16_kernel<true, true, 5384",
+             "gemm_p16_kernelILb1ELb1ELj256E": "gemm_p16_kernel<true, true, 256"}
 
 
 def main():
@@ -127,13 +134,20 @@ def main():
 
     # ---- per GEMM launch class -------------------------------------------------------------------------------------------------
     print(f"### GEMM launch classes inside the step (`{path}`; clocks: `{sys.argv[2] if len(sys.argv) > 2 else '-'}`)\n")
-    print("| launch class | launches / step | us / launch | TFLOP/s | of 2.5 PF | GHz in the step | of the matrix peak at that clock | DMA GB / launch | DMA floor us (28 B/clk/CU) | measured / max(matrix at clock, DMA) |")
+    print("| launch class | launches / step | us / launch | TFLOP/s | of 2.5 PF | GHz in the step | of the matrix peak at that clock | DMA GB / launch | DMA floor us (55 B/clk/CU) | measured / max(matrix at clock, DMA) |")
     print("|---|---|---|---|---|---|---|---|---|---|")
-    for label, key, blocks, per_step, tm, tn, m, n, k in GEMMS:
-        hit = [(avg, calls) for (_, calls, avg, b, name) in rows if key in name and b[0] == blocks]
-        if not hit:
+    seen = set()
+    for label, keys, blocks, per_step, tm, tn, m, n, k in GEMMS:
+        hit, key = [], None
+        for key in keys:
+            hit = [(avg, calls) for (_, calls, avg, b, name) in rows if key in name and b[0] == blocks]
+            if hit:
+                break
+        if not hit or label in seen:
             continue
-        us = hit[0][0]
+        seen.add(label)
+        label = f"{label} [{key.split('_kernel')[0]}]"
+        us = sum(a * c for a, c in hit) / sum(c for _, c in hit)
         fl = 2.0 * m * n * k
         ghz = clock_of(clocks, DEMANGLED[key], blocks, 2.0)
         dma = (m / tm) * (n / tn) * (k / 32.0) * (tm + tn) * 64.0
@@ -152,8 +166,12 @@ def main():
         + M * D * 2 + M * 4 * D * 2 * 2 + M * 4 * D * 2 + M * D * 2 + M * D * 2 + M * D * 2 + M * 3 * D * 2 + M * D * 2
         # wgrads: read both operands
         + (M * 4 * D * 2 + M * D * 2) * 2 + M * D * 2 * 2 + (M * 3 * D * 2 + M * D * 2))
-    gemm_dma = sum(per * (m / tm) * (n / tn) * (k / 32.0) * (tm + tn) * 64.0 for (_, _, blocks, per, tm, tn, m, n, k) in GEMMS if blocks not in (18245, 1869, 1230))
-    lm_dma = sum(per * (m / tm) * (n / tn) * (k / 32.0) * (tm + tn) * 64.0 for (_, _, blocks, per, tm, tn, m, n, k) in GEMMS if blocks in (18245, 1869, 1230))
+    live = [g for g in GEMMS if any(any(key in name and b[0] == g[2] for key in g[1]) for (_, _, _, b, name) in rows)]
+    uniq = {}
+    for g in live:
+        uniq.setdefault(g[0], g)
+    gemm_dma = sum(per * (m / tm) * (n / tn) * (k / 32.0) * (tm + tn) * 64.0 for (_, _, blocks, per, tm, tn, m, n, k) in uniq.values() if blocks not in (18245, 1869, 1230))
+    lm_dma = sum(per * (m / tm) * (n / tn) * (k / 32.0) * (tm + tn) * 64.0 for (_, _, blocks, per, tm, tn, m, n, k) in uniq.values() if blocks in (18245, 1869, 1230))
     lm_flops = 3 * 2.0 * ROWS_LM * D * VPAD
     lm_bytes = ROWS_LM * VPAD * 2 * 3.0 + VPAD * D * 2 * 3
     attn_flops = L * (2.0 * B * T * T * D) * 3.5                       # useful causal: fwd 4 T^2/2 hd per head, bwd 2.5x

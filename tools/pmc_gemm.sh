@@ -20,10 +20,10 @@ for f in sorted(glob.glob('gpurun_out/pmcG_*/**/g_counter_collection.csv', recur
     tag = re.search(r'pmcG_(.+?)_[AB]/', f).group(1)
     agg = collections.defaultdict(float); n = collections.Counter()
     for r in csv.DictReader(open(f)):
-        if 'gemm_glds' not in r['Kernel_Name'] and 'gemm_a16' not in r['Kernel_Name']: continue
+        if not any(k in r['Kernel_Name'] for k in ('gemm_glds', 'gemm_a16', 'gemm_p16', 'gemm_b16')): continue
         agg[r['Counter_Name']] += float(r['Counter_Value']); n[r['Counter_Name']] += 1
     for c, x in agg.items(): per_tag[tag][c] = x / n[c]
-print('# tools/pmc_gemm.sh: SQ counters of the GEMM kernel of each shape (gemm_a16_kernel where it applies, else gemm_glds_kernel), per dispatch (two --pmc passes per shape)')
+print('# tools/pmc_gemm.sh: SQ counters of the GEMM kernel of each shape (whichever main loop served it: gemm_p16 / gemm_a16 / gemm_glds), per dispatch (two --pmc passes per shape)')
 print('# MFMA pipe busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles), kernel cycles = GRBM_GUI_ACTIVE / 8 XCDs')
 print('# wave-cycle split = SQ_WAIT_ANY (parked) | SQ_WAIT_INST_ANY (issue-stalled) | SQ_ACTIVE_INST_ANY, of SQ_WAVE_CYCLES')
 for tag, c in per_tag.items():

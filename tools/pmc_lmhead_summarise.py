@@ -18,7 +18,7 @@ for d, cn in [("pmcL1", "FETCH_SIZE"), ("pmcL2", "WRITE_SIZE")]:
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != cn:
             continue
-        k = "gemm" if ("gemm_glds" in r["Kernel_Name"] or "gemm_a16" in r["Kernel_Name"]) else ("cast" if "cast_f32_bf16" in r["Kernel_Name"] else None)
+        k = "gemm" if any(x in r["Kernel_Name"] for x in ("gemm_glds", "gemm_a16", "gemm_p16", "gemm_b16")) else ("cast" if "cast_f32_bf16" in r["Kernel_Name"] else None)
         if k:
             agg[k].append(float(r["Counter_Value"]))
     res[cn] = {k: sum(v) / len(v) for k, v in agg.items()}
@@ -30,7 +30,7 @@ write = res["WRITE_SIZE"]["gemm"] * 1024 * wcorr
 M = int(sys.argv[2]) if len(sys.argv) > 2 else 22784      # rows of the probed launch (tools/lmhead_probe.py)
 V, VP, K = 52305, 52480, 768
 out = {
-    "kernel": "gemm_a16_kernel<A k-contig, B k-contig> (LM head logits, bf16 out, N = Vpad; gemm_glds_kernel when a tile is not interior)",
+    "kernel": "gemm_p16_kernel<A k-contig, B k-contig, bf16 out> (LM head logits, N = Vpad; round 6: the two-waves-per-SIMD loop)",
     "shape_MNK": [M, V, K], "computed_columns": VP,
     "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (pass 1) / --pmc WRITE_SIZE (pass 2) -- python3 "
                "tools/lmhead_probe.py 5   (tools/pmc_lmhead.sh, summarised by tools/pmc_lmhead_summarise.py)",
