@@ -78,6 +78,14 @@ template <bool A_KC, bool B_KC, unsigned F>
 __global__ __launch_bounds__(512, 2) void gemm_p16_kernel(GemmArgs p) {
   P16_STAMP(0, __builtin_amdgcn_s_memrealtime());
   P16_STAMP(5, (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32));
+#ifdef NEKO_P16_STAGGER_10NS
+  // experiment (tools/probe/p16_variants.sh stagger*): every other CU slot of the first round starts late, so that the CUs of an XCD are not
+  // all in their epilogue (HBM burst) at the same time
+  if (blockIdx.x < 256 && ((blockIdx.x >> 3) & 1)) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)(NEKO_P16_STAGGER_10NS)) __builtin_amdgcn_s_sleep(32);
+  }
+#endif
   if ((F & F_DROP) && p.drop_thr) p.drop_key += neko_drop_salt();
   using C = CP16;
   __shared__ __attribute__((aligned(1024))) char smem[P16_LDS];

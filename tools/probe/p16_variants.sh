@@ -10,6 +10,12 @@ declare -A D          # extra -D flags of a variant
 D[noepi]="-DNEKO_GEMM_DIAG=4"
 D[nostores]="-DNEKO_EPI_ABL=1"
 D[noslab]="-DNEKO_EPI_ABL=3"
+D[stagger8]="-DNEKO_P16_STAGGER_10NS=800"
+V[stagger8]=""
+D[stagger12]="-DNEKO_P16_STAGGER_10NS=1200"
+V[stagger12]=""
+D[stagger16]="-DNEKO_P16_STAGGER_10NS=1600"
+V[stagger16]=""
 D[nt]="-DNEKO_EPI_STORE_POLICY=1"
 V[nt]=""
 D[trace2]="-DNEKO_P16_TRACE=2"

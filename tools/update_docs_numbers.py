@@ -23,11 +23,11 @@ shape = mm['roofline'].get('shape_MNK', [4096, 52305, 768])
 design = f"""<!-- bench:begin -->
 | workload (1 x MI355X, dropout 0.1, fwd + bwd + clip + AdamW, synthetic data; `profiles/{tag}_*`) | ms / step | tokens/s | step MFMA fraction |
 |---|---|---|---|
-| **m-mix, 64 x 1024 tokens per step (the bench default; r04 evidence box: 37.29 ms, 1.757 M, 0.258)** | {mm['ms_per_step']:.2f} | **{mm['value']/1e6:.3f} M** | {mm['step_mfma_frac']:.3f} |
-| m-mix, 32 x 1024 (r01: 23.81 ms, 1.376 M, 0.202; r04: 20.86 ms, 0.231) | {m32['ms_per_step']:.2f} | {m32['value']/1e6:.3f} M | {m32['step_mfma_frac']:.3f} |
-| m-text, 64 x 1024 (LM head on every position; r04: 43.73 ms, 0.314) | {mt['ms_per_step']:.2f} | {mt['value']/1e6:.3f} M | {mt['step_mfma_frac']:.3f} |
-| c2 / c3 / c4 (README shapes, 32 sequences; r04: 5.87 / 5.94 / 11.33 ms) | {c2['ms_per_step']:.2f} / {c3['ms_per_step']:.2f} / {c4['ms_per_step']:.2f} | {c2['value']/1e6:.2f} / {c3['value']/1e6:.2f} / {c4['value']/1e6:.2f} M | {c2['step_mfma_frac']:.3f} / {c3['step_mfma_frac']:.3f} / {c4['step_mfma_frac']:.3f} |
-| configs[4] Gato-1.2B (2048d x 24L x 16H, hd = 128), m-text, 8 x 1024 (r03: 78.64 ms, 0.341; r04: 76.33 ms, 0.352) | {g12['ms_per_step']:.2f} | {g12['value']/1e6:.3f} M | {g12['step_mfma_frac']:.3f} |
+| **m-mix, 64 x 1024 tokens per step (the bench default; r05 evidence box: 36.29 ms, 1.806 M, 0.265)** | {mm['ms_per_step']:.2f} | **{mm['value']/1e6:.3f} M** | {mm['step_mfma_frac']:.3f} |
+| m-mix, 32 x 1024 (r01: 23.81 ms, 0.202; r05: 20.02 ms, 0.241) | {m32['ms_per_step']:.2f} | {m32['value']/1e6:.3f} M | {m32['step_mfma_frac']:.3f} |
+| m-text, 64 x 1024 (LM head on every position; r05: 42.61 ms, 0.322) | {mt['ms_per_step']:.2f} | {mt['value']/1e6:.3f} M | {mt['step_mfma_frac']:.3f} |
+| c2 / c3 / c4 (README shapes, 32 sequences; r05: 5.59 / 5.49 / 10.86 ms) | {c2['ms_per_step']:.2f} / {c3['ms_per_step']:.2f} / {c4['ms_per_step']:.2f} | {c2['value']/1e6:.2f} / {c3['value']/1e6:.2f} / {c4['value']/1e6:.2f} M | {c2['step_mfma_frac']:.3f} / {c3['step_mfma_frac']:.3f} / {c4['step_mfma_frac']:.3f} |
+| configs[4] Gato-1.2B (2048d x 24L x 16H, hd = 128), m-text, 8 x 1024 (r05: 75.61 ms, 0.355) | {g12['ms_per_step']:.2f} | {g12['value']/1e6:.3f} M | {g12['step_mfma_frac']:.3f} |
 | configs[4] Gato-1.2B on the FULL mix (m-mix: text + image-patch + control examples), 32 x 1024 / 64 x 1024 | {g32['ms_per_step']:.1f} / {g64['ms_per_step']:.1f} | {g32['value']/1e6:.3f} / {g64['value']/1e6:.3f} M | {g32['step_mfma_frac']:.3f} / {g64['step_mfma_frac']:.3f} |
 | c5-mix (1024 / 494 / 289 / 240-token examples, 8 each): padded layout / 4 length groups, varlen attention | {c5p['ms_per_step']:.2f} / {c5r['ms_per_step']:.2f} | {c5p['real_tokens_per_sec']/1e6:.2f} / {c5r['real_tokens_per_sec']/1e6:.2f} M real tokens/s | {c5p['step_mfma_frac']:.3f} / {c5r['step_mfma_frac']:.3f} |
 
