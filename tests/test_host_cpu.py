@@ -512,6 +512,16 @@ def test_varlen_geometry_cache_never_evicts_what_a_captured_graph_points_at(monk
     g0.pinned_by_capture = True                      # what get() sets while torch.cuda.is_current_stream_capturing()
     for n in range(3, 12):
         ops.VarlenGeom.get([n, n + 1], 2, "cpu")
-    assert len(ops.VarlenGeom._cache) <= 4
+    # round 6: only geometries no captured graph points at count against the limit and are evicted -- the pinned one rides on top
+    free = [g for g in ops.VarlenGeom._cache.values() if not g.pinned_by_capture]
+    assert len(free) <= 4 and len(ops.VarlenGeom._cache) == len(free) + 1
     assert ops.VarlenGeom.get([5, 7], 2, "cpu") is g0
     assert g0.seq_off.tolist() == [0, 5, 12] and g0.rows == 12
+    # every entry pinned: nothing is evicted (the old code stopped evicting silently AND stopped counting); the unpinned ones still are
+    for g in list(ops.VarlenGeom._cache.values()):
+        g.pinned_by_capture = True
+    npinned = len(ops.VarlenGeom._cache)
+    for n in range(20, 30):
+        ops.VarlenGeom.get([n, n + 1], 2, "cpu")
+    free = [g for g in ops.VarlenGeom._cache.values() if not g.pinned_by_capture]
+    assert len(free) <= 4 and len(ops.VarlenGeom._cache) == npinned + len(free)
