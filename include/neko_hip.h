@@ -155,9 +155,10 @@ int neko_layernorm_bwd_bf16dy(const uint16_t* dy, const float* x, const float* g
  *   bwd workspace: D f32 [B*H*T], qflags int32 [B*ceil(T/64)]; dqkv bf16 [B*T, 3*H*hd] fully written.
  *   hd in {32, 64, 128}.
  *   Two schedules compute the same sums: head-resident kernels (hd = 32, T <= 1024: one workgroup per (b, h) keeps
- *   the head's K/V or Q/dO in LDS) and streaming kernels (any T, hd).  neko_attn_set_path(0) = automatic (default: the
- *   head-resident backward in one pass for 256 < T <= 512, as two kernels otherwise -- round 5), (1) = always streaming, (2) / (3) =
- *   head-resident with the two-kernel (bit-reproducible) / the one-pass backward at every length; returns the previous
+ *   the head's K/V or Q/dO in LDS) and streaming kernels (any T, hd).  neko_attn_set_path(0) = automatic (default; since
+ *   round 6 the head-resident backward is the two-kernel, bit-reproducible form at EVERY length: the one-pass kernel sums dQ in arrival
+ *   order and bought 0.05 ms of a 10.4 ms configs[3] step), (1) = always streaming, (2) / (3) = head-resident with the two-kernel / the
+ *   one-pass backward at every length; returns the previous
  *   mode (any other argument only queries).  Process-wide tuning knob.
  *   neko_attn_bwd_reproducible(1 / 0) (ABI v18): the CALLING THREAD's backward calls use the two-kernel form at every length (0: follow
  *   the knob); returns the previous value, any other argument only queries.  What NEKO_DETERMINISTIC=1 selects -- thread-local, so it

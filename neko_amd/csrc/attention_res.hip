@@ -1303,8 +1303,11 @@ int neko_attn_bwd_res_impl(const bf16_t* qkv, const bf16_t* out, const bf16_t* d
   // the step -- m-mix 64 x 1024: 36.41 -> 36.10 ms over three alternating rounds on one box, profiles/r05_attn_path_ab.txt (round 4
   // measured them level) -- while the single-phase lengths keep the one-pass kernel (c4, T = 494: 11.1 vs 11.15-11.75 ms).  The metric's
   // sequence length therefore runs the bit-reproducible form again.
+  // Round 6: the two kernels are the automatic choice at EVERY length -- the one-pass kernel adds dQ up in the order its waves arrive, so a
+  // configs[3] run (T = 494) was not run-to-run reproducible by default, for 0.05 ms of a 10.4 ms step
+  // (profiles/r06_c4_attn_path_ab.txt: 10.35 vs 10.40 ms over three alternating rounds).  neko_attn_set_path(3) still selects it.
   const int pm = neko_attn_bwd_reproducible_mode() ? 2 : neko_attn_path_mode();       // (a thread's reproducibility request outranks the knob)
-  if (pm == 3 || (pm != 2 && T > 256 && T <= FUSED_Q)) {
+  if (pm == 3) {
     const int Tp = (T + 31) & ~31, Rmax = min(Tp, FUSED_Q);
     const size_t lds = (size_t)Rmax * (128 + 128 + 8) + FUSED_W * 2048 + 16 + 64;
     const float scale = 1.0f / sqrtf(32.0f);

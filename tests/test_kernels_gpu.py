@@ -1284,3 +1284,28 @@ def test_attention_long_sequences_wide_heads(ops, T, hd, mask_kind):
     close(out.view(B, T, d), o_ref, 2 ** -7, 4e-3 * float(o_ref.abs().max()), "attn out")
     dqkv = ops.attn_bwd(qkv_d, out, bf(do.view(B * T, d)), kb, ks, lse, B, T, H, hd)
     close(dqkv.view(B, T, 3 * d), leaf.grad, 2 ** -6, 1e-2 * float(leaf.grad.abs().max()), "attn dqkv")
+
+
+def test_attention_backward_is_bit_reproducible_by_default_at_the_atari_length(ops):
+    """configs[3] (Atari layout, T = 494): since round 6 the automatic head-resident backward is the two-kernel form at every length, so the
+    default schedule -- no knob, no NEKO_DETERMINISTIC -- returns the same bits on every call and the very bits of neko_attn_set_path(2)
+    (the one-pass kernel summed dQ in arrival order for 256 < T <= 512)."""
+    B, T, H, hd = 4, 494, 3, 32
+    d = H * hd
+    g = torch.Generator(device=DEV).manual_seed(494)
+    qkv = (torch.randn(B * T, 3 * d, device=DEV, generator=g) * 0.7).to(torch.bfloat16)
+    do = torch.randn(B * T, d, device=DEV, generator=g).to(torch.bfloat16)
+    m = torch.ones(B, T, device=DEV)
+    m[1, :37] = 0                                        # a left-padded episode
+    kb, ks = ops.mask_bias(m)
+    drop = ops.Drop(0.1, 0xA7A21)
+    assert ops.attn_set_path(-1) == 0                    # the automatic schedule
+    out, lse, mk = ops.attn_fwd(qkv, kb, ks, B, T, H, hd, drop=drop, want_mask=True)
+    got = [ops.attn_bwd(qkv, out, do, kb, ks, lse, B, T, H, hd, drop=drop, mask=mk) for _ in range(4)]
+    assert all(torch.equal(got[0], x) for x in got[1:])
+    prev = ops.attn_set_path(2)
+    try:
+        want = ops.attn_bwd(qkv, out, do, kb, ks, lse, B, T, H, hd, drop=drop, mask=mk)
+    finally:
+        ops.attn_set_path(prev)
+    assert torch.equal(got[0], want)
