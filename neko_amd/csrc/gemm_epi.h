@@ -95,6 +95,9 @@ struct FastEpi {
 #ifndef NEKO_EPI_STORE_POLICY
 #define NEKO_EPI_STORE_POLICY 1
 #endif
+#ifndef NEKO_EPI_BATCH_READS
+#define NEKO_EPI_BATCH_READS 1     // round 6: -1.4 ... -2.5 % per launch on the bf16-output shapes, level inside the step (profiles/r06_p16_batchreads_ab.txt); no spills
+#endif
 #ifndef NEKO_EPI_STORE_POLICY_CF
 #define NEKO_EPI_STORE_POLICY_CF NEKO_EPI_STORE_POLICY      // the fp32 outputs (16-B stores) can take their own policy
 #endif
@@ -212,9 +215,27 @@ __device__ __forceinline__ void epilogue_fast(const GemmArgs& p, const Park& par
       if (F & F_ACCUM) pre_acc[st] = *reinterpret_cast<const float4*>(pcf + (long)st * scf);
     }
     // same-wave LDS write -> read: ordered by the LDS queue, no barrier (a slab is private to its wave)
+#if NEKO_EPI_BATCH_READS
+    // every slab row of the chunk is requested before the first is used (one LDS round trip per chunk instead of one per pair of steps:
+    // left to itself hipcc keeps two ds_read_b128 in flight and waits for each)
+    float4 slab_rows[NST];
+#pragma unroll
+    for (int st = 0; st < NST; ++st) slab_rows[st] = *reinterpret_cast<const float4*>(rbase + (ch * NST + st) * RPI * SWP);
+    // (pinned in registers HERE, four rows per statement: the loads cannot be sunk to their uses)
+#pragma unroll
+    for (int st = 0; st + 3 < NST; st += 4)
+      asm volatile("" : "+v"(slab_rows[st].x), "+v"(slab_rows[st].y), "+v"(slab_rows[st].z), "+v"(slab_rows[st].w),
+                        "+v"(slab_rows[st + 1].x), "+v"(slab_rows[st + 1].y), "+v"(slab_rows[st + 1].z), "+v"(slab_rows[st + 1].w),
+                        "+v"(slab_rows[st + 2].x), "+v"(slab_rows[st + 2].y), "+v"(slab_rows[st + 2].z), "+v"(slab_rows[st + 2].w),
+                        "+v"(slab_rows[st + 3].x), "+v"(slab_rows[st + 3].y), "+v"(slab_rows[st + 3].z), "+v"(slab_rows[st + 3].w));
+#endif
 #pragma unroll
     for (int st = 0; st < NST; ++st) {
+#if NEKO_EPI_BATCH_READS
+      const float4 a4 = slab_rows[st];
+#else
       const float4 a4 = *reinterpret_cast<const float4*>(rbase + (ch * NST + st) * RPI * SWP);
+#endif
       float v[4] = {a4.x, a4.y, a4.z, a4.w};
       if (F & F_ALPHA) {
 #pragma unroll

@@ -10,6 +10,10 @@ declare -A D          # extra -D flags of a variant
 D[noepi]="-DNEKO_GEMM_DIAG=4"
 D[nostores]="-DNEKO_EPI_ABL=1"
 D[noslab]="-DNEKO_EPI_ABL=3"
+D[batchreads]="-DNEKO_EPI_BATCH_READS=1"
+V[batchreads]=""
+D[trace2_batchreads]="-DNEKO_EPI_BATCH_READS=1 -DNEKO_P16_TRACE=2"
+V[trace2_batchreads]=""
 D[stagger8]="-DNEKO_P16_STAGGER_10NS=800"
 V[stagger8]=""
 D[stagger12]="-DNEKO_P16_STAGGER_10NS=1200"
