@@ -84,7 +84,7 @@ int neko_gemm_bf16(const uint16_t* A, long lda, int a_kstrided, const uint16_t* 
  * to gemm_a16 (none to gemm_b16), (2) every launch it can serve to gemm_b16, (0) none to either, (-1) returns to the built-in
  * per-shape choice (also: environment NEKO_GEMM_A16 / NEKO_GEMM_B16 = 0/1); returns the previous mode.  The choice never changes
  * which products are summed into an output element; the loops add them in a different order (fp32).  (ABI v16; replaces v14's
- * neko_gemm_set_persistent, whose kernel moved to tools/probe/) */
+ * neko_gemm_set_persistent, whose kernel moved to tools/probe/r05/) */
 int neko_gemm_set_mainloop(int mode);
 /* ABI v19 (round 6).  A fourth main loop, neko_amd/csrc/gemm_p16.hip: 256 x 256 per workgroup of EIGHT waves (128 x 64 per wave, 128
  * accumulators), the two waves of a SIMD alternating between a matrix segment (32 MFMAs) and a load segment (fragment reads + L2 -> LDS

@@ -3,7 +3,7 @@
 // registers in AGPRs.  The instruction stream of the k-loop (which LDS read, which DMA piece and which scalar instruction sits in
 // which gap between two MFMAs, every s_waitcnt count, the register numbers) is written by hand -- tools/gen_gemm_a16.py holds it and
 // its design notes, gemm_a16_loop.inc is its output -- because the hipcc-scheduled form of this geometry (gemm_glds.hip, C256x256w4 /
-// tools/probe/gemm_mfma16_attempt.patch) spills or serialises (profiles/r03_mfma_shape_power.txt).  Around the loop everything is
+// tools/probe/r04/gemm_mfma16_attempt.patch) spills or serialises (profiles/r03_mfma_shape_power.txt).  Around the loop everything is
 // ordinary HIP: tile rasterisation, the per-lane DMA offsets and LDS read addresses, and the fast epilogue of gemm_epi.h, which
 // takes the accumulators out of the AGPRs 32 rows at a time.
 //
@@ -12,7 +12,7 @@
 #include <cstdlib>
 #include "gemm_epi.h"
 #ifndef NEKO_A16_LOOP_INC
-#define NEKO_A16_LOOP_INC "gemm_a16_loop.inc"      // (tools/probe/gemm_loop_ablation.sh builds timing-only variants of the stream)
+#define NEKO_A16_LOOP_INC "gemm_a16_loop.inc"      // (tools/probe/r05/gemm_loop_ablation.sh builds timing-only variants of the stream)
 #endif
 #include NEKO_A16_LOOP_INC
 

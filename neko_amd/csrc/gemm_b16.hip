@@ -15,7 +15,7 @@
 #include <cstdlib>
 #include "gemm_epi.h"
 #ifndef NEKO_B16_LOOP_INC
-#define NEKO_B16_LOOP_INC "gemm_b16_loop.inc"      // (tools/probe/gemm_loop_ablation.sh builds timing-only variants of the stream)
+#define NEKO_B16_LOOP_INC "gemm_b16_loop.inc"      // (tools/probe/r05/gemm_loop_ablation.sh builds timing-only variants of the stream)
 #endif
 #include NEKO_B16_LOOP_INC
 

@@ -858,7 +858,7 @@ int launch(const GemmArgs& a, hipStream_t s) {
     if (A_KC && B_KC && cfg == 2 && a.N % 256 == 0 && a.N <= 1024 && fill(256, 256, 256) >= 0.9) cfg = 3;
     if (A_KC && !B_KC && cfg == 0 && big_out && a.N % 128 == 0 && a.N <= 1024 && fill(256, 128, 512) >= 0.9) cfg = 2;
     // round 4 (two row panels per rasterisation group): with whole rounds of 256 x 256 tiles the 8-wave block is ahead again for this
-    // shape, inside the step 138.6 -> 131.7 us at 65536 rows (tools/probe/step_kernel_ab.sh)
+    // shape, inside the step 138.6 -> 131.7 us at 65536 rows (tools/probe/r04/step_kernel_ab.sh)
     if (A_KC && !B_KC && cfg == 2 && klen < 1536 && a.N % 256 == 0 && a.N <= 1024 && fill(256, 256, 256) >= 0.9) cfg = 3;
     const long t3n = (long)((a.M + 255) / 256) * ((a.N + 255) / 256) * (a.splitk > 1 ? a.splitk : 1);
     const bool wide = a.N > 2048;

@@ -522,7 +522,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--geom", default="a16", choices=tuple(GEOMS), help="workgroup geometry (see Geom)")
     ap.add_argument("--ablate", default="", choices=("", "mfma", "dma", "reads", "barrier"),
-                    help="timing-only streams (WRONG results) for tools/probe/gemm_loop_ablation.sh: 'mfma' replaces every MFMA by s_nop 0 "
+                    help="timing-only streams (WRONG results) for tools/probe/r05/gemm_loop_ablation.sh: 'mfma' replaces every MFMA by s_nop 0 "
                          "(what the DMA + LDS-read traffic alone costs), 'dma' drops the in-loop DMA requests (matrix pipe + LDS reads alone), "
                          "'reads' drops the fragment reads, 'barrier' the per-k-tile block barriers")
     ap.add_argument("--kc", type=int, default=64, choices=(32, 64), help="layout of a k-contiguous A operand")
