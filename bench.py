@@ -505,6 +505,7 @@ def main():
             "rccl_ranks_seen": ranks_seen,
             "exposed_comm_ms_per_step": exposed_comm_ms,
             "dp_payload": (dp.payload if dp is not None else None),
+            "dp_collective": (dp.collective if dp is not None else None),
             "captured_step": (cap_stats if args.capture else None),
         }
         if not args.no_cpu_baseline and world == 1:          # rank 0 at N = 1 only (the other ranks would idle behind it)

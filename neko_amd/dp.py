@@ -22,8 +22,15 @@ import torch
 import torch.distributed as dist
 
 
+class _Done:
+    """a finished piece of work (marks where a staged payload is widened back once the handles in front of it have been waited for)"""
+    def wait(self):
+        return True
+
+
 class GradReducer:
-    def __init__(self, flat, bucket_bytes: Optional[int] = None, group=None, payload: str = "fp32", force_collectives: bool = False):
+    def __init__(self, flat, bucket_bytes: Optional[int] = None, group=None, payload: str = "fp32", force_collectives: bool = False,
+                 collective: Optional[str] = None):
         """payload: "fp32" (default: what DDP sends for the reference's fp32 master gradients) or "bf16" -- every bucket is
         rounded to bf16 into a staging buffer, summed over the ranks in bf16 and widened back into the fp32 gradient:
         half the bytes on each xGMI link (249 instead of 498 MB per step at 768d) for one extra rounding of each rank's
@@ -31,6 +38,16 @@ class GradReducer:
         train.py."""
         assert payload in ("fp32", "bf16"), payload
         self.payload = payload
+        #: "allreduce" (default) or "rs_ag" (NEKO_DP_COLLECTIVE): every message as reduce-scatter + all-gather (SURVEY 8(e)).  The sums are
+        #: the same; what differs is what RCCL may do with them on the 7-link xGMI mesh: an all-reduce that RCCL runs as a ring carries the
+        #: whole payload over ONE link per direction, while reduce-scatter / all-gather of 1/N shards can use every direct link at once.
+        #: Unmeasured here (the pool hands out one GPU per box): opt-in, and tools/scale_check.sh records which one a real node prefers.
+        #: A backend without reduce_scatter_tensor falls back to all-reduce, with one warning.
+        collective = collective or os.environ.get("NEKO_DP_COLLECTIVE", "allreduce")
+        assert collective in ("allreduce", "rs_ag"), collective
+        self.collective = collective
+        self._rs_ag_ok: Optional[bool] = None
+        self._keep: List = []                # shards of in-flight reduce-scatter / all-gather pairs
         #: issue every collective even in a world of ONE rank (a sum over one rank is the identity): the only way to run
         #: the reducer's RCCL calls, streams and events on a one-GPU box (tests/test_dp_gpu.py, bench.py --force-dp)
         self.force = bool(force_collectives)
@@ -181,10 +198,38 @@ class GradReducer:
                             ops.cast_f32_bf16(g, st)
                         else:
                             st.copy_(g)
-                        h = dist.all_reduce(st, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-                        self.handles.append((h, st, g))
+                        for h in self._sum_over_ranks(st):
+                            self.handles.append((h, None, g))
+                        self.handles.append((_Done(), st, g))          # widened back into g by finish(), behind the handles above
                     else:
-                        self.handles.append((dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True), None, g))
+                        for h in self._sum_over_ranks(g):
+                            self.handles.append((h, None, g))
+
+    def _sum_over_ranks(self, t: torch.Tensor) -> List:
+        """SUM of `t` (1-D, contiguous) over the ranks, in place; returns the async work handles in issue order."""
+        n, w = t.numel(), max(self.world, 1)
+        if self.collective == "rs_ag" and n >= 1024 * w and self._rs_ag_ok is not False:
+            n0 = n // w * w                                   # the part that divides into equal shards; < w elements are left over
+            shard = torch.empty(n0 // w, dtype=t.dtype, device=t.device)
+            try:
+                hs = [dist.reduce_scatter_tensor(shard, t[:n0], op=dist.ReduceOp.SUM, group=self.group, async_op=True)]
+                self._rs_ag_ok = True
+            except (RuntimeError, NotImplementedError) as e:   # raised at issue time, on every rank alike (same backend): nothing was sent
+                self._rs_ag_ok = False
+                import warnings
+                warnings.warn(f"GradReducer(collective='rs_ag'): the backend has no reduce_scatter_tensor for these tensors ({e}); using all-reduce")
+                return [dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)]
+            self._keep.append(shard)
+            # NCCL / RCCL: the collectives of one process group run on one communication stream, so the all-gather is ordered behind the
+            # reduce-scatter that fills `shard` without any wait here (a wait would order the COMPUTE stream behind it).  Other backends
+            # (gloo: a pool of worker threads) give no such order: wait for the first before issuing the second.
+            if not (dist.get_backend(self.group) == "nccl" and t.is_cuda):
+                hs[0].wait()
+            hs.append(dist.all_gather_into_tensor(t[:n0], shard, group=self.group, async_op=True))
+            if n0 < n:
+                hs.append(dist.all_reduce(t[n0:], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            return hs
+        return [dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)]
 
     def reduce_flags(self, flags: torch.Tensor) -> None:
         if self.world > 1 or self.force:   # stream-ordered (NCCL: the current stream waits on the comm stream, the host does not)
@@ -202,6 +247,7 @@ class GradReducer:
                 if staged.is_cuda:       # (allocated while the side stream was current, read here on the compute stream)
                     staged.record_stream(torch.cuda.current_stream(staged.device))
         self.handles.clear()
+        self._keep.clear()
         if self.flat.grad.is_cuda:
             from .engine import SideStream
             SideStream.join(self.flat.grad.device)      # nothing of the backward is left on the side stream when the optimiser starts

@@ -16,7 +16,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, results, declare=False, payload="fp32"):
+def _worker(rank, world, port, results, declare=False, payload="fp32", collective="allreduce"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -25,7 +25,7 @@ def _worker(rank, world, port, results, declare=False, payload="fp32"):
         torch.manual_seed(100 + rank)            # different initial weights per rank
         m = GatoPolicy("cpu", 64, 2, 2, 0.0, resid_mid_channels=128, context_len=32, text_tokenizer=64)
         flat = m._flat
-        dp = GradReducer(flat, bucket_bytes=64 * 1024, payload=payload)      # small buckets: several slices per range
+        dp = GradReducer(flat, bucket_bytes=64 * 1024, payload=payload, collective=collective)      # small buckets: several slices per range
         dp.broadcast_parameters()
         if declare:                 # control-only run: the 64 text rows of the token embedding never see a gradient
             dp.declare_unused_rows("embed_token.weight", 0, m.text_tokens)
@@ -68,19 +68,22 @@ def _worker(rank, world, port, results, declare=False, payload="fp32"):
         w_all = [torch.zeros_like(w0) for _ in range(world)]
         dist.all_gather(w_all, w0)
         results[rank] = dict(ok_sum=bool(ok_sum), ok_never=bool(ok_never), same_w=bool(torch.equal(w_all[0], w_all[1])),
-                             flags=flags.tolist(), scale=float(dp.grad_scale))
+                             flags=flags.tolist(), scale=float(dp.grad_scale), rs_ag=dp._rs_ag_ok)
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("declare,payload", [(False, "fp32"), (True, "fp32"), (False, "bf16"), (True, "bf16")])
-def test_grad_reducer_world2_gloo(declare, payload):
+@pytest.mark.parametrize("declare,payload,collective", [(False, "fp32", "allreduce"), (True, "fp32", "allreduce"), (False, "bf16", "allreduce"),
+                                                        (True, "bf16", "allreduce"), (True, "fp32", "rs_ag"), (False, "bf16", "rs_ag")])
+def test_grad_reducer_world2_gloo(declare, payload, collective):
+    """collective = "rs_ag" (round 6): every message as reduce-scatter + all-gather of 1 / world shards, slices that do not
+    divide by the world size finish with a small all-reduce -- the same sums as the all-reduce form."""
     world = 2
     port = _free_port()
     ctx = mp.get_context("spawn")
     with ctx.Manager() as mgr:
         results = mgr.dict()
-        procs = [ctx.Process(target=_worker, args=(r, world, port, results, declare, payload)) for r in range(world)]
+        procs = [ctx.Process(target=_worker, args=(r, world, port, results, declare, payload, collective)) for r in range(world)]
         for p in procs:
             p.start()
         for p in procs:
@@ -91,6 +94,7 @@ def test_grad_reducer_world2_gloo(declare, payload):
             assert res["ok_sum"] and res["ok_never"] and res["same_w"], res
             assert res["flags"] == [1, 1, 1]          # union over ranks of "range took part in this step"
             assert abs(res["scale"] - 0.5) < 1e-12    # averaging folded into the optimiser's gradient scale
+            assert res["rs_ag"] is (True if collective == "rs_ag" else None)      # the split collectives really ran (gloo has them)
 
 
 def test_bench_gpus_flag_spawns_the_ranks():

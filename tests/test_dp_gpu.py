@@ -162,12 +162,14 @@ def _rccl_worker(port, out):
         from neko_amd.dp import GradReducer
         from neko_amd.training.optim import NekoAdamW
         res = {}
-        for payload in ("fp32", "bf16", None):                 # None: no reducer at all (the reference run)
+        for payload in ("fp32", "bf16", "fp32+rs_ag", None):   # None: no reducer at all (the reference run)
             m = _make()
             opt = NekoAdamW(m, lr=1e-2, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.1)
             dp = None
             if payload is not None:
-                dp = GradReducer(m._flat, bucket_bytes=32 * 1024, payload=payload, force_collectives=True)
+                # "+rs_ag" (round 6): every message as RCCL reduce-scatter + all-gather instead of one all-reduce
+                dp = GradReducer(m._flat, bucket_bytes=32 * 1024, payload=payload.split("+")[0], force_collectives=True,
+                                 collective="rs_ag" if payload.endswith("rs_ag") else "allreduce")
                 dp.broadcast_parameters()
                 dp.attach(m, opt)
             losses = []
@@ -184,6 +186,8 @@ def _rccl_worker(port, out):
             torch.cuda.synchronize()
             res[str(payload)] = (losses, {k: v.detach().cpu() for k, v in m.state_dict().items()
                                           if v.dtype == torch.float32 and 4096 <= v.numel() < 70000})
+            if payload is not None and payload.endswith("rs_ag"):
+                res["rs_ag_ran"] = dp._rs_ag_ok
         out["res"] = res
         out["backend"] = dist.get_backend()
     finally:
@@ -209,6 +213,10 @@ def test_reducer_collectives_execute_on_rccl_in_a_world_of_one():
     l32, w32 = res["fp32"]
     l16, w16 = res["bf16"]
     lref, wref = res["None"]
+    lrs, wrs = res["fp32+rs_ag"]
+    assert res["rs_ag_ran"] is True and lrs == lref          # RCCL's reduce_scatter_tensor / all_gather_into_tensor really ran
+    for k in wref:
+        assert torch.allclose(wrs[k], wref[k], rtol=1e-6, atol=1e-7), k
     assert l32 == lref
     for k in wref:
         assert torch.allclose(w32[k], wref[k], rtol=1e-6, atol=1e-7), k      # (atomics in the embedding scatter)
