@@ -16,15 +16,18 @@ if [ "$ngpu" -lt 2 ]; then
 fi
 export HSA_ENABLE_IPC_MODE_LEGACY=0 GPU_MAX_HW_QUEUES=${GPU_MAX_HW_QUEUES:-8}
 for wl in m-mix c3; do
-  for payload in fp32 bf16; do
+  for payload in fp32 bf16 fp32+rs_ag; do          # "+rs_ag": every message as reduce-scatter + all-gather (NEKO_DP_COLLECTIVE=rs_ag)
+    coll=allreduce; case $payload in *+rs_ag) coll=rs_ag;; esac
+    export NEKO_DP_COLLECTIVE=$coll
+    pl=${payload%%+*}
     for n in 1 2 4 8; do
       [ "$n" -gt "$ngpu" ] && continue
       tag=${wl}_${payload}_n$n
       port=$((29500 + RANDOM % 2000))
       if [ "$n" = 1 ]; then
-        NEKO_DP_PAYLOAD=$payload python3 bench.py --workload $wl --gpus 1 --no-cpu-baseline > "$out/$tag.json" 2> "$out/$tag.err"
+        NEKO_DP_PAYLOAD=$pl python3 bench.py --workload $wl --gpus 1 --no-cpu-baseline > "$out/$tag.json" 2> "$out/$tag.err"
       else
-        NCCL_DEBUG=INFO NCCL_DEBUG_SUBSYS=INIT,COLL,TUNING NEKO_DP_PAYLOAD=$payload python3 -m torch.distributed.run --nnodes=1 --nproc-per-node $n \
+        NCCL_DEBUG=INFO NCCL_DEBUG_SUBSYS=INIT,COLL,TUNING NEKO_DP_PAYLOAD=$pl python3 -m torch.distributed.run --nnodes=1 --nproc-per-node $n \
           --master-addr 127.0.0.1 --master-port $port bench.py --workload $wl --gpus $n --no-cpu-baseline > "$out/$tag.json" 2> "$out/$tag.err"
       fi
       python3 - "$out/$tag.json" "$out/$tag.err" "$wl" "$payload" "$n" <<'PY' | tee -a "$out/summary.txt"
@@ -49,7 +52,7 @@ python3 - "$out" <<'PY' | tee -a "$out/summary.txt"
 import glob, json, os, re, sys
 rows = {}
 for f in glob.glob(os.path.join(sys.argv[1], "*_n*.json")):
-    m = re.match(r"(.+)_(fp32|bf16)_n(\d+)\.json", os.path.basename(f))
+    m = re.match(r"(.+)_(fp32|bf16|fp32\+rs_ag)_n(\d+)\.json", os.path.basename(f))
     line = next((l for l in open(f) if l.startswith("{")), None)
     if m and line:
         rows.setdefault((m.group(1), m.group(2)), {})[int(m.group(3))] = json.loads(line)["value"]
