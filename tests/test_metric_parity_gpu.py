@@ -114,6 +114,24 @@ def test_metric_shape_768d_6L_hd32_vs_oracle():
     _compare(cfg, S.metric_mix_batch(3, 5, "cpu"), seed=11, row_stride=37)
 
 
+def test_metric_shape_vs_oracle_through_the_two_waves_per_simd_gemm_loop():
+    """Round 6: gemm_p16.hip serves every forward / dgrad / LM-head-logits launch of the bench step, but only above 512 tiles -- a
+    3-sequence parity batch (3072 rows) never reaches it by itself.  neko_gemm_set_mainloop(3) sends every launch it can serve to it
+    (K = 768 / 2304 / 3072 are whole loop trips, 3072 rows and the padded loss rows whole 256-row tiles): the same oracle gates, and a
+    probe call says that the loop really is the one in use."""
+    from neko_amd import ops
+    from neko_amd.tasks import synthetic as S
+    cfg = O.OracleConfig(embed_dim=768, layers=6, heads=24)
+    prev = ops.gemm_set_mainloop(3)
+    try:
+        a = torch.randn(3072, 768, device=DEV).to(torch.bfloat16); w = torch.randn(768, 2304, device=DEV).to(torch.bfloat16)
+        ops.gemm(a, w, 3072, 2304, 768, b_kstrided=True, out_bf16=torch.empty(3072, 2304, dtype=torch.bfloat16, device=DEV))
+        assert ops.gemm_last_mainloop() == 5
+        _compare(cfg, S.metric_mix_batch(3, 5, "cpu"), seed=11, row_stride=37)
+    finally:
+        ops.gemm_set_mainloop(prev)
+
+
 def test_c5_geometry_2048d_hd128_vs_oracle():
     from neko_amd.tasks import synthetic as S
     cfg = O.OracleConfig(embed_dim=2048, layers=2, heads=16)
