@@ -325,7 +325,8 @@ int neko_gemm_p16_try(const GemmArgs& a_in, int a_kstrided, int b_kstrided, int 
     // gemm_glds64 (profiles/r06_p16_first_bench.txt), m-mix step 36.16 -> 35.20 ms (profiles/r06_p16_step_ab.txt); the weight gradients
     // (both operands k-strided, long contraction) are level with gemm_a16 and stay there.
     static const int rule = [] { const char* e = getenv("NEKO_GEMM_P16_RULE"); return e ? atoi(e) : 63; }();
-    static const int min_tiles = [] { const char* e = getenv("NEKO_GEMM_P16_MIN_TILES"); return e ? atoi(e) : 512; }();
+    static const int min_tiles = [] { const char* e = getenv("NEKO_GEMM_P16_MIN_TILES"); return e ? atoi(e) : 256; }();      // one full round of CUs: 32768-row steps (384 tiles at N = 768)
+                                                                                    // 19.53 -> 19.23 ms with 384 / 192 against 512; README sizes level (profiles/r06_p16_min_tiles_b32.txt, r06_nt_sizes_ab.txt)
     const long tiles = (long)(a.M / 256) * (a.N / 256) * (a.splitk > 1 ? a.splitk : 1);
     int cls;
     if (a_kstrided) cls = 64;
