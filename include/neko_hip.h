@@ -88,8 +88,8 @@ int neko_gemm_bf16(const uint16_t* A, long lda, int a_kstrided, const uint16_t* 
 int neko_gemm_set_mainloop(int mode);
 /* ABI v19 (round 6).  A fourth main loop, neko_amd/csrc/gemm_p16.hip: 256 x 256 per workgroup of EIGHT waves (128 x 64 per wave, 128
  * accumulators), the two waves of a SIMD alternating between a matrix segment (32 MFMAs) and a load segment (fragment reads + L2 -> LDS
- * requests) of hand-placed instruction streams; serves launches of interior 256 x 256 tiles whose contraction range is a multiple of 384
- * (A k-contiguous) or 128 (both operands k-strided).  neko_gemm_set_mainloop(3) sends every launch it can serve to it.
+ * requests) of hand-placed instruction streams; serves launches of interior 256 x 256 tiles whose contraction range is a multiple of 128 and
+ * at least 384 (A k-contiguous: 12 k-tiles per loop trip, a tail of 4 / 8) or 128 (both operands k-strided).  neko_gemm_set_mainloop(3) sends every launch it can serve to it.
  * neko_gemm_last_mainloop(): which loop served the calling thread's last neko_gemm_bf16 / neko_gemm_dgrad_gelu_colsum launch --
  * 0 gemm_glds (32 x 32 x 16 loop, any tile configuration), 1 gemm_a16, 2 gemm_b16, 3 gemm_glds64 (the 8-wave 256 x 256 loop with
  * whole-line A slots), 4 the register-staged fallback (gemm_bf16.hip), 5 gemm_p16; -1 before the first launch.  Thread-local; exists so

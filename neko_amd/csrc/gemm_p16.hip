@@ -9,7 +9,7 @@
 //
 // LDS (160 KB, one workgroup per CU): A k-contiguous in THREE 64-k slots of whole 128-B lines (96 KB at 0) or k-strided in a 4-stage
 // 32-k ring (64 KB at 0); B in a 4-stage 32-k ring at 96 KB, k-strided or k-contiguous.  Serves launches of interior 256 x 256 tiles whose
-// contraction range (per split-K slice) is a multiple of 384 (A k-contiguous: 12 k-tiles per loop trip) or 128 (A k-strided), with
+// contraction range (per split-K slice) is a multiple of 128 and at least one loop trip (384 with a k-contiguous A operand, else 128), with
 // one of the compiled epilogue feature sets; everything else stays with gemm_a16.hip / gemm_glds.hip.
 #include <cstdlib>
 #include "gemm_epi.h"
@@ -100,7 +100,9 @@ __global__ __launch_bounds__(512, 2) void gemm_p16_kernel(GemmArgs p) {
     kbeg = slice * p.k_per_split;
     kend = min(p.K, kbeg + p.k_per_split);
   }
-  const unsigned nkt = (unsigned)(kend - kbeg) / 32u, ntrips = nkt / (A_KC ? (unsigned)NEKO_P16_TRIP_KC : 4u);
+  // k-tiles = whole loop trips (12 with a k-contiguous A operand, else 4) + a tail of 0 / 4 / 8 k-tiles (the first groups of the same body)
+  const unsigned nkt = (unsigned)(kend - kbeg) / 32u, trip = A_KC ? (unsigned)NEKO_P16_TRIP_KC : 4u;
+  const unsigned ntrips = nkt / trip, tail = (nkt % trip) / 4u;
 
   const unsigned lds0 = __builtin_amdgcn_readfirstlane(
       (unsigned)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)smem));
@@ -195,7 +197,8 @@ __global__ __launch_bounds__(512, 2) void gemm_p16_kernel(GemmArgs p) {
     [vob2] "v"(vob[2]), [vob3] "v"(vob[3]), [ra0] "v"(ra[0]), [ra1] "v"(ra[1]), [ra2] "v"(ra[2]), [ra3] "v"(ra[3]), [rb0] "v"(rb[0]),  \
     [rb1] "v"(rb[1]), [ha] "v"(ha), [hb] "v"(hb),                                                                               \
     [galo] "s"(galo), [gahi] "s"(gahi), [gblo] "s"(gblo), [gbhi] "s"(gbhi), [sa] "s"(P16_U(stepa)), [sb] "s"(P16_U(stepb)),       \
-    [nkt] "s"(P16_U(nkt)), [ntrips] "s"(P16_U(ntrips)), [ldswa] "s"(P16_U(ldswa)), [ldswb] "s"(P16_U(ldswb)), [half] "s"(P16_U(half)) \
+    [nkt] "s"(P16_U(nkt)), [ntrips] "s"(P16_U(ntrips)), [ldswa] "s"(P16_U(ldswa)), [ldswb] "s"(P16_U(ldswb)), [half] "s"(P16_U(half)), \
+    [tail] "s"(P16_U(tail))                                                                                                     \
   : NEKO_P16_CLOBBERS
   if constexpr (A_KC && B_KC) asm volatile(NEKO_P16_LOOP_KC_KC : NEKO_P16_OPERANDS);
   else if constexpr (A_KC && !B_KC) asm volatile(NEKO_P16_LOOP_KC_KS : NEKO_P16_OPERANDS);
@@ -293,18 +296,20 @@ int neko_gemm_p16_try(const GemmArgs& a_in, int a_kstrided, int b_kstrided, int 
   if (a_kstrided && !b_kstrided) return 1;
   GemmArgs a = a_in;
   if ((a.M & 255) || (a.N & 255)) return 1;
-  const int unit = a_kstrided ? 128 : 32 * NEKO_P16_TRIP_KC;                                   // k-tiles per loop trip x 32
+  // contraction range (per split-K slice): at least one loop trip (12 k-tiles with a k-contiguous A operand, else 4) and a multiple of
+  // 128 -- what is left behind whole trips (4 or 8 k-tiles) runs as the first groups of the same loop body
+  const int trip_k = a_kstrided ? 128 : 32 * NEKO_P16_TRIP_KC;
   const int klen = a.splitk > 1 ? a.k_per_split : a.K;
-  if (klen < unit || (klen % unit)) return 1;
-  if (a.splitk > 1) {                                                         // every slice a whole number of loop trips
+  if (klen < trip_k || (klen % 128)) return 1;
+  if (a.splitk > 1) {
     const long last = (long)a.K - (long)(a.splitk - 1) * a.k_per_split;
-    if (last < unit || (last % unit)) return 1;
+    if (last < trip_k || (last % 128)) return 1;
   }
   // the per-lane DMA offsets are 32-bit byte offsets within the tile's operand panel
   if ((a_kstrided ? 32 * a.lda : 256 * a.lda) * 2 >= (1L << 31) || (b_kstrided ? 32 * a.ldb : 256 * a.ldb) * 2 >= (1L << 31)) return 1;
   const bool to_ws = a.splitk > 1 && a.splitk_ws;
   if (a.splitk > 1 && !to_ws) return 1;
-  if (to_ws && (a.bias || a.resid || a.act || a.Cb || a.drop_thr || a.alpha != 1.0f || a.alpha_dev)) return 1;
+  if (to_ws && (a.bias || a.resid || a.act || a.Cb || a.drop_thr)) return 1;      // (alpha scales every slice: linear, the LM-head dH uses it)
   const long ldcf_out = to_ws ? a.N : a.ldcf;
   if (((ldcf_out | a.ldr | a.ldcb | a.ldact | a.ldpre) & 3)) return 1;
   // column sums ride along only with the GELU' dgrad feature sets (every tile is interior here)

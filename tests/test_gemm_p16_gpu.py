@@ -51,11 +51,12 @@ def operands(M, N, K, layout, seed=None):
 
 
 @pytest.mark.parametrize("layout,K", [("nn", 384), ("nn", 768), ("nn", 3072), ("nt", 384), ("nt", 768), ("nt", 2304), ("tn", 128), ("tn", 512),
-                                      ("tn", 4224)])
+                                      ("tn", 4224), ("nn", 512), ("nn", 640), ("nn", 2048), ("nt", 512), ("nt", 1024), ("nt", 8192)])
 @pytest.mark.parametrize("M,N", [(256, 256), (768, 512)])
 def test_gemm_p16_main_loop_layouts(p16, layout, M, N, K):
     """One loop trip (12 k-tiles with a k-contiguous A operand, 4 with both operands k-strided: the surplus requests at the end re-fetch
-    the last unit), two and many trips; forward (A k-contiguous x weights stored (in, out)), dgrad (both k-contiguous: B in two 64-k
+    the last unit), two and many trips, and contraction ranges that leave 4 or 8 k-tiles behind whole trips (512 = 12 + 4, 640 = 12 + 8,
+    1024 / 2048 / 8192: the 2048d geometry of configs[4]) -- the tail runs the first groups of the same loop body; forward (A k-contiguous x weights stored (in, out)), dgrad (both k-contiguous: B in two 64-k
     slots) and weight-gradient (both k-strided) layouts; fp32 and bf16 outputs; against the fp32 product and against the default loops."""
     A, Bm, A_dev, B_dev, a_ks, b_ks, _ = operands(M, N, K, layout)
     ref = A @ Bm
@@ -98,7 +99,7 @@ def test_gemm_p16_many_tiles_and_leading_dimensions(p16):
 
 
 @pytest.mark.parametrize("epi", ["bias_bf16", "bias_resid", "bias_resid_drop", "bias_gelu_pre", "bias_gelu_factor", "gelubwd", "gelubwd_factor_colsum",
-                                 "alpha_dev", "bias_f32", "wgrad_accumulate", "wgrad_alpha_accumulate", "wgrad_splitk", "fwd_splitk"])
+                                 "alpha_dev", "bias_f32", "wgrad_accumulate", "wgrad_alpha_accumulate", "wgrad_splitk", "fwd_splitk", "fwd_splitk_alpha"])
 def test_gemm_p16_epilogues(p16, epi):
     """Every compiled epilogue behind gemm_p16.hip (one kernel per layout and feature set; the accumulators leave the AGPRs 32 rows at a
     time): fp32 tolerance against the reference product, the dropped elements equal to the default loop's, run-to-run bit identity."""
@@ -217,6 +218,14 @@ def test_gemm_p16_epilogues(p16, epi):
             return (out,)
         (out,) = twice(run)
         close(out, ref, 2e-4, 2e-4 * math.sqrt(K), epi)
+    elif epi == "fwd_splitk_alpha":          # the LM-head dH form: split-K slices to the workspace, each scaled by the device-side loss scale
+        alpha_dev = torch.tensor([0.25], device=DEV)
+        def run():
+            out = torch.full((M, N), float("nan"), device=DEV)
+            p16.gemm(A_dev, B_fwd, M, N, K, alpha=2.0, alpha_dev=alpha_dev, out_f32=out, splitk=2, k_per_split=384, **fwd)
+            return (out,)
+        (out,) = twice(run)
+        close(out, 0.5 * ref, 2e-4, 2e-4 * math.sqrt(K), epi)
     else:
         def run():
             out = torch.full((M, N), float("nan"), device=DEV)
@@ -227,9 +236,9 @@ def test_gemm_p16_epilogues(p16, epi):
 
 
 def test_gemm_p16_declines_what_it_cannot_serve(p16):
-    """Edge tiles, contraction ranges that are not whole loop trips, and the A-k-strided x B-k-contiguous layout stay with the other loops
-    (same results)."""
-    for (M, N, K, layout) in [(300, 256, 768, "nn"), (256, 256, 512, "nn"), (256, 256, 768, "tt")]:
+    """Edge tiles, contraction ranges below one loop trip or not a multiple of 128, and the A-k-strided x B-k-contiguous layout stay with
+    the other loops (same results)."""
+    for (M, N, K, layout) in [(300, 256, 768, "nn"), (256, 256, 256, "nn"), (256, 256, 448, "nt"), (256, 256, 768, "tt")]:
         g = torch.Generator().manual_seed(K + M)
         A = rb(torch.randn(M, K, generator=g)); Bm = rb(torch.randn(K, N, generator=g) * 0.25)
         a_ks, b_ks = layout in ("tn", "tt"), layout in ("nn", "tn")

@@ -451,24 +451,29 @@ def stream_p16(a_mode, b_mode, sched):
     # [L, C] with [C, L] between two B0s as the hardware arbitrates
     b1 = ["s_barrier"] if sched["p16_b1"] else []
 
-    def body_x(rep):          # C(j) | B0 | L(j + 1) | B1
-        out = []
-        for j in range(trip * rep, trip * (rep + 1)):
-            out += comp + [f"s_waitcnt vmcnt({counts[j]})", "s_barrier"] + ld[j + 1] + ["s_waitcnt lgkmcnt(0)"] + b1
-        return out
+    def tile_x(j):            # C(j) | B0 | L(j + 1) | B1
+        return comp + [f"s_waitcnt vmcnt({counts[j]})", "s_barrier"] + ld[j + 1] + ["s_waitcnt lgkmcnt(0)"] + b1
 
-    def body_y(rep):          # L(j) | B0 | C(j) | B1
-        out = []
-        for j in range(trip * rep, trip * (rep + 1)):
-            out += ld[j] + [f"s_waitcnt vmcnt({counts[j]})", "s_waitcnt lgkmcnt(0)", "s_barrier"] + comp + b1
-        return out
+    def tile_y(j):            # L(j) | B0 | C(j) | B1
+        return ld[j] + [f"s_waitcnt vmcnt({counts[j]})", "s_waitcnt lgkmcnt(0)", "s_barrier"] + comp + b1
+
+    def body(tile, rep, lo=0, hi=None):
+        return [ins for j in range(trip * rep + lo, trip * rep + (trip if hi is None else hi)) for ins in tile(j)]
     # one loop body per half: the first trip (which follows the prologue's issue order) must equal the steady state
-    assert body_x(0) == body_x(1) == body_x(2), "X: loop body not periodic from the first trip on"
-    assert body_y(0) == body_y(1) == body_y(2), "Y: loop body not periodic from the first trip on"
-    assert sum(i == "s_barrier" for i in body_x(1)) == sum(i == "s_barrier" for i in body_y(1)) == (2 if sched["p16_b1"] else 1) * trip
+    for tile in (tile_x, tile_y):
+        assert body(tile, 0) == body(tile, 1) == body(tile, 2), "loop body not periodic from the first trip on"
+    assert sum(i == "s_barrier" for i in body(tile_x, 1)) == sum(i == "s_barrier" for i in body(tile_y, 1)) == (2 if sched["p16_b1"] else 1) * trip
     loop_tail = [f"s_sub_u32 s{S_CNT}, s{S_CNT}, 1", f"s_cmp_lg_u32 s{S_CNT}, 0"]
-    X = ld[0] + ["s_waitcnt lgkmcnt(0)", "XLOOP_%=:"] + body_x(1) + loop_tail + ["s_cbranch_scc1 XLOOP_%=", "s_branch PEND_%="]
-    Y = (["s_setprio 1"] if sched["p16_setprio"] else []) + ["YLOOP_%=:"] + body_y(1) + loop_tail + ["s_cbranch_scc1 YLOOP_%="] + \
+
+    def tail(tile, tag):
+        """contraction ranges that are whole trips plus 4 or 8 k-tiles (K % 128 == 0, e.g. 2048 or 8192): behind the loop the tile index is a
+        multiple of `trip` again, so the remainder is the first one or two 4-tile groups of the very same body (%[tail] = (k-tiles % 12) / 4)"""
+        if trip == 4:
+            return []
+        return ["s_cmp_eq_u32 %[tail], 0", f"s_cbranch_scc1 {tag}END_%="] + body(tile, 1, 0, 4) + \
+               ["s_cmp_eq_u32 %[tail], 1", f"s_cbranch_scc1 {tag}END_%="] + body(tile, 1, 4, 8) + [f"{tag}END_%=:"]
+    X = ld[0] + ["s_waitcnt lgkmcnt(0)", "XLOOP_%=:"] + body(tile_x, 1) + loop_tail + ["s_cbranch_scc1 XLOOP_%="] + tail(tile_x, "X") + ["s_branch PEND_%="]
+    Y = (["s_setprio 1"] if sched["p16_setprio"] else []) + ["YLOOP_%=:"] + body(tile_y, 1) + loop_tail + ["s_cbranch_scc1 YLOOP_%="] + tail(tile_y, "Y") + \
         (["s_setprio 0"] if sched["p16_setprio"] else [])
     L += X + ["YPROG_%=:"] + Y + ["PEND_%=:"]
     # surplus DMA landed, surplus fragment reads returned, accumulators readable
