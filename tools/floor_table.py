@@ -43,7 +43,7 @@ GEMMS = [
     ("wgrads c_fc / MLP c_proj (split-K)", ("gemm_a16_kernelILb0ELb0",), 252, 12, 256, 256, 4 * D, D, M),
     ("wgrads c_attn / attn c_proj (split-K)", ("gemm_a16_kernelILb0ELb0",), 243, 12, 256, 256, 2 * D, D, M),
     ("LM-head logits", ("gemm_p16_kernelILb1ELb1ELj256E", "gemm_a16_kernelILb1ELb1"), 18245, 1, 256, 256, ROWS_LM, VPAD, D),
-    ("LM-head dH (split-K)", ("gemm_a16_kernelILb1ELb0",), 1869, 1, 256, 256, ROWS_LM, D, VPAD),
+    ("LM-head dH (split-K)", ("gemm_p16_kernelILb1ELb0ELj576E", "gemm_a16_kernelILb1ELb0"), 1869, 1, 256, 256, ROWS_LM, D, VPAD),
     ("LM-head dW (split-K)", ("gemm_a16_kernelILb0ELb0",), 1230, 1, 256, 256, VPAD, D, ROWS_LM),
 ]
 
@@ -105,7 +105,7 @@ DEMANGLED = {"gemm_a16_kernelILb1ELb0": "gemm_a16_kernel<true, false>", "gemm_a1
              "gemm_glds64_kernelILb0": "gemm_glds64_kernel<false>", "gemm_glds64_kernelILb1": "gemm_glds64_kernel<true>",
              "gemm_p16_kernelILb1ELb0ELj257E": "gemm_p16_kernel<true, false, 257", "gemm_p16_kernelILb1ELb0ELj2311E": "gemm_p16_kernel<true, false, 2311",
              "gemm_p16_kernelILb1ELb0ELj113E": "gemm_p16_kernel<true, false, 113", "gemm_p16_kernelILb1ELb1ELj5384E": "gemm_p16_kernel<true, true, 5384",
-             "gemm_p16_kernelILb1ELb1ELj256E": "gemm_p16_kernel<true, true, 256"}
+             "gemm_p16_kernelILb1ELb1ELj256E": "gemm_p16_kernel<true, true, 256", "gemm_p16_kernelILb1ELb0ELj576E": "gemm_p16_kernel<true, false, 576"}
 
 
 def main():
