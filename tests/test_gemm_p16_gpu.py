@@ -282,3 +282,17 @@ def test_gemm_fp32_and_bf16_outputs_every_loop_at_step_size(mode):
             assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), f"mode {mode} {what}: not run-to-run identical"
     finally:
         ops.gemm_set_mainloop(prev)
+
+
+def test_gemm_p16_random_shapes():
+    """tools/probe/p16_fuzz.py: random tile counts, contraction lengths of every class (whole trips, + 4, + 8 k-tiles), layouts, leading
+    dimensions, split-K with an uneven last slice, output kinds -- against the fp32 product, nothing written outside the output columns."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "probe", "p16_fuzz.py")], env=dict(os.environ, CASES="120", SEED="11"),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    last = r.stdout.strip().splitlines()[-1]
+    assert last.endswith("0 bad") and int(last.split("cases,")[1].split("served")[0]) >= 60, last
