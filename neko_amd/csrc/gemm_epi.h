@@ -103,13 +103,19 @@ struct FastEpi {
 #endif
 typedef uint32_t epi_u32x2 __attribute__((ext_vector_type(2)));
 typedef float epi_f32x4 __attribute__((ext_vector_type(4)));
+// Policy 1 goes through the compiler's own non-temporal store (global_store_dwordx2 / x4 ... nt): hipcc then counts the stores in its
+// s_waitcnt vmcnt(N) bookkeeping and pads the wide-store data hazard itself.  The first version of this round issued them from inline asm:
+// (a) a 16-byte store reads its data registers for a few cycles after it issues and the next instruction overwrote them (wrong fp32 outputs
+// until wait states went behind the store), (b) stores the compiler cannot see make every later vmcnt wait for a prefetched epilogue input
+// also wait for the stores issued since -- their HBM acknowledgements -- which lengthened the residual / GELU' epilogues (16 -> 19 us per tile).
+// Policies 2 / 3 (sc1, sc0 sc1: A/B builds only) still use inline asm, with the wait states.
 __device__ __forceinline__ void epi_store8(void* dst, uint2 v) {
 #if NEKO_EPI_STORE_POLICY == 0
   *reinterpret_cast<uint2*>(dst) = v;
 #else
   const epi_u32x2 w = {v.x, v.y};
 #if NEKO_EPI_STORE_POLICY == 1
-  asm volatile("global_store_dwordx2 %0, %1, off nt" ::"v"(dst), "v"(w) : "memory");
+  __builtin_nontemporal_store(w, reinterpret_cast<epi_u32x2*>(dst));
 #elif NEKO_EPI_STORE_POLICY == 2
   asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(dst), "v"(w) : "memory");
 #else
@@ -117,17 +123,13 @@ __device__ __forceinline__ void epi_store8(void* dst, uint2 v) {
 #endif
 #endif
 }
-// (the s_nop: a VMEM store of more than 64 bits reads its data registers for a few cycles after it has issued, and the instruction
-// behind it may not overwrite them (the ISA's "store of more than 8 bytes followed by a write of its data VGPRs" wait states).  hipcc's
-// hazard recogniser pads its own stores but does not look inside inline asm: without the wait states the first dword of a float4 was
-// replaced by the next step's value in the hand-placed kernels' fp32 outputs -- tools/probe/gemm_determinism.py, tools/probe/resid_bug.py)
 __device__ __forceinline__ void epi_store16(void* dst, float4 v) {
 #if NEKO_EPI_STORE_POLICY_CF == 0
   *reinterpret_cast<float4*>(dst) = v;
 #else
   const epi_f32x4 w = {v.x, v.y, v.z, v.w};
 #if NEKO_EPI_STORE_POLICY_CF == 1
-  asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(dst), "v"(w) : "memory");
+  __builtin_nontemporal_store(w, reinterpret_cast<epi_f32x4*>(dst));
 #elif NEKO_EPI_STORE_POLICY_CF == 2
   asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(w) : "memory");
 #else
