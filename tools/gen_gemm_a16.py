@@ -364,9 +364,10 @@ def p16_last_piece(op, other):
     return max(range(len(d)), key=lambda pc: (d[pc], pc))
 
 
-def p16_loader(A, B, j, issue, sched, zero=None):
+def p16_loader(A, B, j, issue, sched, zero=None, skip=()):
     """L(j): the fragment reads of tile j (none in the prologue, j < 0: accumulator zeroing instead) and the DMA requests; an M0 write
-    may not sit directly in front of the LDS-DMA that uses it, so a read (or a zeroing move) goes between them"""
+    may not sit directly in front of the LDS-DMA that uses it, so a read (or a zeroing move) goes between them.  Units in `skip` were
+    requested by the early block (p16_early): only their bookkeeping (the source base moving on) stays"""
     reads = (B.reads(j, 0) + A.reads(j, 0)) if j >= 0 else []
     reqs = []
     for op, other in ((A, B), (B, A)):
@@ -386,6 +387,9 @@ def p16_loader(A, B, j, issue, sched, zero=None):
             return zero.pop(0)
         return "s_nop 0"
     for setm0, req, tag, adv in reqs:
+        if tag in skip:
+            lines += adv
+            continue
         lines += [setm0, filler(), req]
         issue.add(tag)
         lines += adv
@@ -409,6 +413,27 @@ def p16_wait(A, B, issue, j):
     return issue.wait_count(need)
 
 
+def p16_early(A, B, issue):
+    """The early block: the requests of the units that hold k-tile 0, as an asm statement of its own.  gemm_p16.hip issues it for a
+    workgroup's NEXT tile in front of the epilogue of the current one (the k-loop has ended behind a block barrier: the ring is free; the
+    epilogue's slabs keep clear of the two places these units land in), so that the first k-tile of every tile but a workgroup's first
+    is in LDS when its loop starts.  Loads return in order among loads: the loop's own counted waits see these requests as the
+    oldest ones whatever stores the epilogue has put between them and the rest of the prologue."""
+    E = ["s_nop 4", f"s_mov_b32 s{S_M0}, m0"]
+    for op in (A, B):
+        sg = S_G[op.w]
+        E += [f"s_mov_b32 s{sg}, %[g{op.w}lo]", f"s_mov_b32 s{sg + 1}, %[g{op.w}hi]"]
+    tags = []
+    for op in (A, B):
+        unit = op.unit_of_tile(0)
+        for setm0, req in op.pieces(unit):
+            E += [setm0, "s_nop 0", req]
+            issue.add((op.w, unit))
+        tags.append((op.w, unit))
+    E += [f"s_mov_b32 m0, s{S_M0}"]
+    return E, tuple(tags)
+
+
 def stream_p16(a_mode, b_mode, sched):
     A, B = Op("a", a_mode), Op("b", b_mode)
     trip = 12 if a_mode == "kc64" and A.nslot == 3 else 4
@@ -425,11 +450,12 @@ def stream_p16(a_mode, b_mode, sched):
                 L += [f"v_xor_b32 v{vb + t}, {t}, %[h{op.w}]", f"v_lshl_add_u32 v{vb + t}, v{vb + t}, 5, %[r{op.w}0]"]
     zero = [f"v_accvgpr_write_b32 a{i}, 0" for i in range(4 * G.nm)]
     issue = Issue()
+    E, skip = p16_early(A, B, issue) if sched.get("p16_early") else ([], ())
     # prologue: what L(-7) .. L(-1) would have requested, in that order (accumulators zeroed underneath)
     need0 = {("a", A.unit_of_tile(0)), ("b", B.unit_of_tile(0))}
     early = False
     for j in range(-7, 0):
-        L += p16_loader(A, B, j, issue, dict(sched, p16_reads_per_piece=4), zero)
+        L += p16_loader(A, B, j, issue, dict(sched, p16_reads_per_piece=4), zero, skip)
         if sched["p16_early_wait"] and not early and all(t in issue.log for t in need0):
             # --p16-early-wait: tile 0's units land before the rest of the prologue is requested (every CU of the chip is in its
             # prologue at the same time: ~160 KB per CU requested at once delay the 48 KB the first k-tile needs)
@@ -479,10 +505,10 @@ def stream_p16(a_mode, b_mode, sched):
     # surplus DMA landed, surplus fragment reads returned, accumulators readable
     L += ["s_waitcnt vmcnt(0)", "s_waitcnt lgkmcnt(0)", "s_nop 15", "s_nop 15", "s_barrier", f"s_mov_b32 m0, s{S_M0}"]
     check_scc(L)
-    return ablate(L), [counts[j] for j in range(trip, 2 * trip)], n0, trip
+    return ablate(L), [counts[j] for j in range(trip, 2 * trip)], n0, trip, E
 
 
-SCHED_P16 = {"p16_reads_first": 0, "p16_reads_per_piece": 2, "p16_setprio": True, "p16_b1": True, "p16_early_wait": False}
+SCHED_P16 = {"p16_reads_first": 0, "p16_reads_per_piece": 2, "p16_setprio": True, "p16_b1": True, "p16_early_wait": False, "p16_early": False}
 
 
 def main_p16(args):
@@ -495,6 +521,7 @@ def main_p16(args):
     sched["p16_setprio"] = not args.p16_no_setprio
     sched["p16_b1"] = not args.p16_no_b1
     sched["p16_early_wait"] = args.p16_early_wait
+    sched["p16_early"] = args.p16_early
     G.nslot["a"] = args.p16_nslot_a
     kcb = f"kc{args.p16_kcb}"
     # per-piece delays (load segments after the one that follows the freeing tile): next to a ring operand (2 requests per segment) A's
@@ -511,12 +538,18 @@ def main_p16(args):
            f"#define NEKO_P16_TRIP_KC {12 if args.p16_nslot_a == 3 else 4}      // k-tiles per loop trip with a k-contiguous A operand", ""]
     for a_kc, b_kc in ((True, False), (True, True), (False, False)):
         name = f"NEKO_P16_LOOP_{'KC' if a_kc else 'KS'}_{'KC' if b_kc else 'KS'}"
-        L, counts, n0, trip = stream_p16("kc64" if a_kc else "ks", kcb if b_kc else "ks", sched)
+        L, counts, n0, trip, E = stream_p16("kc64" if a_kc else "ks", kcb if b_kc else "ks", sched)
         txt.append(f"// {name}: {trip} k-tiles per loop trip; vmcnt at the prologue wait {n0}, in front of B0 of the tiles of a trip {counts}")
         txt.append(f"#define {name} \\")
         txt += [f'  "{ins}\\n\\t" \\' for ins in L[:-1]]
         txt.append(f'  "{L[-1]}"')
         txt.append("")
+        if E:
+            txt.append(f"// {name.replace('LOOP', 'EARLY')}: the requests of k-tile 0's units (the loop above starts behind them)")
+            txt.append(f"#define {name.replace('LOOP', 'EARLY')} \\")
+            txt += [f'  "{ins}\\n\\t" \\' for ins in E[:-1]]
+            txt.append(f'  "{E[-1]}"')
+            txt.append("")
     txt.append(f"#define NEKO_P16_CLOBBERS {clobbers()}")
     txt.append("")
     open(out, "w").write("\n".join(txt))
@@ -544,6 +577,7 @@ def main():
     ap.add_argument("--p16-kcb", type=int, default=64, choices=(32, 64), help="p16: a k-contiguous B in two 64-k slots of whole lines (default) or in the 32-k ring")
     ap.add_argument("--p16-nslot-a", type=int, default=3, choices=(2, 3), help="p16: 64-k slots of a k-contiguous A operand (2: four k-tiles per loop trip, any K % 128 == 0)")
     ap.add_argument("--p16-no-b1", action="store_true", help="p16: no barrier between a half's matrix segment and the other half's (one barrier per k-tile)")
+    ap.add_argument("--p16-early", action="store_true", help="p16 experiment (tools/probe/p16_tile_walk_early_block.patch, measured level): k-tile 0's requests as a statement of their own")
     ap.add_argument("--p16-early-wait", action="store_true", help="p16: the prologue waits for tile 0's units before it requests the rest")
     ap.add_argument("--p16-no-setprio", action="store_true", help="p16: no static s_setprio 1 on the second half (A/B runs)")
     ap.add_argument("--p16-no-spread", action="store_true", help="p16: a slot's four requests in ONE load segment (A/B runs)")
