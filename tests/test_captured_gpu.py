@@ -136,7 +136,7 @@ def test_eager_path_is_untouched_after_close():
     m2 = _policy(0.0)
     m2.load_state_dict(m.state_dict())
     _, l2 = m2.forward(inputs=b, compute_loss=True, return_logits=False)
-    assert abs(float(l1) - float(l2)) < 2e-6 * abs(float(l2))
+    assert abs(float(l1.detach()) - float(l2.detach())) < 2e-6 * abs(float(l2.detach()))
 
 
 def test_train_py_with_capture_step(tmp_path, monkeypatch):
